@@ -1,0 +1,169 @@
+/*
+ * uresnet_hip.h -- C-ABI of the MI355X-native U-ResNet forward/backward hot path.
+ *
+ * The reference (DeepLearnPhysics/u-resnet) has no FFI: the path sits behind a Python
+ * class protocol (lib/ssnet.py ssnet_base) whose methods each issue one tf.Session.run
+ * fetch-set.  This header declares one entry point per fetch-set plus lifecycle, so a
+ * Python 3 `ssnet_base` (u-resnet_amd/ssnet.py) binds them with ctypes and keeps the
+ * reference surface.  Citations are file:line relative to the reference tree.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; ursn_last_error() gives text;
+ *   - all tensor pointers are DEVICE pointers (hipMalloc'd or torch tensor.data_ptr());
+ *     the caller owns every buffer it passes in, the library owns only the host-side handle;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - layouts follow the reference: activations N(D)HWC row-major (lib/ssnet.py:34-40),
+ *     conv filters [k..,Cin,Cout], transposed-conv filters [k..,Cout,Cin];
+ *   - one handle per GPU; calls on a handle are serialised by the caller (the reference
+ *     issues all sess.run calls from one thread, lib/ssnet_trainval.py:156-233).
+ */
+#ifndef URESNET_HIP_H
+#define URESNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define URSN_ABI_VERSION 1
+
+typedef struct ursn_net ursn_net; /* opaque */
+
+/* Mirrors uresnet.__init__ (lib/uresnet.py:15-20) + ssnet_base.construct (lib/ssnet.py:20-24). */
+typedef struct ursn_config {
+  int32_t ndim;          /* 2 (H,W,C) or 3 (H,W,D,C): len(dims)-1, lib/ssnet.py:11-14            */
+  int32_t spatial[3];    /* dims[:-1]; spatial[2] unused for ndim==2; each divisible by 2^strides */
+  int32_t cin;           /* dims[-1]                                                              */
+  int32_t base_filters;  /* base_num_outputs, lib/uresnet.py:18                                   */
+  int32_t num_class;     /* lib/ssnet.py:15                                                       */
+  int32_t num_strides;   /* lib/uresnet.py:19 (reference fixes 5)                                 */
+  int32_t max_batch;     /* largest N any call will pass (placeholder dim is None in the ref)     */
+  int32_t trainable;     /* construct(trainable=...): allocate the backward workspace             */
+  int32_t use_weight;    /* construct(use_weight=...), lib/ssnet.py:68-69                         */
+  float bn_eps;          /* slim.batch_norm epsilon (default 1e-3)                                */
+} ursn_config;
+
+typedef struct ursn_sizes {
+  int64_t n_params;        /* trainable floats (weights + BN beta), TF variable order             */
+  int64_t n_tensors;       /* number of trainable variables (2 per conv-like layer)               */
+  int64_t n_layers;        /* conv-like layers (58 for num_strides=5)                             */
+  int64_t workspace_bytes; /* device bytes for activations / stashes / scratch at max_batch       */
+} ursn_sizes;
+
+typedef struct ursn_param_info {
+  char name[128];      /* TF variable name, e.g. "UResNet/conv0/weights"                          */
+  int64_t offset;      /* float offset inside the flat parameter / gradient buffers              */
+  int64_t nelem;
+  int32_t rank;
+  int32_t shape[5];
+} ursn_param_info;
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+int ursn_abi_version(void);
+const char* ursn_last_error(void);
+
+/* Size query; no device access. */
+int ursn_query(const ursn_config* cfg, ursn_sizes* out);
+
+/* Replaces graph construction (lib/ssnet.py:20-89 + lib/uresnet.py:22-123).  The four flat
+ * fp32 buffers (n_params floats each) and the workspace are caller-owned device memory;
+ * `grads` is the accum_vars set (lib/ssnet.py:53-55), adam_m/adam_v the Adam slots.
+ * grads/adam_m/adam_v may be NULL when cfg->trainable == 0. */
+int ursn_create(const ursn_config* cfg, float* params, float* grads, float* adam_m, float* adam_v,
+                void* workspace, size_t workspace_bytes, ursn_net** out);
+int ursn_destroy(ursn_net* net);
+int ursn_get_sizes(const ursn_net* net, ursn_sizes* out);
+int ursn_param(const ursn_net* net, int64_t index, ursn_param_info* out);
+
+/* ---- the fetch-sets of lib/ssnet.py:91-139 --------------------------------------------- */
+/* zero_gradients (lib/ssnet.py:99-101). */
+int ursn_zero_grad(ursn_net* net, void* stream);
+
+/* accum_gradients (lib/ssnet.py:103-115): forward + loss + backward, gradients ADDED into
+ * `grads` (assign_add, :77).  data [N,prod(dims)], label/weight [N,prod(dims[:-1])] fp32 (label
+ * values are class indices stored as float, :32,40).  weight may be NULL iff use_weight==0.
+ * If out3 != NULL the call synchronises the stream and writes {loss, acc_all, acc_nonzero};
+ * if NULL it only enqueues (metrics stay on the device, see ursn_read_metrics). */
+int ursn_accum_step(ursn_net* net, const float* data, const float* label, const float* weight,
+                    int32_t n, float* out3, void* stream);
+
+/* apply_gradients (lib/ssnet.py:117-119): TF-form Adam on the accumulated gradients.
+ * lr<=0 selects the TF default 1e-3 (lib/ssnet.py:72-75). The step counter is kept in the handle. */
+int ursn_apply_adam(ursn_net* net, float lr, void* stream);
+
+/* run_test (lib/ssnet.py:121-128): forward + {loss, acc_all, acc_nonzero}, no gradients. */
+int ursn_eval(ursn_net* net, const float* data, const float* label, const float* weight, int32_t n,
+              float* out3, void* stream);
+
+/* inference (lib/ssnet.py:130-139): softmax_out [N,*spatial,num_class]; if label != NULL also
+ * out2 = {acc_all, acc_nonzero}.  Always synchronises. */
+int ursn_infer(ursn_net* net, const float* data, const float* label, int32_t n, float* softmax_out,
+               float* out2, void* stream);
+
+/* Metrics of the last accum/eval call: synchronises, writes {loss, acc_all, acc_nonzero}. */
+int ursn_read_metrics(ursn_net* net, float* out3, void* stream);
+
+/* Adam step counter access (checkpoint / tests). */
+int ursn_get_adam_step(const ursn_net* net, int64_t* t);
+int ursn_set_adam_step(ursn_net* net, int64_t t);
+
+/* Debug/parity: device pointer + channel stride of a named internal tensor of the last forward.
+ * name = TF scope ("UResNet/conv0", ".../module1") optionally suffixed ":z" (raw conv output). */
+int ursn_tensor(const ursn_net* net, const char* name, float** ptr, int64_t* voxels, int32_t* channels,
+                int32_t* cstride);
+
+/* ---- op-level entry points (unit parity tests; same kernels the net-level calls use) ----- */
+typedef struct ursn_conv_desc {
+  int32_t ndim;        /* 2 or 3                                                                   */
+  int32_t n;           /* batch                                                                    */
+  int32_t in_sp[3];    /* input spatial dims                                                       */
+  int32_t cin, cout;
+  int32_t k;           /* 1 or 3                                                                   */
+  int32_t stride;      /* 1 or 2                                                                   */
+  int32_t transposed;  /* 0: slim.conv{2,3}d SAME; 1: slim.conv{2,3}d_transpose k3 s2 SAME          */
+  int32_t in_cstride;  /* channel stride (floats per voxel) of x / dx; 0 = compact (= cin)         */
+  int32_t out_cstride; /* channel stride of y / dy; 0 = compact (= cout)                           */
+  int32_t algo;        /* 0 auto, 1 naive reference kernel, 2 generic MFMA, 3 tiled small-C MFMA   */
+} ursn_conv_desc;
+
+/* y = conv(x, w).  w layout [k..,Cin,Cout] (transposed: [k..,Cout,Cin]). */
+int ursn_conv_forward(const ursn_conv_desc* d, const float* x, const float* w, float* y, void* stream);
+/* dx (=|+=) conv^T(dy, w); accumulate != 0 adds into dx. */
+int ursn_conv_backward_data(const ursn_conv_desc* d, const float* dy, const float* w, float* dx,
+                            int32_t accumulate, void* stream);
+/* dw += x (*) dy.  scratch: device buffer of ursn_conv_wgrad_scratch_bytes(d) bytes. */
+int ursn_conv_backward_weight(const ursn_conv_desc* d, const float* x, const float* dy, float* dw,
+                              void* scratch, size_t scratch_bytes, void* stream);
+size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d);
+
+/* Batch-statistics BatchNorm (beta only) + optional residual + optional ReLU:
+ * y = act((z-mu)*rsqrt(var+eps)+beta [+ res]); stats_out (optional) gets {mean[C], rstd[C]} as fp32. */
+int ursn_bn_forward(const float* z, const float* beta, const float* res, float* y, int64_t voxels,
+                    int32_t channels, float eps, int32_t relu, float* stats_out, void* scratch,
+                    size_t scratch_bytes, void* stream);
+/* dz = BN backward of g = dy * (relu ? y>0 : 1); dbeta += sum g. */
+int ursn_bn_backward(const float* dy, const float* y, const float* z, float* dz, float* dbeta,
+                     int64_t voxels, int32_t channels, float eps, int32_t relu, void* scratch,
+                     size_t scratch_bytes, void* stream);
+size_t ursn_bn_scratch_bytes(int64_t voxels, int32_t channels);
+
+/* Fused head (lib/ssnet.py:57-71): softmax / weighted CE / accuracies / dlogits.
+ * logits [n*pix, ncls]; data [n*pix] (cin==1); out3 = {loss, acc_all, acc_nonzero};
+ * softmax_out, dlogits may be NULL. Synchronises. */
+int ursn_softmax_ce(const float* logits, const float* data, const float* label, const float* weight,
+                    int32_t n, int64_t pix, int32_t ncls, float* softmax_out, float* dlogits,
+                    float* out3, void* scratch, size_t scratch_bytes, void* stream);
+
+/* TF-form Adam on a flat buffer: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps). */
+int ursn_adam(float* p, const float* g, float* m, float* v, int64_t nelem, float lr, float b1, float b2,
+              float eps, int64_t t, void* stream);
+
+/* MFMA lane-layout probe used by tests (writes 64*16 floats). */
+int ursn_mfma_probe(int32_t which, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* URESNET_HIP_H */

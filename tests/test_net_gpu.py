@@ -1,0 +1,119 @@
+"""Net-level parity through the reference plugin surface (uresnet / ssnet_base run methods) against
+the numpy fp64 oracle with injected weights.  PARITY UNPINNED (oracle/__init__.py).
+
+Tolerances (north_star): per-pixel class labels bit-exact wherever the oracle's top-2 logit margin
+exceeds 1e-3, softmax/logits within 1e-3 relative; gradients within 2e-3 of each tensor's max."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import uresnet_np as O
+from _net import make_inputs, max_rel, oracle_params
+from uresnet_amd import uresnet
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # dims, base filters, classes, batch, use_weight
+    ((64, 64, 1), 4, 3, 2, False),     # train2d.cfg shape class (USE_WEIGHTS False), reduced
+    ((32, 32, 32, 1), 4, 3, 2, True),  # train3d.cfg shape class, reduced; 1^3 bottleneck
+    ((64, 64, 64, 1), 4, 3, 1, True),
+    ((64, 96, 1), 8, 5, 3, True),      # 5 classes, non-square
+]
+
+
+def build(dims, base, ncls, use_weight, trainable=True, lr=None):
+    net = uresnet(dims=list(dims), num_class=ncls, base_num_outputs=base)
+    net.construct(trainable=trainable, use_weight=use_weight, learning_rate=lr)
+    return net
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_accum_gradients_parity(case):
+    dims, base, ncls, N, use_w = case
+    P = oracle_params(dims, base, ncls)
+    data, label, weight = make_inputs(dims, ncls, N, seed=3)
+    g_ref, m = O.step_gradients(P, dims, base, data, label, weight if use_w else None, keep_acts=True)
+
+    net = build(dims, base, ncls, use_w)
+    net.set_variables(P)
+    net.zero_gradients(None)
+    res, doc = net.accum_gradients(None, data, label, weight if use_w else None)
+    assert doc == ['', 'loss', 'acc. all', 'acc. nonzero']
+    assert abs(res[1] - m["loss"]) <= 1e-4 * abs(m["loss"])
+    # forward tensors
+    z0 = net.debug_tensor("UResNet/conv0:z")
+    assert max_rel(z0, m["acts"]["UResNet/conv0:z"]) < 1e-5
+    for name in ["UResNet/conv0", "UResNet/resnet_module0/module1", "UResNet/resnet_module4/module2",
+                 "UResNet/deconv0", "UResNet/resnet_module9/module2", "UResNet/conv1"]:
+        assert max_rel(net.debug_tensor(name), m["acts"][name]) < 1e-3, name
+    # labels: exact where the oracle margin is not a near-tie
+    zl = net.debug_tensor("UResNet/conv2:z")
+    zr = m["acts"]["UResNet/conv2:z"]
+    assert max_rel(zl, zr) < 1e-3
+    sm = net.inference(None, data)[0]
+    assert max_rel(sm, m["softmax"]) < 1e-3
+    srt = np.sort(m["logits"], axis=-1)
+    safe = (srt[..., -1] - srt[..., -2]) > 1e-3
+    assert safe.mean() > 0.95
+    assert np.array_equal(sm.argmax(-1)[safe], m["pred"][safe])
+    n_unsafe = int((~safe).sum())
+    assert abs(res[2] - m["acc_all"]) <= (n_unsafe + 0.5) / safe.size
+    # gradients
+    g = net.get_gradients()
+    worst = max((max_rel(g[k], g_ref[k]), k) for k in g_ref if np.abs(g_ref[k]).max() > 1e-12)
+    assert worst[0] < 2e-3, worst
+    # accumulation is a SUM (lib/ssnet.py:77)
+    net.accum_gradients(None, data, label, weight if use_w else None)
+    g2 = net.get_gradients()
+    assert max(max_rel(g2[k], 2 * g[k]) for k in g if np.abs(g[k]).max() > 1e-12) < 1e-5
+
+
+def test_train_steps_match_oracle():
+    """zero -> accumulate over NUM_MINIBATCHES=2 -> TF-form Adam apply, three iterations
+    (lib/ssnet_trainval.py:164-191)."""
+    dims, base, ncls, N = (32, 32, 32, 1), 4, 3, 2
+    P = oracle_params(dims, base, ncls)
+    net = build(dims, base, ncls, True, lr=1e-3)
+    net.set_variables(P)
+    opt = O.Adam(P, lr=1e-3)
+    for it in range(3):
+        mbs = [make_inputs(dims, ncls, N, seed=100 + 2 * it + j) for j in range(2)]
+        ref_metrics, _ = O.train_step(P, opt, dims, base, mbs, use_weight=True)
+        net.zero_gradients(None)
+        got = []
+        for d, l, w in mbs:
+            res, _ = net.accum_gradients(None, d, l, w)
+            got.append(res[1:])
+        net.apply_gradients(None)
+        got = np.mean(np.array(got), axis=0)
+        assert abs(got[0] - ref_metrics[0]) < 2e-3 * abs(ref_metrics[0])
+        assert abs(got[1] - ref_metrics[1]) < 5e-3
+    V = net.get_variables()
+    # Adam normalises the step to ~lr per element, so compare the parameter *update* loosely and the
+    # parameters tightly.
+    worst = max((np.abs(V[k] - P[k]).max(), k) for k in P)
+    assert worst[0] < 5e-4, worst
+
+
+def test_run_test_and_inference_contract():
+    dims, base, ncls, N = (64, 64, 1), 4, 3, 2
+    net = build(dims, base, ncls, True, trainable=True)
+    data, label, weight = make_inputs(dims, ncls, N, seed=9)
+    res, doc = net.run_test(None, data, label, weight)
+    assert doc == ['loss', 'acc. all', 'acc. nonzero'] and len(res) == 3
+    out = net.inference(None, data, label)
+    assert out[0].shape == (N, 64, 64, ncls) and out[0].dtype == np.float32
+    assert np.allclose(out[0].sum(-1), 1.0, atol=1e-5)
+    assert abs(out[1] - res[1]) < 1e-6 and abs(out[2] - res[2]) < 1e-6
+    assert len(net.inference(None, data)) == 1
+    with pytest.raises(TypeError):  # lib/ssnet.py:143-145
+        net.run_test(None, data, label, None)
+
+
+def test_ana_mode_net_is_not_trainable():
+    net = build((64, 64, 1), 4, 3, False, trainable=False)
+    data, label, _ = make_inputs((64, 64, 1), 3, 1, seed=1)
+    assert net.inference(None, data, label)[0].shape == (1, 64, 64, 3)
+    with pytest.raises(RuntimeError):
+        net.accum_gradients(None, data, label)

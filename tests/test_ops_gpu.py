@@ -1,0 +1,221 @@
+"""Op-level parity: every HIP kernel family against the numpy fp64 oracle (PARITY UNPINNED: the
+oracle is a restatement, see oracle/__init__.py).  Tolerances: fp32 accumulation over at most a
+few thousand terms -> 2e-5 relative to the tensor's max magnitude."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import uresnet_np as O
+from _ops import (P, conv_backward_data, conv_backward_weight, conv_forward, desc, dev, rel_err, stream)
+from uresnet_amd import _lib
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+CONV_CASES = [
+    # ndim, N, S, cin, cout, k, stride
+    (3, 2, (8, 12, 16), 8, 8, 3, 1),
+    (3, 1, (8, 8, 8), 1, 8, 3, 1),
+    (3, 2, (8, 8, 16), 8, 3, 3, 1),
+    (3, 2, (8, 12, 16), 8, 16, 3, 2),
+    (3, 2, (8, 12, 16), 8, 16, 1, 2),
+    (3, 2, (6, 6, 6), 32, 16, 1, 1),
+    (3, 1, (6, 6, 6), 64, 64, 3, 1),
+    (3, 2, (2, 2, 2), 128, 256, 3, 2),
+    (3, 1, (1, 1, 1), 16, 16, 3, 1),
+    (2, 2, (16, 24), 16, 16, 3, 1),
+    (2, 3, (16, 16), 16, 32, 3, 2),
+    (2, 2, (16, 16), 1, 16, 3, 1),
+    (2, 2, (8, 8), 16, 5, 3, 1),
+    (2, 2, (4, 4), 256, 512, 3, 2),
+    (2, 1, (8, 8), 32, 16, 1, 1),
+    (3, 1, (4, 10, 20), 12, 20, 3, 1),   # channel counts that are not powers of two
+]
+
+
+def _rand(rng, shape):
+    return rng.standard_normal(shape)
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case, algo):
+    ndim, N, S, ci, co, k, s = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (k,) * ndim + (ci, co)) * 0.2
+    y = O.conv_fwd(x, w, s)
+    dy = _rand(rng, y.shape)
+    dx, dw = O.conv_bwd(x, w, s, dy)
+    d = desc(ndim, N, S, ci, co, k, s, algo=algo)
+    xg, wg, dyg = dev(x), dev(w), dev(dy)
+    yg = conv_forward(d, xg, wg, y.shape)
+    assert rel_err(yg.cpu().numpy(), y) < TOL
+    dxg = conv_backward_data(d, dyg, wg, x.shape)
+    assert rel_err(dxg.cpu().numpy(), dx) < TOL
+    # accumulate mode adds onto existing contents
+    base = torch.ones(x.shape, dtype=torch.float32, device="cuda")
+    dxa = conv_backward_data(d, dyg, wg, x.shape, accumulate=1, dx_init=base)
+    assert rel_err(dxa.cpu().numpy(), dx + 1.0) < TOL
+    dwg = conv_backward_weight(d, xg, dyg, w.shape)
+    assert rel_err(dwg.cpu().numpy(), dw) < 5e-5
+    # dw accumulates (assign_add semantics)
+    dwa = conv_backward_weight(d, xg, dyg, w.shape, dw_init=dwg)
+    assert rel_err(dwa.cpu().numpy(), 2 * dw) < 5e-5
+
+
+DECONV_CASES = [
+    (3, 2, (4, 6, 8), 16, 8),
+    (3, 1, (1, 1, 1), 32, 16),
+    (3, 2, (2, 2, 2), 256, 128),
+    (2, 2, (8, 8), 32, 16),
+    (2, 1, (2, 2), 512, 256),
+]
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("case", DECONV_CASES)
+def test_deconv_fwd_bwd(case, algo):
+    ndim, N, S, ci, co = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (3,) * ndim + (co, ci)) * 0.2
+    y = O.deconv_fwd(x, w)
+    dy = _rand(rng, y.shape)
+    dx, dw = O.deconv_bwd(x, w, dy)
+    d = desc(ndim, N, S, ci, co, 3, 2, transposed=1, algo=algo)
+    xg, wg, dyg = dev(x), dev(w), dev(dy)
+    assert rel_err(conv_forward(d, xg, wg, y.shape).cpu().numpy(), y) < TOL
+    assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
+    assert rel_err(conv_backward_weight(d, xg, dyg, w.shape).cpu().numpy(), dw) < 5e-5
+
+
+def test_conv_channel_strides():
+    """Concat-free buffers: input read from / output written into channel slices of wider tensors."""
+    rng = np.random.default_rng(5)
+    N, S, ci, co = 2, (4, 6, 8), 8, 8
+    xfull = _rand(rng, (N,) + S + (16,))
+    w = _rand(rng, (3, 3, 3, ci, co)) * 0.2
+    x = xfull[..., 8:]
+    y = O.conv_fwd(x, w, 1)
+    d = desc(3, N, S, ci, co, 3, 1, in_cs=16, out_cs=24, algo=2)
+    xg = dev(xfull)
+    yfull = torch.zeros((N,) + S + (24,), dtype=torch.float32, device="cuda")
+    lib = _lib.load()
+    xoff = ctypes.c_void_p(xg.data_ptr() + 8 * 4)
+    yoff = ctypes.c_void_p(yfull.data_ptr() + 4 * 4)
+    _lib.check(lib.ursn_conv_forward(ctypes.byref(d), xoff, P(dev(w)), yoff, stream()))
+    torch.cuda.synchronize()
+    got = yfull.cpu().numpy()
+    assert rel_err(got[..., 4:12], y) < TOL
+    assert np.all(got[..., :4] == 0) and np.all(got[..., 12:] == 0)
+
+
+@pytest.mark.parametrize("C,relu,res", [(8, 1, False), (16, 1, True), (3, 0, False), (64, 0, True), (12, 1, False)])
+def test_bn_forward_backward(C, relu, res):
+    rng = np.random.default_rng(C)
+    V = 4 * 6 * 10 * 3
+    z = _rand(rng, (V, C)) * 2.0 + 0.5
+    beta = _rand(rng, (C,)) * 0.3
+    r = _rand(rng, (V, C)) if res else None
+    y, cache = O.bn_fwd(z, beta)
+    if res:
+        y = y + r
+    if relu:
+        y = np.maximum(y, 0)
+    lib = _lib.load()
+    nb = lib.ursn_bn_scratch_bytes(V, C)
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    zg, bg = dev(z), dev(beta)
+    rg = dev(r) if res else None
+    yg = torch.empty((V, C), dtype=torch.float32, device="cuda")
+    st = torch.empty(2 * C, dtype=torch.float32, device="cuda")
+    _lib.check(lib.ursn_bn_forward(P(zg), P(bg), P(rg), P(yg), V, C, 1e-3, relu, P(st), P(scratch), nb, stream()))
+    torch.cuda.synchronize()
+    assert rel_err(yg.cpu().numpy(), y) < 1e-5
+    assert rel_err(st.cpu().numpy()[C:], cache[1]) < 1e-5
+    dy = _rand(rng, (V, C))
+    g = dy * (y > 0) if relu else dy
+    dz, dbeta = O.bn_bwd(cache, g)
+    dzg = torch.empty((V, C), dtype=torch.float32, device="cuda")
+    dbg = torch.zeros(C, dtype=torch.float32, device="cuda")
+    _lib.check(lib.ursn_bn_backward(P(dev(dy)), P(yg), P(zg), P(dzg), P(dbg), V, C, 1e-3, relu, P(scratch), nb,
+                                    stream()))
+    torch.cuda.synchronize()
+    assert rel_err(dzg.cpu().numpy(), dz) < 2e-5
+    assert rel_err(dbg.cpu().numpy(), dbeta) < 2e-5
+
+
+@pytest.mark.parametrize("ncls,use_w", [(3, True), (5, False), (3, False)])
+def test_softmax_ce_head(ncls, use_w):
+    rng = np.random.default_rng(ncls)
+    n, pix = 3, 500
+    logits = _rand(rng, (n, pix, ncls)) * 3
+    logits[0, :7] = 1.25  # exact ties -> argmax must return the lowest index
+    data = rng.uniform(0, 1, (n, pix)) * (rng.uniform(0, 1, (n, pix)) > 0.6)
+    label = rng.integers(0, ncls, (n, pix)).astype(np.float64)
+    w = rng.uniform(0.1, 2, (n, pix)) if use_w else None
+    m = O.loss_and_metrics(logits, data, label, w)
+    lib = _lib.load()
+    scratch = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    sm = torch.empty((n, pix, ncls), dtype=torch.float32, device="cuda")
+    dl = torch.empty((n, pix, ncls), dtype=torch.float32, device="cuda")
+    out = (ctypes.c_float * 3)()
+    _lib.check(lib.ursn_softmax_ce(P(dev(logits)), P(dev(data)), P(dev(label)), P(dev(w)) if use_w else None, n, pix,
+                                   ncls, P(sm), P(dl), out, P(scratch), 1 << 20, stream()))
+    assert abs(out[0] - m["loss"]) / abs(m["loss"]) < 1e-5
+    assert abs(out[1] - m["acc_all"]) < 1e-6
+    assert abs(out[2] - m["acc_nonzero"]) < 1e-6
+    assert rel_err(sm.cpu().numpy(), m["softmax"]) < 1e-5
+    assert rel_err(dl.cpu().numpy(), m["dlogits"]) < 1e-5
+
+
+def test_head_no_nonzero_pixels_gives_nan():
+    lib = _lib.load()
+    n, pix, ncls = 1, 64, 3
+    scratch = torch.empty(1 << 16, dtype=torch.uint8, device="cuda")
+    out = (ctypes.c_float * 3)()
+    z = torch.zeros((n, pix, ncls), device="cuda")
+    _lib.check(lib.ursn_softmax_ce(P(z), P(torch.zeros(n, pix, device="cuda")), P(torch.zeros(n, pix, device="cuda")),
+                                   None, n, pix, ncls, None, None, out, P(scratch), 1 << 16, stream()))
+    assert np.isnan(out[2]) and out[1] == 1.0 and abs(out[0] - pix * np.log(3)) < 1e-3
+
+
+def test_adam_tf_form():
+    rng = np.random.default_rng(0)
+    n = 10007
+    p = {"a": rng.standard_normal(n)}
+    opt = O.Adam(p, lr=1e-3)
+    pg, mg, vg = dev(p["a"]), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    lib = _lib.load()
+    for t in range(1, 4):
+        g = rng.standard_normal(n) * 10.0 ** rng.integers(-6, 2, n)
+        opt.apply(p, {"a": g})
+        _lib.check(lib.ursn_adam(P(pg), P(dev(g)), P(mg), P(vg), n, 1e-3, 0.9, 0.999, 1e-8, t, stream()))
+    torch.cuda.synchronize()
+    assert rel_err(pg.cpu().numpy(), p["a"]) < 1e-6
+
+
+def test_mfma_probe_layouts():
+    """Pins the lane layouts the kernels assume (v_mfma_f32_16x16x4_f32 documented in the CDNA4
+    guide; v_mfma_f32_4x4x1_16b_f32 incl. cbsz/abid broadcast decoded here)."""
+    lib = _lib.load()
+    out = torch.zeros(256, dtype=torch.float32, device="cuda")
+    res = {}
+    for which in range(1, 7):
+        _lib.check(lib.ursn_mfma_probe(which, P(out), stream()))
+        torch.cuda.synchronize()
+        res[which] = out.cpu().numpy().reshape(64, 4).copy()
+    lane = np.arange(64)
+    # 16x16x4: D row = 4*(lane>>4)+reg, col = lane&15
+    assert np.array_equal(res[5], (1 + 4 * (lane[:, None] >> 4) + np.arange(4)[None, :]) * 33825.0)
+    assert np.array_equal(res[6], np.repeat((1 + (lane & 15))[:, None], 4, 1) * 33825.0)
+    # 4x4x1 (16 blocks): block = lane>>2; D[i=reg][j=lane&3] = A[i]*B[j]
+    assert np.array_equal(res[1], (4 * (lane[:, None] >> 2) + np.arange(4)[None, :] + 1).astype(np.float32))
+    assert np.array_equal(res[2], np.repeat((lane + 1)[:, None], 4, 1).astype(np.float32))
+    # cbsz=4, abid=3: every block uses A of block 3 (lanes 12..15)
+    assert np.array_equal(res[3], np.repeat((12 + np.arange(4) + 1)[None, :], 64, 0).astype(np.float32))
+    # cbsz=2, abid=1: blocks 4g..4g+3 use A of block 4g+1
+    assert np.array_equal(res[4], (4 * (4 * (lane[:, None] >> 4) + 1) + np.arange(4)[None, :] + 1).astype(np.float32))

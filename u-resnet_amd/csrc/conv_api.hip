@@ -1,0 +1,355 @@
+// Geometry construction (TF SAME semantics) and the op-level C-ABI.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ursn_common.h"
+
+static thread_local char g_err[1024] = "";
+void ursn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* ursn_last_error(void) { return g_err; }
+extern "C" int ursn_abi_version(void) { return URSN_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// Spatial axes are padded to 3 with a leading unit axis for 2-D problems.
+// ---------------------------------------------------------------------------------------------
+struct Dims3 {
+  int in[3], out[3], kd[3], pb[3];
+};
+
+static int make_dims(const ursn_conv_desc& d, Dims3& D) {
+  URSN_REQUIRE(d.ndim == 2 || d.ndim == 3, "conv: ndim %d not in {2,3}", d.ndim);
+  URSN_REQUIRE(d.k == 1 || d.k == 3, "conv: kernel %d not in {1,3}", d.k);
+  URSN_REQUIRE(d.stride == 1 || d.stride == 2, "conv: stride %d not in {1,2}", d.stride);
+  URSN_REQUIRE(!d.transposed || (d.k == 3 && d.stride == 2), "conv_transpose: only k3 s2 supported");
+  URSN_REQUIRE(d.cin >= 1 && d.cout >= 1 && d.n >= 1, "conv: bad channel/batch counts");
+  int lead = 3 - d.ndim;
+  for (int j = 0; j < 3; ++j) {
+    if (j < lead) {
+      D.in[j] = D.out[j] = 1;
+      D.kd[j] = 1;
+      D.pb[j] = 0;
+      continue;
+    }
+    int sz = d.in_sp[j - lead];
+    URSN_REQUIRE(sz >= 1, "conv: bad spatial size");
+    D.in[j] = sz;
+    D.kd[j] = d.k;
+    if (d.transposed) {
+      D.out[j] = 2 * sz;
+      D.pb[j] = 0;
+    } else {
+      int o = (sz + d.stride - 1) / d.stride;
+      int tot = (o - 1) * d.stride + d.k - sz;
+      if (tot < 0) tot = 0;
+      D.out[j] = o;
+      D.pb[j] = tot / 2;
+    }
+  }
+  return 0;
+}
+
+static void geom_common(GatherGeom& g, const ursn_conv_desc& d) {
+  memset(&g, 0, sizeof(g));
+  g.N = d.n;
+  for (int j = 0; j < 3; ++j) {
+    g.so[j] = 1;
+    g.si[j] = 1;
+  }
+}
+
+int build_geoms(const ursn_conv_desc& d, ConvPass pass, GatherGeom* out8) {
+  Dims3 D;
+  if (make_dims(d, D)) return -1;
+  const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin;
+  const int ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+  const int ntap_all = D.kd[0] * D.kd[1] * D.kd[2];
+  const bool gather_type = (!d.transposed && pass == PASS_FWD) || (d.transposed && pass == PASS_DGRAD);
+
+  if (pass == PASS_WGRAD) {
+    GatherGeom& g = out8[0];
+    geom_common(g, d);
+    for (int j = 0; j < 3; ++j) {
+      // S tensor: x (conv) or dy (transposed);  C tensor: dy (conv) or x (transposed)
+      g.in_d[j] = d.transposed ? D.out[j] : D.in[j];
+      g.q_d[j] = d.transposed ? D.in[j] : D.out[j];
+      g.out_d[j] = g.q_d[j];
+      g.si[j] = d.stride;
+    }
+    g.in_cs = d.transposed ? ocs : ics;
+    g.out_cs = d.transposed ? ics : ocs;
+    g.K = d.transposed ? d.cout : d.cin;
+    g.Nn = d.transposed ? d.cin : d.cout;
+    g.ntaps = ntap_all;
+    int t = 0;
+    for (int t0 = 0; t0 < D.kd[0]; ++t0)
+      for (int t1 = 0; t1 < D.kd[1]; ++t1)
+        for (int t2 = 0; t2 < D.kd[2]; ++t2, ++t) {
+          g.tap_d[t][0] = t0 - D.pb[0];
+          g.tap_d[t][1] = t1 - D.pb[1];
+          g.tap_d[t][2] = t2 - D.pb[2];
+          g.tap_w[t] = t;
+        }
+    g.w_tap_stride = g.K * g.Nn;
+    g.w_sk = g.Nn;
+    g.w_sn = 1;
+    return 1;
+  }
+
+  if (gather_type) {
+    // conv forward:        y[o] = sum_t x[o*s + t - pb] . W[t][ci][co]
+    // transposed dgrad:    dx[i] = sum_t dy[2i + t] . Wd[t][co][ci]
+    GatherGeom& g = out8[0];
+    geom_common(g, d);
+    const bool fwd = (pass == PASS_FWD);
+    for (int j = 0; j < 3; ++j) {
+      g.in_d[j] = fwd ? D.in[j] : D.out[j];
+      g.out_d[j] = fwd ? D.out[j] : D.in[j];
+      g.q_d[j] = g.out_d[j];
+      g.si[j] = d.stride;
+    }
+    g.in_cs = fwd ? ics : ocs;
+    g.out_cs = fwd ? ocs : ics;
+    g.K = fwd ? d.cin : d.cout;
+    g.Nn = fwd ? d.cout : d.cin;
+    g.ntaps = ntap_all;
+    int t = 0;
+    for (int t0 = 0; t0 < D.kd[0]; ++t0)
+      for (int t1 = 0; t1 < D.kd[1]; ++t1)
+        for (int t2 = 0; t2 < D.kd[2]; ++t2, ++t) {
+          g.tap_d[t][0] = t0 - D.pb[0];
+          g.tap_d[t][1] = t1 - D.pb[1];
+          g.tap_d[t][2] = t2 - D.pb[2];
+          g.tap_w[t] = t;
+        }
+    g.w_tap_stride = g.K * g.Nn;  // [t][K][N] natural in both cases
+    g.w_sk = g.Nn;
+    g.w_sn = 1;
+    return 1;
+  }
+
+  // scatter-type passes, evaluated as gathers per output-parity class:
+  //   conv dgrad:         dx[p] = sum_{o,t: o*s + t - pb = p} dy[o] . W[t][ci][co]     (contract co)
+  //   transposed forward: y[o]  = sum_{i,t: 2i + t = o}       x[i]  . Wd[t][co][ci]    (contract ci)
+  const bool dgrad = (pass == PASS_DGRAD);
+  const int s = d.stride;
+  int ncls = 0;
+  int npar[3];
+  for (int j = 0; j < 3; ++j) npar[j] = (s == 2 && D.kd[j] > 0 && (dgrad ? D.in[j] : D.out[j]) > 1) ? 2 : 1;
+  for (int c0 = 0; c0 < npar[0]; ++c0)
+    for (int c1 = 0; c1 < npar[1]; ++c1)
+      for (int c2 = 0; c2 < npar[2]; ++c2) {
+        GatherGeom& g = out8[ncls++];
+        geom_common(g, d);
+        int par[3] = {c0, c1, c2};
+        for (int j = 0; j < 3; ++j) {
+          int tgt = dgrad ? D.in[j] : D.out[j];  // dims of the tensor being produced
+          g.in_d[j] = dgrad ? D.out[j] : D.in[j];
+          g.out_d[j] = tgt;
+          g.so[j] = npar[j];
+          g.po[j] = par[j];
+          g.q_d[j] = (tgt - par[j] + npar[j] - 1) / npar[j];
+          g.si[j] = 1;
+        }
+        g.in_cs = dgrad ? ocs : ics;
+        g.out_cs = dgrad ? ics : ocs;
+        g.K = dgrad ? d.cout : d.cin;
+        g.Nn = dgrad ? d.cin : d.cout;
+        // weights: conv W[t][ci][co] with n=ci,k=co ; transposed Wd[t][co][ci] with n=co,k=ci
+        g.w_tap_stride = d.cin * d.cout;
+        g.w_sk = 1;
+        g.w_sn = g.K;
+        int nt = 0, t = 0;
+        for (int t0 = 0; t0 < D.kd[0]; ++t0)
+          for (int t1 = 0; t1 < D.kd[1]; ++t1)
+            for (int t2 = 0; t2 < D.kd[2]; ++t2, ++t) {
+              int tt[3] = {t0, t1, t2};
+              bool okt = true;
+              int dd[3];
+              for (int j = 0; j < 3; ++j) {
+                // target position p = so*q + par ; source index = (p + pb - t) / s must be integral
+                int num = par[j] + D.pb[j] - tt[j];
+                if (s == 2 && npar[j] == 2) {
+                  if (num & 1) { okt = false; break; }
+                  dd[j] = num / 2;  // exact (num even); C++ division truncates toward zero, fine for even
+                } else if (s == 2) {
+                  // size-1 axis with stride 2 (only q=0, p=0): source = (pb - t)/2 if integral
+                  if (num & 1) { okt = false; break; }
+                  dd[j] = num / 2;
+                } else {
+                  dd[j] = num;
+                }
+              }
+              if (!okt) continue;
+              g.tap_d[nt][0] = dd[0];
+              g.tap_d[nt][1] = dd[1];
+              g.tap_d[nt][2] = dd[2];
+              g.tap_w[nt] = t;
+              ++nt;
+            }
+        g.ntaps = nt;
+      }
+  return ncls;
+}
+
+// ---------------------------------------------------------------------------------------------
+// op-level C-ABI
+// ---------------------------------------------------------------------------------------------
+int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out, int accumulate,
+                  hipStream_t s);  // conv_tiled.hip may override for small-C layers
+
+static int run_gather(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
+                      int accumulate, hipStream_t s) {
+  GatherGeom g[8];
+  int n = build_geoms(d, pass, g);
+  if (n < 0) return 2;
+  for (int i = 0; i < n; ++i) {
+    g[i].accumulate = accumulate;
+    if (g[i].ntaps == 0 && accumulate) continue;
+    if (d.algo == 1) URSN_TRY(launch_gconv_naive(g[i], in, w, out, s));
+    else URSN_TRY(launch_gconv_mfma(g[i], in, w, out, s));
+  }
+  return 0;
+}
+
+int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass);
+int launch_tiled_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
+                      int accumulate, hipStream_t s);
+
+int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out, int accumulate,
+                  hipStream_t s) {
+  if (d.algo == 3) {
+    URSN_REQUIRE(tiled_conv_supported(d, pass), "tiled conv kernel does not support this shape");
+    return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
+  }
+  if (d.algo == 0 && tiled_conv_supported(d, pass)) return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
+  return run_gather(d, pass, in, w, out, accumulate, s);
+}
+
+extern "C" int ursn_conv_forward(const ursn_conv_desc* d, const float* x, const float* w, float* y, void* stream) {
+  URSN_REQUIRE(d && x && w && y, "conv_forward: null argument");
+  return conv_dispatch(*d, PASS_FWD, x, w, y, 0, (hipStream_t)stream);
+}
+
+extern "C" int ursn_conv_backward_data(const ursn_conv_desc* d, const float* dy, const float* w, float* dx,
+                                       int32_t accumulate, void* stream) {
+  URSN_REQUIRE(d && dy && w && dx, "conv_backward_data: null argument");
+  return conv_dispatch(*d, PASS_DGRAD, dy, w, dx, accumulate, (hipStream_t)stream);
+}
+
+int tiled_wgrad_supported(const ursn_conv_desc& d);
+size_t tiled_wgrad_scratch_bytes(const ursn_conv_desc& d);
+int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
+                       size_t scratch_bytes, hipStream_t s);
+
+extern "C" size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d) {
+  if (!d) return 0;
+  GatherGeom g[8];
+  if (build_geoms(*d, PASS_WGRAD, g) != 1) return 0;
+  size_t a = wgrad_plan(g[0]).scratch_bytes;
+  size_t b = tiled_wgrad_supported(*d) ? tiled_wgrad_scratch_bytes(*d) : 0;
+  return (a > b ? a : b) + 256;
+}
+
+int wgrad_dispatch(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
+                   size_t scratch_bytes, hipStream_t s) {
+  if ((d.algo == 0 || d.algo == 3) && tiled_wgrad_supported(d))
+    return launch_tiled_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
+  URSN_REQUIRE(d.algo != 3, "tiled wgrad kernel does not support this shape");
+  GatherGeom g[8];
+  if (build_geoms(d, PASS_WGRAD, g) != 1) return 2;
+  const float* S = d.transposed ? dy : x;
+  const float* C = d.transposed ? x : dy;
+  if (d.algo == 1) return launch_wgrad_naive(g[0], S, C, dw, s);
+  return launch_wgrad_mfma(g[0], S, C, dw, scratch, scratch_bytes, s);
+}
+
+extern "C" int ursn_conv_backward_weight(const ursn_conv_desc* d, const float* x, const float* dy, float* dw,
+                                         void* scratch, size_t scratch_bytes, void* stream) {
+  URSN_REQUIRE(d && x && dy && dw, "conv_backward_weight: null argument");
+  return wgrad_dispatch(*d, x, dy, dw, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BN / head / adam op-level wrappers
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t ursn_bn_scratch_bytes(int64_t voxels, int32_t channels) {
+  return reduce_scratch_bytes(voxels, channels, 3) + 2 * (size_t)channels * sizeof(float) + 512;
+}
+
+static float* carve_floats(void* scratch, size_t scratch_bytes, int64_t V, int C) {
+  size_t off = (reduce_scratch_bytes(V, C, 3) + 255) & ~(size_t)255;
+  if (off + 2 * (size_t)C * sizeof(float) > scratch_bytes) return nullptr;
+  return (float*)((char*)scratch + off);
+}
+
+extern "C" int ursn_bn_forward(const float* z, const float* beta, const float* res, float* y, int64_t voxels,
+                               int32_t channels, float eps, int32_t relu, float* stats_out, void* scratch,
+                               size_t scratch_bytes, void* stream) {
+  URSN_REQUIRE(z && beta && y && scratch, "bn_forward: null argument");
+  float* ms = carve_floats(scratch, scratch_bytes, voxels, channels);
+  URSN_REQUIRE(ms, "bn_forward: scratch too small");
+  hipStream_t s = (hipStream_t)stream;
+  URSN_TRY(launch_bn_stats(z, channels, voxels, channels, eps, ms, ms + channels, scratch, s));
+  BnActArgs a;
+  memset(&a, 0, sizeof(a));
+  a.z = z; a.zcs = channels; a.mean = ms; a.rstd = ms + channels; a.beta = beta;
+  a.res = res; a.rescs = channels; a.y = y; a.ycs = channels; a.V = voxels; a.C = channels; a.relu = relu;
+  URSN_TRY(launch_bn_act(a, s));
+  if (stats_out) URSN_HIP(hipMemcpyAsync(stats_out, ms, 2 * (size_t)channels * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+extern "C" int ursn_bn_backward(const float* dy, const float* y, const float* z, float* dz, float* dbeta,
+                                int64_t voxels, int32_t channels, float eps, int32_t relu, void* scratch,
+                                size_t scratch_bytes, void* stream) {
+  URSN_REQUIRE(dy && z && dz && scratch && (!relu || y), "bn_backward: null argument");
+  float* ms = carve_floats(scratch, scratch_bytes, voxels, channels);
+  URSN_REQUIRE(ms, "bn_backward: scratch too small");
+  hipStream_t s = (hipStream_t)stream;
+  URSN_TRY(launch_bn_stats(z, channels, voxels, channels, eps, ms, ms + channels, scratch, s));
+  BnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dy = dy; a.dycs = channels; a.y = y; a.ycs = channels; a.z = z; a.zcs = channels;
+  a.mean = ms; a.rstd = ms + channels; a.dz = dz; a.dzcs = channels; a.dbeta = dbeta;
+  a.V = voxels; a.C = channels; a.relu = relu; a.scratch = scratch;
+  return launch_bn_bwd(a, s);
+}
+
+extern "C" int ursn_softmax_ce(const float* logits, const float* data, const float* label, const float* weight,
+                               int32_t n, int64_t pix, int32_t ncls, float* softmax_out, float* dlogits,
+                               float* out3, void* scratch, size_t scratch_bytes, void* stream) {
+  URSN_REQUIRE(logits && scratch, "softmax_ce: null argument");
+  size_t need = head_scratch_bytes(n, pix) + 64;
+  URSN_REQUIRE(scratch_bytes >= need, "softmax_ce: scratch too small (%zu < %zu)", scratch_bytes, need);
+  hipStream_t s = (hipStream_t)stream;
+  HeadArgs a;
+  memset(&a, 0, sizeof(a));
+  a.z = logits; a.data = data; a.data_cs = 1; a.label = label; a.weight = weight;
+  a.n = n; a.pix = pix; a.ncls = ncls; a.softmax_out = softmax_out; a.dlogits = dlogits;
+  a.scratch = scratch;
+  a.metrics = (float*)((char*)scratch + ((head_scratch_bytes(n, pix) + 15) & ~(size_t)15));
+  URSN_TRY(launch_head(a, s));
+  if (out3) {
+    URSN_HIP(hipMemcpyAsync(out3, a.metrics, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    URSN_HIP(hipStreamSynchronize(s));
+  }
+  return 0;
+}
+
+extern "C" int ursn_adam(float* p, const float* g, float* m, float* v, int64_t nelem, float lr, float b1, float b2,
+                         float eps, int64_t t, void* stream) {
+  URSN_REQUIRE(p && g && m && v && t >= 1, "adam: bad argument");
+  double lr_t = (double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
+  return launch_adam(p, g, m, v, nelem, (float)lr_t, b1, b2, eps, (hipStream_t)stream);
+}
+
+extern "C" int ursn_mfma_probe(int32_t which, float* out, void* stream) {
+  URSN_REQUIRE(out, "mfma_probe: null output");
+  return launch_mfma_probe(which, out, (hipStream_t)stream);
+}

@@ -1,0 +1,509 @@
+// HBM-bound kernels of the path: batch-statistics BatchNorm (stats / apply / backward), residual
+// join + ReLU, the fused softmax-CE/metrics head, TF-form Adam and small utilities (gfx950).
+//
+// Thread mapping shared by all per-voxel kernels: a block iteration covers VPB = 256/CP voxels,
+// CP = next_pow2(C/VEC) channel slots per voxel; VEC = 4 (16-byte accesses) whenever every
+// channel count / stride involved is a multiple of 4, else 1.  All per-channel sums are kept in
+// double (these kernels are bandwidth-bound; fp64 adds are free) so one-pass variance is safe.
+#include "ursn_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+template <int VEC> struct VT;
+template <> struct VT<1> { typedef float T; };
+template <> struct VT<4> { typedef f32x4 T; };
+
+template <int VEC> __device__ inline typename VT<VEC>::T ldv(const float* p) { return *(const typename VT<VEC>::T*)p; }
+template <int VEC> __device__ inline void stv(float* p, typename VT<VEC>::T v) { *(typename VT<VEC>::T*)p = v; }
+__device__ inline float elem(float v, int) { return v; }
+__device__ inline float elem(f32x4 v, int j) { return v[j]; }
+__device__ inline void setelem(float& v, int, float x) { v = x; }
+__device__ inline void setelem(f32x4& v, int j, float x) { v[j] = x; }
+
+struct Map {
+  int CP, shift, VPB, grid;
+};
+static Map make_map(int64_t V, int C, int VEC) {
+  Map m;
+  int cq = C / VEC;
+  m.CP = next_pow2(cq);
+  m.shift = 0;
+  while ((1 << m.shift) < m.CP) ++m.shift;
+  m.VPB = 256 / m.CP;
+  int64_t blocks = cdiv64(V, (int64_t)m.VPB * 8);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  m.grid = (int)blocks;
+  return m;
+}
+static bool vec4_ok(int C, std::initializer_list<int> strides, std::initializer_list<const void*> ptrs) {
+  if (C % 4) return false;
+  if (C / 4 > 256) return false;
+  for (int s : strides) if (s % 4) return false;
+  for (const void* p : ptrs) if (p && (((uintptr_t)p) & 15)) return false;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// Block reduction of NS*VEC doubles per thread over the voxel slots of a block -> partial[block][NS][C]
+// ------------------------------------------------------------------------------------------
+template <int NS, int VEC>
+__device__ inline void block_reduce_store(double (&acc)[NS][VEC], int CP, int C, double* partial_blk) {
+  __shared__ double sm[256 * NS * VEC];
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sm[(s * VEC + j) * 256 + tid] = acc[s][j];
+  __syncthreads();
+  for (int st = 128; st >= CP; st >>= 1) {
+    if (tid < st) {
+#pragma unroll
+      for (int k = 0; k < NS * VEC; ++k) sm[k * 256 + tid] += sm[k * 256 + tid + st];
+    }
+    __syncthreads();
+  }
+  if (tid < CP) {
+    int c = tid * VEC;
+    if (c < C) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) partial_blk[s * C + c + j] = sm[(s * VEC + j) * 256 + tid];
+    }
+  }
+}
+
+int reduce_nblocks(int64_t V, int C) {
+  int VEC = (C % 4 == 0) ? 4 : 1;
+  return make_map(V, C, VEC).grid;
+}
+size_t reduce_scratch_bytes(int64_t V, int C, int nsums) {
+  // partials [grid][nsums][C] doubles + finals [nsums][C] doubles
+  return ((size_t)reduce_nblocks(V, C) * nsums * C + (size_t)nsums * C) * sizeof(double) + 256;
+}
+
+// ------------------------------------------------------------------------------------------
+// BN statistics
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, int zcs, int64_t V, int C,
+                                                               int shift, double* __restrict__ partial) {
+  const int CP = 1 << shift;
+  const int VPB = 256 >> shift;
+  const int c = (threadIdx.x & (CP - 1)) * VEC;
+  const int vr = threadIdx.x >> shift;
+  double acc[2][VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = 0.0;
+  if (c < C) {
+    for (int64_t v = (int64_t)blockIdx.x * VPB + vr; v < V; v += (int64_t)gridDim.x * VPB) {
+      typename VT<VEC>::T x = ldv<VEC>(z + v * zcs + c);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        double d = (double)elem(x, j);
+        acc[0][j] += d;
+        acc[1][j] += d * d;
+      }
+    }
+  }
+  block_reduce_store<2, VEC>(acc, CP, C, partial + (size_t)blockIdx.x * 2 * C);
+}
+
+__global__ void bn_stats_final_kernel(const double* __restrict__ partial, int nblocks, int C, int64_t V, float eps,
+                                      float* __restrict__ mean, float* __restrict__ rstd) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    s += partial[(size_t)b * 2 * C + c];
+    q += partial[(size_t)b * 2 * C + C + c];
+  }
+  double mu = s / (double)V;
+  double var = q / (double)V - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+int launch_bn_stats(const float* z, int zcs, int64_t V, int C, float eps, float* mean, float* rstd, void* scratch,
+                    hipStream_t s) {
+  bool v4 = vec4_ok(C, {zcs}, {z});
+  URSN_REQUIRE(v4 || C <= 256, "bn_stats: unsupported channel count %d", C);
+  Map m = make_map(V, C, v4 ? 4 : 1);
+  double* partial = (double*)scratch;
+  if (v4) hipLaunchKernelGGL(bn_stats_partial_kernel<4>, dim3(m.grid), dim3(256), 0, s, z, zcs, V, C, m.shift, partial);
+  else hipLaunchKernelGGL(bn_stats_partial_kernel<1>, dim3(m.grid), dim3(256), 0, s, z, zcs, V, C, m.shift, partial);
+  URSN_HIP(hipGetLastError());
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, (const double*)partial, m.grid, C, V,
+                     eps, mean, rstd);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// BN apply (+ second BN'd branch | + residual) (+ ReLU)
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, int shift) {
+  const int CP = 1 << shift;
+  const int VPB = 256 >> shift;
+  const int c = (threadIdx.x & (CP - 1)) * VEC;
+  const int vr = threadIdx.x >> shift;
+  if (c >= a.C) return;
+  float sc[VEC], sh[VEC], sc2[VEC], sh2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sc[j] = a.rstd[c + j];
+    sh[j] = a.beta[c + j] - a.mean[c + j] * sc[j];
+    if (a.z2) {
+      sc2[j] = a.rstd2[c + j];
+      sh2[j] = a.beta2[c + j] - a.mean2[c + j] * sc2[j];
+    } else {
+      sc2[j] = sh2[j] = 0.f;
+    }
+  }
+  for (int64_t v = (int64_t)blockIdx.x * VPB + vr; v < a.V; v += (int64_t)gridDim.x * VPB) {
+    typename VT<VEC>::T x = ldv<VEC>(a.z + v * a.zcs + c), y;
+    typename VT<VEC>::T x2, r;
+    if (a.z2) x2 = ldv<VEC>(a.z2 + v * a.z2cs + c);
+    if (a.res) r = ldv<VEC>(a.res + v * a.rescs + c);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t = fmaf(elem(x, j), sc[j], sh[j]);
+      if (a.z2) t += fmaf(elem(x2, j), sc2[j], sh2[j]);
+      if (a.res) t += elem(r, j);
+      if (a.relu) t = fmaxf(t, 0.f);
+      setelem(y, j, t);
+    }
+    stv<VEC>(a.y + v * a.ycs + c, y);
+  }
+}
+
+int launch_bn_act(const BnActArgs& a, hipStream_t s) {
+  bool v4 = vec4_ok(a.C, {a.zcs, a.ycs, a.z2 ? a.z2cs : 0, a.res ? a.rescs : 0}, {a.z, a.y, a.z2, a.res});
+  URSN_REQUIRE(v4 || a.C <= 256, "bn_act: unsupported channel count %d", a.C);
+  Map m = make_map(a.V, a.C, v4 ? 4 : 1);
+  if (v4) hipLaunchKernelGGL(bn_act_kernel<4>, dim3(m.grid), dim3(256), 0, s, a, m.shift);
+  else hipLaunchKernelGGL(bn_act_kernel<1>, dim3(m.grid), dim3(256), 0, s, a, m.shift);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// BN backward: reduce (sum g, sum g*xhat[, sum g*xhat2]) then apply
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int shift, double* __restrict__ partial) {
+  const int CP = 1 << shift;
+  const int VPB = 256 >> shift;
+  const int c = (threadIdx.x & (CP - 1)) * VEC;
+  const int vr = threadIdx.x >> shift;
+  double acc[3][VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.0;
+  if (c < a.C) {
+    float mu[VEC], rs[VEC], mu2[VEC], rs2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      mu[j] = a.mean[c + j];
+      rs[j] = a.rstd[c + j];
+      mu2[j] = a.z2 ? a.mean2[c + j] : 0.f;
+      rs2[j] = a.z2 ? a.rstd2[c + j] : 0.f;
+    }
+    for (int64_t v = (int64_t)blockIdx.x * VPB + vr; v < a.V; v += (int64_t)gridDim.x * VPB) {
+      typename VT<VEC>::T g = ldv<VEC>(a.dy + v * a.dycs + c);
+      typename VT<VEC>::T x = ldv<VEC>(a.z + v * a.zcs + c);
+      typename VT<VEC>::T yv, x2;
+      if (a.relu) yv = ldv<VEC>(a.y + v * a.ycs + c);
+      if (a.z2) x2 = ldv<VEC>(a.z2 + v * a.z2cs + c);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float gj = elem(g, j);
+        if (a.relu && !(elem(yv, j) > 0.f)) gj = 0.f;
+        double gd = (double)gj;
+        acc[0][j] += gd;
+        acc[1][j] += gd * (double)((elem(x, j) - mu[j]) * rs[j]);
+        if (a.z2) acc[2][j] += gd * (double)((elem(x2, j) - mu2[j]) * rs2[j]);
+      }
+    }
+  }
+  block_reduce_store<3, VEC>(acc, CP, a.C, partial + (size_t)blockIdx.x * 3 * a.C);
+}
+
+// finals: [3][C] doubles = mean(g), mean(g*xhat), mean(g*xhat2); dbeta(+2) += sum g
+__global__ void bn_bwd_final_kernel(const double* __restrict__ partial, int nblocks, int C, int64_t V,
+                                    double* __restrict__ finals, float* __restrict__ dbeta,
+                                    float* __restrict__ dbeta2) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int b = 0; b < nblocks; ++b) {
+    const double* p = partial + (size_t)b * 3 * C;
+    s0 += p[c];
+    s1 += p[C + c];
+    s2 += p[2 * C + c];
+  }
+  finals[c] = s0 / (double)V;
+  finals[C + c] = s1 / (double)V;
+  finals[2 * C + c] = s2 / (double)V;
+  if (dbeta) dbeta[c] += (float)s0;
+  if (dbeta2) dbeta2[c] += (float)s0;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int shift, const double* __restrict__ finals) {
+  const int CP = 1 << shift;
+  const int VPB = 256 >> shift;
+  const int c = (threadIdx.x & (CP - 1)) * VEC;
+  const int vr = threadIdx.x >> shift;
+  if (c >= a.C) return;
+  float mu[VEC], rs[VEC], mu2[VEC], rs2[VEC], mg[VEC], mgx[VEC], mgx2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    mu[j] = a.mean[c + j];
+    rs[j] = a.rstd[c + j];
+    mu2[j] = a.z2 ? a.mean2[c + j] : 0.f;
+    rs2[j] = a.z2 ? a.rstd2[c + j] : 0.f;
+    mg[j] = (float)finals[c + j];
+    mgx[j] = (float)finals[a.C + c + j];
+    mgx2[j] = (float)finals[2 * a.C + c + j];
+  }
+  for (int64_t v = (int64_t)blockIdx.x * VPB + vr; v < a.V; v += (int64_t)gridDim.x * VPB) {
+    typename VT<VEC>::T g = ldv<VEC>(a.dy + v * a.dycs + c);
+    typename VT<VEC>::T x = ldv<VEC>(a.z + v * a.zcs + c);
+    typename VT<VEC>::T yv, x2, dz, dz2, dr;
+    if (a.relu) yv = ldv<VEC>(a.y + v * a.ycs + c);
+    if (a.z2) x2 = ldv<VEC>(a.z2 + v * a.z2cs + c);
+    if (a.dres && a.dres_accumulate) dr = ldv<VEC>(a.dres + v * a.drescs + c);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float gj = elem(g, j);
+      if (a.relu && !(elem(yv, j) > 0.f)) gj = 0.f;
+      float xh = (elem(x, j) - mu[j]) * rs[j];
+      setelem(dz, j, rs[j] * (gj - mg[j] - xh * mgx[j]));
+      if (a.z2) {
+        float xh2 = (elem(x2, j) - mu2[j]) * rs2[j];
+        setelem(dz2, j, rs2[j] * (gj - mg[j] - xh2 * mgx2[j]));
+      }
+      if (a.dres) setelem(dr, j, a.dres_accumulate ? elem(dr, j) + gj : gj);
+    }
+    stv<VEC>(a.dz + v * a.dzcs + c, dz);
+    if (a.z2) stv<VEC>(a.dz2 + v * a.dz2cs + c, dz2);
+    if (a.dres) stv<VEC>(a.dres + v * a.drescs + c, dr);
+  }
+}
+
+int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
+  bool v4 = vec4_ok(a.C, {a.dycs, a.relu ? a.ycs : 0, a.zcs, a.dzcs, a.z2 ? a.z2cs : 0, a.z2 ? a.dz2cs : 0,
+                          a.dres ? a.drescs : 0},
+                    {a.dy, a.relu ? a.y : nullptr, a.z, a.dz, a.z2, a.dz2, a.dres});
+  URSN_REQUIRE(v4 || a.C <= 256, "bn_bwd: unsupported channel count %d", a.C);
+  Map m = make_map(a.V, a.C, v4 ? 4 : 1);
+  double* partial = (double*)a.scratch;
+  double* finals = partial + (size_t)m.grid * 3 * a.C;
+  if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(m.grid), dim3(256), 0, s, a, m.shift, partial);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(m.grid), dim3(256), 0, s, a, m.shift, partial);
+  URSN_HIP(hipGetLastError());
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((a.C + 63) / 64), dim3(64), 0, s, (const double*)partial, m.grid, a.C,
+                     a.V, finals, a.dbeta, a.z2 ? a.dbeta2 : nullptr);
+  URSN_HIP(hipGetLastError());
+  if (v4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(m.grid), dim3(256), 0, s, a, m.shift, (const double*)finals);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(m.grid), dim3(256), 0, s, a, m.shift, (const double*)finals);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Head: logits = bn(z); softmax; weighted CE; accuracies; dlogits        (lib/ssnet.py:57-71)
+// ------------------------------------------------------------------------------------------
+#define URSN_MAX_CLASS 8
+__global__ __launch_bounds__(256) void head_kernel(HeadArgs a, double* __restrict__ partial) {
+  const int64_t P = (int64_t)a.n * a.pix;
+  double loss = 0.0;
+  unsigned int n_ok = 0, n_nz = 0, n_ok_nz = 0;
+  float sc[URSN_MAX_CLASS], sh[URSN_MAX_CLASS];
+#pragma unroll
+  for (int k = 0; k < URSN_MAX_CLASS; ++k) {
+    sc[k] = 1.f;
+    sh[k] = 0.f;
+    if (k < a.ncls && a.mean) {
+      sc[k] = a.rstd[k];
+      sh[k] = a.beta[k] - a.mean[k] * sc[k];
+    }
+  }
+  const float invn = 1.0f / (float)a.n;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    float z[URSN_MAX_CLASS];
+    float m = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int k = 0; k < URSN_MAX_CLASS; ++k) {
+      if (k < a.ncls) {
+        z[k] = fmaf(a.z[p * a.ncls + k], sc[k], sh[k]);
+        if (z[k] > m) { m = z[k]; arg = k; }  // strict '>' keeps the lowest index on ties
+      }
+    }
+    float ssum = 0.f;
+    float e[URSN_MAX_CLASS];
+#pragma unroll
+    for (int k = 0; k < URSN_MAX_CLASS; ++k)
+      if (k < a.ncls) { e[k] = expf(z[k] - m); ssum += e[k]; }
+    float inv = 1.0f / ssum;
+    if (a.softmax_out) {
+#pragma unroll
+      for (int k = 0; k < URSN_MAX_CLASS; ++k)
+        if (k < a.ncls) a.softmax_out[p * a.ncls + k] = e[k] * inv;
+    }
+    if (a.label) {
+      int lab = (int)a.label[p];  // tf.cast(float -> int64) truncates toward zero
+      bool lab_ok = lab >= 0 && lab < a.ncls;
+      int labc = lab_ok ? lab : 0;
+      float w = a.weight ? a.weight[p] : 1.0f;
+      float zl = 0.f;
+#pragma unroll
+      for (int k = 0; k < URSN_MAX_CLASS; ++k)
+        if (k == labc) zl = z[k];
+      float ce = (m + logf(ssum)) - zl;
+      loss += lab_ok ? (double)(w * ce) : (double)NAN;
+      bool okp = (arg == lab);
+      bool nz = a.data ? (a.data[p * a.data_cs] > 0.f) : false;
+      n_ok += okp;
+      n_nz += nz;
+      n_ok_nz += (okp && nz);
+      if (a.dlogits) {
+#pragma unroll
+        for (int k = 0; k < URSN_MAX_CLASS; ++k)
+          if (k < a.ncls) a.dlogits[p * a.ncls + k] = w * invn * (e[k] * inv - (k == labc ? 1.f : 0.f));
+      }
+    }
+  }
+  __shared__ double sm[4][256];
+  sm[0][threadIdx.x] = loss;
+  sm[1][threadIdx.x] = (double)n_ok;
+  sm[2][threadIdx.x] = (double)n_nz;
+  sm[3][threadIdx.x] = (double)n_ok_nz;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (threadIdx.x < st)
+      for (int k = 0; k < 4; ++k) sm[k][threadIdx.x] += sm[k][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] = sm[threadIdx.x][0];
+}
+
+__global__ void head_final_kernel(const double* __restrict__ partial, int nblocks, int n, int64_t pix,
+                                  float* __restrict__ metrics) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s[4] = {0, 0, 0, 0};
+  for (int b = 0; b < nblocks; ++b)
+    for (int k = 0; k < 4; ++k) s[k] += partial[(size_t)b * 4 + k];
+  metrics[0] = (float)(s[0] / (double)n);
+  metrics[1] = (float)(s[1] / ((double)n * (double)pix));
+  metrics[2] = s[2] > 0 ? (float)(s[3] / s[2]) : NAN;
+  metrics[3] = (float)s[2];
+}
+
+static int head_blocks(int n, int64_t pix) {
+  int64_t b = cdiv64((int64_t)n * pix, 256 * 4);
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+size_t head_scratch_bytes(int n, int64_t pix) { return (size_t)head_blocks(n, pix) * 4 * sizeof(double) + 64; }
+
+int launch_head(const HeadArgs& a, hipStream_t s) {
+  URSN_REQUIRE(a.ncls >= 1 && a.ncls <= URSN_MAX_CLASS, "head: num_class %d not in [1,%d]", a.ncls, URSN_MAX_CLASS);
+  int nb = head_blocks(a.n, a.pix);
+  double* partial = (double*)a.scratch;
+  hipLaunchKernelGGL(head_kernel, dim3(nb), dim3(256), 0, s, a, partial);
+  URSN_HIP(hipGetLastError());
+  hipLaunchKernelGGL(head_final_kernel, dim3(1), dim3(64), 0, s, (const double*)partial, nb, a.n, a.pix, a.metrics);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam (TF form), fill, reduce
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr_t,
+                                                   float b1, float b2, float eps) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2, float eps,
+                hipStream_t s) {
+  if (n == 0) return 0;
+  int blocks = (int)(cdiv64(n, 256) < 4096 ? cdiv64(n, 256) : 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void fill_kernel(float* p, float value, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = value;
+}
+int launch_fill(float* p, float value, int64_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  int blocks = (int)(cdiv64(n, 256) < 4096 ? cdiv64(n, 256) : 4096);
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, p, value, n);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void reduce_accum_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n, int nchunks) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += src[(int64_t)c * n + i];
+    dst[i] += s;
+  }
+}
+int launch_reduce_accum(float* dst, const float* src, int64_t n, int nchunks, hipStream_t s) {
+  if (n == 0) return 0;
+  int blocks = (int)(cdiv64(n, 256) < 2048 ? cdiv64(n, 256) : 2048);
+  hipLaunchKernelGGL(reduce_accum_kernel, dim3(blocks), dim3(256), 0, s, dst, src, n, nchunks);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA lane-layout probe (tests/test_mfma_probe.py decodes it)
+//   which 1: 4x4x1_16B, a = lane+1, b = 1          -> D = source A lane + 1
+//   which 2: 4x4x1_16B, a = 1,      b = lane+1     -> D = source B lane + 1
+//   which 3: as 1 with cbsz=4, abid=3              (A block 3 broadcast to all 16 blocks)
+//   which 4: as 1 with cbsz=2, abid=1              (A block 1 of every 4 broadcast in its group)
+//   which 5: 16x16x4, a = 2^(lane>>4) * (1+(lane&15)), b = 1   (sum over k identifies lanes)
+//   which 6: 16x16x4, a = 1, b = 2^(8*(lane>>4))... encoded per k: b = (1+(lane&15)) * 32^(lane>>4)
+// out[lane*4 + r] = D reg r of lane.
+// ------------------------------------------------------------------------------------------
+__global__ void mfma_probe_kernel(int which, float* out) {
+  int lane = threadIdx.x;
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  float a = 1.f, b = 1.f;
+  f32x4 d = c;
+  switch (which) {
+    case 1: a = (float)(lane + 1); d = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); break;
+    case 2: b = (float)(lane + 1); d = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); break;
+    case 3: a = (float)(lane + 1); d = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, 3, 0); break;
+    case 4: a = (float)(lane + 1); d = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 2, 1, 0); break;
+    case 5: a = (float)((1 + (lane & 15)) * (1 << (5 * (lane >> 4)))); d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); break;
+    case 6: b = (float)((1 + (lane & 15)) * (1 << (5 * (lane >> 4)))); d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); break;
+    default: break;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) out[lane * 4 + r] = d[r];
+}
+int launch_mfma_probe(int which, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, s, which, out);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,587 @@
+// Net-level C-ABI: the U-ResNet of lib/uresnet.py:22-123 + lib/resnet_module.py:10-87 as a fixed
+// launch plan over caller-owned device memory, one entry point per sess.run fetch-set of
+// lib/ssnet.py:91-139.  Host-side orchestration only; all arithmetic is in the HIP kernels.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ursn_common.h"
+
+int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out, int accumulate,
+                  hipStream_t s);
+int wgrad_dispatch(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
+                   size_t scratch_bytes, hipStream_t s);
+
+namespace {
+
+struct Arena {
+  char* base = nullptr;
+  size_t off = 0;
+  void* take(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = base ? (void*)(base + off) : nullptr;
+    off += bytes;
+    return p;
+  }
+  float* floats(int64_t n) { return (float*)take((size_t)n * sizeof(float)); }
+};
+
+struct Act {       // activation tensor view (+ gradient view with identical layout)
+  float* p = nullptr;
+  float* g = nullptr;
+  int C = 0, cs = 0, lvl = 0;
+  int flag = -1;   // index into ursn_net::ginit (gradient-initialised state shared between views)
+};
+
+struct Layer {
+  std::string name;
+  int kind = 0;  // 0 conv, 1 deconv
+  int k = 3, stride = 1, cin = 0, cout = 0, lin = 0, lout = 0;
+  int64_t w_off = 0, b_off = 0, w_n = 0;
+  ursn_conv_desc desc;
+  float *z = nullptr, *dz = nullptr, *mean = nullptr, *rstd = nullptr;
+};
+
+struct Unit {
+  std::string scope;
+  int sc = -1, c1 = -1, c2 = -1;  // layer indices
+  Act in, a1, out;
+};
+
+}  // namespace
+
+struct ursn_net {
+  ursn_config cfg;
+  ursn_sizes sizes;
+  int nlev = 0;
+  int ldim[8][3];        // spatial dims per level (3 entries, leading 1 for 2-D)
+  int64_t lvox[8];       // voxels per image per level
+  std::vector<Layer> layers;
+  std::vector<Unit> units;           // encoder units then decoder units, execution order
+  std::vector<int> deconv;           // layer index per decoder step
+  std::vector<Act> deconv_in, deconv_out, cat;  // per decoder step
+  int conv0 = -1, conv1 = -1, conv2 = -1;
+  Act a_data, a_conv0, a_conv1, a_pre1;  // a_pre1: input of conv1 (last decoder unit output)
+  std::vector<int> ginit;
+  float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  float* dlog = nullptr;     // d loss / d logits  [V0, ncls]
+  float* metrics = nullptr;  // device [4]
+  void* red_scratch = nullptr;
+  void* head_scratch = nullptr;
+  void* wg_scratch = nullptr;
+  size_t wg_scratch_bytes = 0;
+  int64_t adam_t = 0;
+  int last_n = 0;
+  std::map<std::string, Act> named;       // debug lookup: activations
+  std::map<std::string, int> named_z;     // layer name -> layer index
+};
+
+namespace {
+
+int new_flag(ursn_net* n) {
+  n->ginit.push_back(0);
+  return (int)n->ginit.size() - 1;
+}
+
+Act make_act(ursn_net* n, Arena& A, int lvl, int C, bool grad) {
+  Act a;
+  a.C = C;
+  a.cs = C;
+  a.lvl = lvl;
+  int64_t e = (int64_t)n->cfg.max_batch * n->lvox[lvl] * C;
+  a.p = A.floats(e);
+  a.g = grad ? A.floats(e) : nullptr;
+  a.flag = new_flag(n);
+  return a;
+}
+
+Act sub_act(const Act& full, int c0, int C) {
+  Act a = full;
+  a.p = full.p ? full.p + c0 : nullptr;
+  a.g = full.g ? full.g + c0 : nullptr;
+  a.C = C;
+  return a;  // same cs, same flag
+}
+
+int add_layer(ursn_net* n, Arena& A, const std::string& name, int kind, int k, int s, int ci, int co, int lin, int lout,
+              int64_t& poff) {
+  Layer L;
+  L.name = "UResNet/" + name;
+  L.kind = kind; L.k = k; L.stride = s; L.cin = ci; L.cout = co; L.lin = lin; L.lout = lout;
+  int64_t taps = 1;
+  for (int j = 0; j < n->cfg.ndim; ++j) taps *= k;
+  L.w_n = taps * ci * co;
+  L.w_off = poff; poff += L.w_n;
+  L.b_off = poff; poff += co;
+  memset(&L.desc, 0, sizeof(L.desc));
+  L.desc.ndim = n->cfg.ndim;
+  L.desc.n = n->cfg.max_batch;
+  for (int j = 0; j < n->cfg.ndim; ++j) L.desc.in_sp[j] = n->ldim[lin][3 - n->cfg.ndim + j];
+  L.desc.cin = ci; L.desc.cout = co; L.desc.k = k; L.desc.stride = s; L.desc.transposed = kind;
+  int64_t e = (int64_t)n->cfg.max_batch * n->lvox[lout] * co;
+  L.z = A.floats(e);
+  L.dz = n->cfg.trainable ? A.floats(e) : nullptr;
+  L.mean = A.floats(co);
+  L.rstd = A.floats(co);
+  n->layers.push_back(L);
+  n->named_z[L.name] = (int)n->layers.size() - 1;
+  return (int)n->layers.size() - 1;
+}
+
+// Builds the whole plan; with A.base == nullptr only sizes are computed.
+int plan(ursn_net* n, Arena& A) {
+  const ursn_config& c = n->cfg;
+  URSN_REQUIRE(c.ndim == 2 || c.ndim == 3, "len(dims) must be 3 (H,W,C) or 4 (H,W,D,C)");
+  URSN_REQUIRE(c.num_strides >= 1 && c.num_strides <= 6, "num_strides %d out of range", c.num_strides);
+  URSN_REQUIRE(c.cin >= 1 && c.base_filters >= 1 && c.num_class >= 1 && c.num_class <= 8 && c.max_batch >= 1,
+               "bad channel / class / batch configuration");
+  const int ns = c.num_strides;
+  n->nlev = ns + 1;
+  for (int l = 0; l <= ns; ++l) {
+    n->lvox[l] = 1;
+    for (int j = 0; j < 3; ++j) {
+      int lead = 3 - c.ndim;
+      if (j < lead) { n->ldim[l][j] = 1; continue; }
+      int s0 = c.spatial[j - lead];
+      URSN_REQUIRE(s0 > 0 && s0 % (1 << ns) == 0, "spatial size %d not divisible by 2^%d (deconv/skip shapes would differ)", s0, ns);
+      n->ldim[l][j] = s0 >> l;
+      n->lvox[l] *= n->ldim[l][j];
+    }
+  }
+  const bool tr = c.trainable != 0;
+  const int F = c.base_filters;
+  int64_t poff = 0;
+  n->layers.clear(); n->units.clear(); n->deconv.clear(); n->cat.clear(); n->deconv_in.clear(); n->deconv_out.clear();
+  n->ginit.clear(); n->named.clear(); n->named_z.clear();
+
+  // concat buffers first (decoder step i lives at level ns-1-i with F*2^(ns-i) channels)
+  n->cat.resize(ns);
+  for (int i = 0; i < ns; ++i) n->cat[i] = make_act(n, A, ns - 1 - i, F << (ns - i), tr);
+  auto fmap_view = [&](int lvl) {  // encoder feature map at level lvl (< ns) = second half of its concat buffer
+    const Act& full = n->cat[ns - 1 - lvl];
+    return sub_act(full, full.C / 2, full.C / 2);
+  };
+
+  n->a_data = Act();
+  n->a_data.C = c.cin; n->a_data.cs = c.cin; n->a_data.lvl = 0;
+
+  n->conv0 = add_layer(n, A, "conv0", 0, 3, 1, c.cin, F, 0, 0, poff);
+  n->a_conv0 = fmap_view(0);
+  n->named["UResNet/conv0"] = n->a_conv0;
+
+  auto add_unit = [&](const std::string& scope, const Act& in, int co, int s, int lout, const Act* out_view) {
+    Unit u;
+    u.scope = "UResNet/" + scope;
+    u.in = in;
+    if (!(in.C == co && s == 1)) u.sc = add_layer(n, A, scope + "/shortcut", 0, 1, s, in.C, co, in.lvl, lout, poff);
+    u.c1 = add_layer(n, A, scope + "/resnet_conv1", 0, 3, s, in.C, co, in.lvl, lout, poff);
+    u.a1 = make_act(n, A, lout, co, tr);
+    u.c2 = add_layer(n, A, scope + "/resnet_conv2", 0, 3, 1, co, co, lout, lout, poff);
+    u.out = out_view ? *out_view : make_act(n, A, lout, co, tr);
+    n->units.push_back(u);
+    n->named[u.scope] = u.out;
+    n->named[n->layers[u.c1].name] = u.a1;
+    return u.out;
+  };
+
+  Act net = n->a_conv0;
+  for (int step = 0; step < ns; ++step) {
+    char sc[64];
+    int co = net.C * 2;
+    snprintf(sc, sizeof(sc), "resnet_module%d/module1", step);
+    Act u1 = add_unit(sc, net, co, 2, step + 1, nullptr);
+    snprintf(sc, sizeof(sc), "resnet_module%d/module2", step);
+    if (step + 1 < ns) {
+      Act view = fmap_view(step + 1);
+      net = add_unit(sc, u1, co, 1, step + 1, &view);
+    } else {
+      net = add_unit(sc, u1, co, 1, step + 1, nullptr);
+    }
+  }
+  for (int i = 0; i < ns; ++i) {
+    char sc[64];
+    int co = net.C / 2;
+    int lvl = ns - 1 - i;
+    snprintf(sc, sizeof(sc), "deconv%d", i);
+    int li = add_layer(n, A, sc, 1, 3, 2, net.C, co, net.lvl, lvl, poff);
+    n->deconv.push_back(li);
+    n->deconv_in.push_back(net);
+    Act dout = sub_act(n->cat[i], 0, co);
+    n->deconv_out.push_back(dout);
+    n->named[n->layers[li].name] = dout;
+    snprintf(sc, sizeof(sc), "resnet_module%d/module1", i + 5);
+    Act u1 = add_unit(sc, n->cat[i], co, 1, lvl, nullptr);
+    snprintf(sc, sizeof(sc), "resnet_module%d/module2", i + 5);
+    net = add_unit(sc, u1, co, 1, lvl, nullptr);
+  }
+  n->a_pre1 = net;
+  n->conv1 = add_layer(n, A, "conv1", 0, 3, 1, net.C, F, 0, 0, poff);
+  n->a_conv1 = make_act(n, A, 0, F, tr);
+  n->named["UResNet/conv1"] = n->a_conv1;
+  n->conv2 = add_layer(n, A, "conv2", 0, 3, 1, F, c.num_class, 0, 0, poff);
+
+  const int64_t V0 = (int64_t)c.max_batch * n->lvox[0];
+  n->dlog = tr ? A.floats(V0 * c.num_class) : nullptr;
+  n->metrics = A.floats(8);
+  n->head_scratch = A.take(head_scratch_bytes(c.max_batch, n->lvox[0]) + 64);
+  size_t red = 0, wg = 0;
+  for (const Layer& L : n->layers) {
+    size_t r = reduce_scratch_bytes((int64_t)c.max_batch * n->lvox[L.lout], L.cout, 3);
+    if (r > red) red = r;
+    if (tr) {
+      size_t w = ursn_conv_wgrad_scratch_bytes(&L.desc);
+      if (w > wg) wg = w;
+    }
+  }
+  n->red_scratch = A.take(red + 256);
+  n->wg_scratch_bytes = wg;
+  n->wg_scratch = tr ? A.take(wg + 256) : nullptr;
+
+  n->sizes.n_params = poff;
+  n->sizes.n_layers = (int64_t)n->layers.size();
+  n->sizes.n_tensors = 2 * (int64_t)n->layers.size();
+  n->sizes.workspace_bytes = (int64_t)((A.off + 255) & ~(size_t)255);
+  return 0;
+}
+
+// ---- forward pieces -----------------------------------------------------------------------
+int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s) {
+  Layer& L = n->layers[li];
+  ursn_conv_desc d = L.desc;
+  d.n = N;
+  d.in_cstride = in.cs;
+  d.out_cstride = L.cout;
+  URSN_TRY(conv_dispatch(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, s));
+  URSN_TRY(launch_bn_stats(L.z, L.cout, (int64_t)N * n->lvox[L.lout], L.cout, n->cfg.bn_eps, L.mean, L.rstd,
+                           n->red_scratch, s));
+  return 0;
+}
+
+int bn_out(ursn_net* n, int li, const Act& out, int relu, int N, int li2, const float* res, int rescs, hipStream_t s) {
+  Layer& L = n->layers[li];
+  BnActArgs a;
+  memset(&a, 0, sizeof(a));
+  a.z = L.z; a.zcs = L.cout; a.mean = L.mean; a.rstd = L.rstd; a.beta = n->params + L.b_off;
+  if (li2 >= 0) {
+    Layer& L2 = n->layers[li2];
+    a.z2 = L2.z; a.z2cs = L2.cout; a.mean2 = L2.mean; a.rstd2 = L2.rstd; a.beta2 = n->params + L2.b_off;
+  }
+  a.res = res; a.rescs = rescs;
+  a.y = out.p; a.ycs = out.cs; a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.cout; a.relu = relu;
+  return launch_bn_act(a, s);
+}
+
+int unit_fwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
+  if (u.sc >= 0) URSN_TRY(conv_stats(n, u.sc, u.in, N, s));
+  URSN_TRY(conv_stats(n, u.c1, u.in, N, s));
+  URSN_TRY(bn_out(n, u.c1, u.a1, 0, N, -1, nullptr, 0, s));
+  URSN_TRY(conv_stats(n, u.c2, u.a1, N, s));
+  if (u.sc >= 0) URSN_TRY(bn_out(n, u.c2, u.out, 1, N, u.sc, nullptr, 0, s));
+  else URSN_TRY(bn_out(n, u.c2, u.out, 1, N, -1, u.in.p, u.in.cs, s));
+  return 0;
+}
+
+int forward(ursn_net* n, const float* data, int N, hipStream_t s) {
+  const int ns = n->cfg.num_strides;
+  Act din = n->a_data;
+  din.p = const_cast<float*>(data);
+  URSN_TRY(conv_stats(n, n->conv0, din, N, s));
+  URSN_TRY(bn_out(n, n->conv0, n->a_conv0, 1, N, -1, nullptr, 0, s));
+  size_t ui = 0;
+  for (int step = 0; step < ns; ++step) {
+    URSN_TRY(unit_fwd(n, n->units[ui++], N, s));
+    URSN_TRY(unit_fwd(n, n->units[ui++], N, s));
+  }
+  for (int i = 0; i < ns; ++i) {
+    URSN_TRY(conv_stats(n, n->deconv[i], n->deconv_in[i], N, s));
+    URSN_TRY(bn_out(n, n->deconv[i], n->deconv_out[i], 1, N, -1, nullptr, 0, s));
+    URSN_TRY(unit_fwd(n, n->units[ui++], N, s));
+    URSN_TRY(unit_fwd(n, n->units[ui++], N, s));
+  }
+  URSN_TRY(conv_stats(n, n->conv1, n->a_pre1, N, s));
+  URSN_TRY(bn_out(n, n->conv1, n->a_conv1, 1, N, -1, nullptr, 0, s));
+  URSN_TRY(conv_stats(n, n->conv2, n->a_conv1, N, s));
+  return 0;
+}
+
+int head(ursn_net* n, const float* data, const float* label, const float* weight, int N, float* softmax_out,
+         bool want_grad, hipStream_t s) {
+  Layer& L = n->layers[n->conv2];
+  HeadArgs a;
+  memset(&a, 0, sizeof(a));
+  a.z = L.z; a.mean = L.mean; a.rstd = L.rstd; a.beta = n->params + L.b_off;
+  a.data = (n->cfg.cin == 1) ? data : nullptr;  // acc_nonzero needs one input channel (lib/ssnet.py:59)
+  a.data_cs = n->cfg.cin;
+  a.label = label; a.weight = weight; a.n = N; a.pix = n->lvox[0]; a.ncls = n->cfg.num_class;
+  a.softmax_out = softmax_out; a.dlogits = want_grad ? n->dlog : nullptr;
+  a.scratch = n->head_scratch; a.metrics = n->metrics;
+  return launch_head(a, s);
+}
+
+// ---- backward pieces ----------------------------------------------------------------------
+bool take_flag(ursn_net* n, const Act& a) {  // returns "accumulate?" and marks the gradient as initialised
+  bool acc = n->ginit[a.flag] != 0;
+  n->ginit[a.flag] = 1;
+  return acc;
+}
+
+int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStream_t s) {
+  Layer& L = n->layers[li];
+  ursn_conv_desc d = L.desc;
+  d.n = N;
+  d.in_cstride = in.cs;
+  d.out_cstride = L.cout;
+  if (need_dgrad) {
+    bool acc = take_flag(n, in);
+    URSN_TRY(conv_dispatch(d, PASS_DGRAD, L.dz, n->params + L.w_off, in.g, acc ? 1 : 0, s));
+  }
+  URSN_TRY(wgrad_dispatch(d, in.p, L.dz, n->grads + L.w_off, n->wg_scratch, n->wg_scratch_bytes, s));
+  return 0;
+}
+
+int bn_back(ursn_net* n, int li, const float* dy, int dycs, const float* y, int ycs, int relu, int li2, float* dres,
+            int drescs, int dres_acc, int N, hipStream_t s) {
+  Layer& L = n->layers[li];
+  BnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dy = dy; a.dycs = dycs; a.y = y; a.ycs = ycs;
+  a.z = L.z; a.zcs = L.cout; a.mean = L.mean; a.rstd = L.rstd; a.dz = L.dz; a.dzcs = L.cout;
+  a.dbeta = n->grads + L.b_off;
+  if (li2 >= 0) {
+    Layer& L2 = n->layers[li2];
+    a.z2 = L2.z; a.z2cs = L2.cout; a.mean2 = L2.mean; a.rstd2 = L2.rstd; a.dz2 = L2.dz; a.dz2cs = L2.cout;
+    a.dbeta2 = n->grads + L2.b_off;
+  }
+  a.dres = dres; a.drescs = drescs; a.dres_accumulate = dres_acc;
+  a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.cout; a.relu = relu; a.scratch = n->red_scratch;
+  return launch_bn_bwd(a, s);
+}
+
+int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
+  // join: g = dout * (out > 0); BN2 (and shortcut BN) backward; identity shortcut adds g into d(in)
+  if (u.sc >= 0) {
+    URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, u.sc, nullptr, 0, 0, N, s));
+  } else {
+    bool acc = take_flag(n, u.in);
+    URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, -1, u.in.g, u.in.cs, acc ? 1 : 0, N, s));
+  }
+  URSN_TRY(conv_bwd(n, u.c2, u.a1, true, N, s));
+  URSN_TRY(bn_back(n, u.c1, u.a1.g, u.a1.cs, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
+  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s));
+  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, true, N, s));
+  return 0;
+}
+
+int backward(ursn_net* n, const float* data, int N, hipStream_t s) {
+  const int ns = n->cfg.num_strides;
+  for (size_t i = 0; i < n->ginit.size(); ++i) n->ginit[i] = 0;
+  Layer& L2 = n->layers[n->conv2];
+  URSN_TRY(bn_back(n, n->conv2, n->dlog, L2.cout, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
+  URSN_TRY(conv_bwd(n, n->conv2, n->a_conv1, true, N, s));
+  URSN_TRY(bn_back(n, n->conv1, n->a_conv1.g, n->a_conv1.cs, n->a_conv1.p, n->a_conv1.cs, 1, -1, nullptr, 0, 0, N, s));
+  URSN_TRY(conv_bwd(n, n->conv1, n->a_pre1, true, N, s));
+  size_t ui = n->units.size();
+  for (int i = ns - 1; i >= 0; --i) {
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
+    const Act& dout = n->deconv_out[i];
+    URSN_TRY(bn_back(n, n->deconv[i], dout.g, dout.cs, dout.p, dout.cs, 1, -1, nullptr, 0, 0, N, s));
+    URSN_TRY(conv_bwd(n, n->deconv[i], n->deconv_in[i], true, N, s));
+  }
+  for (int step = ns - 1; step >= 0; --step) {
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
+  }
+  const Act& a0 = n->a_conv0;
+  URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, a0.p, a0.cs, 1, -1, nullptr, 0, 0, N, s));
+  Act din = n->a_data;
+  din.p = const_cast<float*>(data);
+  URSN_TRY(conv_bwd(n, n->conv0, din, false, N, s));
+  return 0;
+}
+
+int read_metrics(ursn_net* n, float* out, int cnt, hipStream_t s) {
+  float h[4];
+  URSN_HIP(hipMemcpyAsync(h, n->metrics, sizeof(h), hipMemcpyDeviceToHost, s));
+  URSN_HIP(hipStreamSynchronize(s));
+  if (cnt == 3) { out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; }
+  else { out[0] = h[1]; out[1] = h[2]; }
+  return 0;
+}
+
+int check_call(ursn_net* n, const float* data, int N) {
+  URSN_REQUIRE(n, "null handle");
+  URSN_REQUIRE(data, "input_data is null");
+  URSN_REQUIRE(N >= 1 && N <= n->cfg.max_batch, "batch %d outside [1,%d]", N, n->cfg.max_batch);
+  return 0;
+}
+
+}  // namespace
+
+// ---- C-ABI ----------------------------------------------------------------------------------
+extern "C" int ursn_query(const ursn_config* cfg, ursn_sizes* out) {
+  URSN_REQUIRE(cfg && out, "query: null argument");
+  ursn_net tmp;
+  tmp.cfg = *cfg;
+  if (tmp.cfg.bn_eps <= 0.f) tmp.cfg.bn_eps = 1e-3f;
+  Arena A;
+  URSN_TRY(plan(&tmp, A));
+  *out = tmp.sizes;
+  return 0;
+}
+
+extern "C" int ursn_create(const ursn_config* cfg, float* params, float* grads, float* adam_m, float* adam_v,
+                           void* workspace, size_t workspace_bytes, ursn_net** out) {
+  URSN_REQUIRE(cfg && params && workspace && out, "create: null argument");
+  URSN_REQUIRE(!cfg->trainable || (grads && adam_m && adam_v), "create: trainable net needs grads/adam buffers");
+  URSN_REQUIRE((((uintptr_t)workspace) & 255) == 0, "create: workspace must be 256-byte aligned");
+  ursn_net* n = new ursn_net();
+  n->cfg = *cfg;
+  if (n->cfg.bn_eps <= 0.f) n->cfg.bn_eps = 1e-3f;
+  Arena A;
+  A.base = (char*)workspace;
+  int rc = plan(n, A);
+  if (rc == 0 && (size_t)n->sizes.workspace_bytes > workspace_bytes) {
+    ursn_set_error("create: workspace too small: need %lld bytes, got %zu", (long long)n->sizes.workspace_bytes,
+                   workspace_bytes);
+    rc = 2;
+  }
+  if (rc) { delete n; return rc; }
+  n->params = params; n->grads = grads; n->adam_m = adam_m; n->adam_v = adam_v;
+  *out = n;
+  return 0;
+}
+
+extern "C" int ursn_destroy(ursn_net* net) { delete net; return 0; }
+
+extern "C" int ursn_get_sizes(const ursn_net* net, ursn_sizes* out) {
+  URSN_REQUIRE(net && out, "get_sizes: null argument");
+  *out = net->sizes;
+  return 0;
+}
+
+extern "C" int ursn_param(const ursn_net* net, int64_t index, ursn_param_info* out) {
+  URSN_REQUIRE(net && out, "param: null argument");
+  URSN_REQUIRE(index >= 0 && index < net->sizes.n_tensors, "param: index %lld out of range", (long long)index);
+  const Layer& L = net->layers[index / 2];
+  memset(out, 0, sizeof(*out));
+  if (index % 2 == 0) {
+    snprintf(out->name, sizeof(out->name), "%s/weights", L.name.c_str());
+    out->offset = L.w_off; out->nelem = L.w_n; out->rank = net->cfg.ndim + 2;
+    for (int j = 0; j < net->cfg.ndim; ++j) out->shape[j] = L.k;
+    out->shape[net->cfg.ndim] = L.kind ? L.cout : L.cin;
+    out->shape[net->cfg.ndim + 1] = L.kind ? L.cin : L.cout;
+  } else {
+    snprintf(out->name, sizeof(out->name), "%s/BatchNorm/beta", L.name.c_str());
+    out->offset = L.b_off; out->nelem = L.cout; out->rank = 1; out->shape[0] = L.cout;
+  }
+  return 0;
+}
+
+extern "C" int ursn_zero_grad(ursn_net* net, void* stream) {
+  URSN_REQUIRE(net && net->grads, "zero_grad: net is not trainable");
+  URSN_HIP(hipMemsetAsync(net->grads, 0, (size_t)net->sizes.n_params * sizeof(float), (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int ursn_accum_step(ursn_net* net, const float* data, const float* label, const float* weight, int32_t n,
+                               float* out3, void* stream) {
+  URSN_TRY(check_call(net, data, n));
+  URSN_REQUIRE(net->cfg.trainable && net->grads, "accum_step: net constructed with trainable=False");
+  URSN_REQUIRE(label, "accum_step: input_label is null");
+  URSN_REQUIRE(!net->cfg.use_weight || weight, "Network configured to use loss pixel-weighting. Cannot run w/ input_weight=None");
+  hipStream_t s = (hipStream_t)stream;
+  net->last_n = n;
+  URSN_TRY(forward(net, data, n, s));
+  URSN_TRY(head(net, data, label, net->cfg.use_weight ? weight : nullptr, n, nullptr, true, s));
+  URSN_TRY(backward(net, data, n, s));
+  if (out3) URSN_TRY(read_metrics(net, out3, 3, s));
+  return 0;
+}
+
+extern "C" int ursn_apply_adam(ursn_net* net, float lr, void* stream) {
+  URSN_REQUIRE(net && net->grads, "apply_adam: net is not trainable");
+  const double b1 = 0.9, b2 = 0.999;
+  if (lr <= 0.f) lr = 1e-3f;  // tf.train.AdamOptimizer() default (lib/ssnet.py:72-73)
+  net->adam_t += 1;
+  double lr_t = (double)lr * sqrt(1.0 - pow(b2, (double)net->adam_t)) / (1.0 - pow(b1, (double)net->adam_t));
+  return launch_adam(net->params, net->grads, net->adam_m, net->adam_v, net->sizes.n_params, (float)lr_t, (float)b1,
+                     (float)b2, 1e-8f, (hipStream_t)stream);
+}
+
+extern "C" int ursn_eval(ursn_net* net, const float* data, const float* label, const float* weight, int32_t n,
+                         float* out3, void* stream) {
+  URSN_TRY(check_call(net, data, n));
+  URSN_REQUIRE(label, "eval: input_label is null");
+  URSN_REQUIRE(!net->cfg.use_weight || weight, "Network configured to use loss pixel-weighting. Cannot run w/ input_weight=None");
+  hipStream_t s = (hipStream_t)stream;
+  net->last_n = n;
+  URSN_TRY(forward(net, data, n, s));
+  URSN_TRY(head(net, data, label, net->cfg.use_weight ? weight : nullptr, n, nullptr, false, s));
+  if (out3) URSN_TRY(read_metrics(net, out3, 3, s));
+  return 0;
+}
+
+extern "C" int ursn_infer(ursn_net* net, const float* data, const float* label, int32_t n, float* softmax_out,
+                          float* out2, void* stream) {
+  URSN_TRY(check_call(net, data, n));
+  URSN_REQUIRE(softmax_out, "infer: softmax_out is null");
+  hipStream_t s = (hipStream_t)stream;
+  net->last_n = n;
+  URSN_TRY(forward(net, data, n, s));
+  URSN_TRY(head(net, data, label, nullptr, n, softmax_out, false, s));
+  if (label && out2) URSN_TRY(read_metrics(net, out2, 2, s));
+  else URSN_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+extern "C" int ursn_read_metrics(ursn_net* net, float* out3, void* stream) {
+  URSN_REQUIRE(net && out3, "read_metrics: null argument");
+  return read_metrics(net, out3, 3, (hipStream_t)stream);
+}
+
+extern "C" int ursn_get_adam_step(const ursn_net* net, int64_t* t) {
+  URSN_REQUIRE(net && t, "null argument");
+  *t = net->adam_t;
+  return 0;
+}
+extern "C" int ursn_set_adam_step(ursn_net* net, int64_t t) {
+  URSN_REQUIRE(net && t >= 0, "bad argument");
+  net->adam_t = t;
+  return 0;
+}
+
+extern "C" int ursn_tensor(const ursn_net* net, const char* name, float** ptr, int64_t* voxels, int32_t* channels,
+                           int32_t* cstride) {
+  URSN_REQUIRE(net && name && ptr && voxels && channels && cstride, "tensor: null argument");
+  std::string s(name);
+  bool want_z = false, want_g = false, want_dz = false;
+  auto strip = [&](const char* suf, bool& f) {
+    size_t L = strlen(suf);
+    if (s.size() > L && s.compare(s.size() - L, L, suf) == 0) { f = true; s = s.substr(0, s.size() - L); }
+  };
+  strip(":dz", want_dz);
+  strip(":z", want_z);
+  strip(":grad", want_g);
+  if (want_z || want_dz) {
+    auto it = net->named_z.find(s);
+    URSN_REQUIRE(it != net->named_z.end(), "tensor: no layer named %s", s.c_str());
+    const Layer& L = net->layers[it->second];
+    *ptr = want_z ? L.z : L.dz;
+    *voxels = net->lvox[L.lout];
+    *channels = L.cout;
+    *cstride = L.cout;
+    return 0;
+  }
+  auto it = net->named.find(s);
+  URSN_REQUIRE(it != net->named.end(), "tensor: no activation named %s", s.c_str());
+  *ptr = want_g ? it->second.g : it->second.p;
+  *voxels = net->lvox[it->second.lvl];
+  *channels = it->second.C;
+  *cstride = it->second.cs;
+  return 0;
+}

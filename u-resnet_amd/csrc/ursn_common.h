@@ -1,0 +1,142 @@
+// Internal declarations shared by the HIP translation units of liburesnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/uresnet_hip.h"
+
+void ursn_set_error(const char* fmt, ...);
+
+#define URSN_HIP(expr)                                                                   \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      ursn_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+      return 1;                                                                          \
+    }                                                                                    \
+  } while (0)
+
+#define URSN_REQUIRE(cond, ...)     \
+  do {                              \
+    if (!(cond)) {                  \
+      ursn_set_error(__VA_ARGS__);  \
+      return 2;                     \
+    }                               \
+  } while (0)
+
+#define URSN_TRY(expr)        \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------
+// Gather-convolution geometry.  Every conv-like op of the path (conv s1/s2, 1x1, transposed
+// conv by output-parity class, and all data gradients) is
+//     out[n, q*so+po, :] (+)= sum_t  in[n, q*si + d_t, :] . W_t        (q over q_d)
+// with W_t addressed as w[tap_w[t]*w_tap_stride + k*w_sk + n*w_sn] (k = contraction index).
+// Weight gradients are  dW_t[m][n] = sum_q S[q*si + d_t][m] * C[q][n].
+// Spatial axes are (d0,d1,d2), d2 fastest; 2-D problems use d0 == 1.
+// ---------------------------------------------------------------------------------------
+#define URSN_MAX_TAPS 27
+
+struct GatherGeom {
+  int N;
+  int in_d[3];   // spatial dims of the gathered ("shifted") tensor
+  int out_d[3];  // spatial dims of the output tensor
+  int q_d[3];    // iteration grid
+  int so[3], po[3];
+  int si[3];
+  int ntaps;
+  int tap_d[URSN_MAX_TAPS][3];
+  int tap_w[URSN_MAX_TAPS];
+  int K;   // contraction channels
+  int Nn;  // output channels
+  int in_cs, out_cs;
+  int w_tap_stride, w_sk, w_sn;
+  int accumulate;
+};
+
+// conv kernels (conv_generic.hip)
+int launch_gconv_naive(const GatherGeom& g, const float* in, const float* w, float* out, hipStream_t s);
+int launch_gconv_mfma(const GatherGeom& g, const float* in, const float* w, float* out, hipStream_t s);
+
+struct WgradPlan {
+  int RT, BN, nchunks;
+  int rows;          // T*M
+  size_t scratch_bytes;
+};
+// dW[t][m][n] += sum_q S[q*si+d_t][m] * C[q][n]; S has (in_d, in_cs), C has (q_d, out_cs); M = g.K, N = g.Nn.
+WgradPlan wgrad_plan(const GatherGeom& g);
+int launch_wgrad_naive(const GatherGeom& g, const float* S, const float* C, float* dw, hipStream_t s);
+int launch_wgrad_mfma(const GatherGeom& g, const float* S, const float* C, float* dw, void* scratch,
+                      size_t scratch_bytes, hipStream_t s);
+
+// Geometry builders (conv_geom.cpp part of api)
+enum ConvPass { PASS_FWD = 0, PASS_DGRAD = 1, PASS_WGRAD = 2 };
+// Fills one or more GatherGeom (transposed-type passes need one per output-parity class).
+// Returns number of geoms written (<= 8).
+int build_geoms(const ursn_conv_desc& d, ConvPass pass, GatherGeom* out8);
+
+// ---------------------------------------------------------------------------------------
+// Elementwise / reduction kernels (elementwise.hip)
+// ---------------------------------------------------------------------------------------
+struct BnStats {     // per-layer device block, all arrays [C]
+  double* sum;       // partial-reduced: sum z, sum z^2  (2*C doubles) then mean / var
+  float* mean;
+  float* rstd;
+};
+
+// Reduction scratch: doubles [nblocks][nsums][C]
+size_t reduce_scratch_bytes(int64_t voxels, int channels, int nsums);
+int reduce_nblocks(int64_t voxels, int channels);
+
+// sum z, sum z^2 over voxels -> mean[C], rstd[C] (fp32), two kernels.
+int launch_bn_stats(const float* z, int zcs, int64_t V, int C, float eps, float* mean, float* rstd,
+                    void* scratch, hipStream_t s);
+// y = act(bn(z) [+ bn(z2) | + res]); any of z2/res may be null.
+struct BnActArgs {
+  const float* z; int zcs; const float* mean; const float* rstd; const float* beta;
+  const float* z2; int z2cs; const float* mean2; const float* rstd2; const float* beta2;
+  const float* res; int rescs;
+  float* y; int ycs;
+  int64_t V; int C; int relu;
+};
+int launch_bn_act(const BnActArgs& a, hipStream_t s);
+
+// Backward of the above.  g = dy * (relu ? y > 0 : 1).
+//   dz  = rstd  * (g - mean(g) - xhat  * mean(g*xhat))      dbeta  += sum g
+//   dz2 = rstd2 * (g - mean(g) - xhat2 * mean(g*xhat2))     dbeta2 += sum g     (if z2)
+//   dres (=|+=) g                                                                (if dres)
+struct BnBwdArgs {
+  const float* dy; int dycs; const float* y; int ycs;
+  const float* z; int zcs; const float* mean; const float* rstd; float* dz; int dzcs; float* dbeta;
+  const float* z2; int z2cs; const float* mean2; const float* rstd2; float* dz2; int dz2cs; float* dbeta2;
+  float* dres; int drescs; int dres_accumulate;
+  int64_t V; int C; int relu;
+  void* scratch;
+};
+int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
+
+// Head: logits = bn(z) (mean/rstd/beta may be null => z are logits already).
+struct HeadArgs {
+  const float* z; const float* mean; const float* rstd; const float* beta;
+  const float* data; int data_cs; const float* label; const float* weight;
+  int n; int64_t pix; int ncls;
+  float* softmax_out; float* dlogits;  // nullable
+  double* partial;                     // [nblocks][4]
+  float* metrics;                      // device [3 + 1]
+  void* scratch;
+};
+size_t head_scratch_bytes(int n, int64_t pix);
+int launch_head(const HeadArgs& a, hipStream_t s);
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
+                float eps, hipStream_t s);
+int launch_fill(float* p, float value, int64_t n, hipStream_t s);
+// dst[i] += sum_c src[c*n + i]
+int launch_reduce_accum(float* dst, const float* src, int64_t n, int nchunks, hipStream_t s);
+int launch_mfma_probe(int which, float* out, hipStream_t s);
