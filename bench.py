@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""bench.py -- fwd+bwd images/s of the MI355X-native U-ResNet hot path (BASELINE.json metric).
+
+A "step" is one full reference training iteration with NUM_MINIBATCHES=1 on device-resident synthetic
+LArTPC volumes: zero_gradients -> accum_gradients (forward + loss + backward) -> [RCCL sum-all-reduce
+of the flat gradient buffer when N > 1] -> apply_gradients (TF-form Adam)
+(lib/ssnet_trainval.py:164-191).  Default workload: BASELINE.json configs[2], the 3-D 192^3x1 3-class
+F=8 U-ResNet at batch 4 per GPU, fp32.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel: algorithmic FLOPs / HIP-event launch durations vs the fp32 peak
+  cpu_baseline -- the torch-CPU restatement of the reference graph (oracle "port") timed on the host
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+PEAK_HBM_GBS = 8000.0      # spec; ~6300 achievable
+
+WORKLOADS = {
+    # name: dims, base filters, classes, per-GPU batch, generator
+    "cfg3_3d192_f8_b4": ((192, 192, 192, 1), 8, 3, 4, "lartpc_sparse"),
+    "cfg2_2d512_f16_b16": ((512, 512, 1), 16, 5, 16, "lartpc_sparse"),
+    "cfg1_2d256_f16_b4": ((256, 256, 1), 16, 3, 4, "dense_uniform"),
+    "tiny_3d64_f8_b2": ((64, 64, 64, 1), 8, 3, 2, "lartpc_sparse"),
+}
+
+
+def cpu_baseline_child(size, reps):
+    """Runs in a child process: torch-CPU oracle, one image of size^3, fwd + loss + bwd."""
+    import numpy as np
+    import torch
+    from oracle import uresnet_np as O, uresnet_torch as T
+    from importlib import import_module
+    import uresnet_amd  # noqa: F401
+    sio = import_module("uresnet_amd.synthetic_io")
+    torch.set_num_threads(os.cpu_count() or 1)
+    dims, base, ncls = (size, size, size, 1), 8, 3
+    P = T.params_from_numpy(O.init_params(3, 1, base, ncls, seed=1234, dtype=np.float32), dtype=torch.float32)
+    d, l, w = sio.lartpc_sparse(dims, ncls, 0)
+    w = w / w.sum()
+    best = None
+    for _ in range(reps):
+        t0 = time.time()
+        T.step_gradients(P, dims, base, d[None], l[None], w[None])
+        dt = time.time() - t0
+        best = dt if best is None else min(best, dt)
+    print(json.dumps({"sec_per_image": best, "threads": torch.get_num_threads(), "size": size}))
+
+
+def run_cpu_baseline(full_size):
+    """images/s of the CPU port on a bounded sample; oneDNN first, native ATen if that crashes."""
+    attempts = [(full_size, "1", 2), (96, "0", 2)]
+    for size, mkldnn, reps in attempts:
+        env = dict(os.environ, URSN_ORACLE_MKLDNN=mkldnn)
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(size),
+                                  "--cpu-reps", str(reps)], env=env, capture_output=True, text=True, timeout=900)
+            line = [x for x in out.stdout.strip().split("\n") if x.startswith("{")]
+            if out.returncode != 0 or not line:
+                continue
+            r = json.loads(line[-1])
+            scale = (float(size) / full_size) ** 3   # work is linear in voxels
+            sec_full = r["sec_per_image"] / scale
+            return {"value": 1.0 / sec_full, "unit": "images/s", "cores": r["threads"], "kind": "port",
+                    "sample": "torch-CPU restatement of the reference graph (not TensorFlow), fp32, %s convs: "
+                              "1 image of %d^3x1 (F=8, 3 classes) fwd+loss+bwd, best of %d; %s"
+                              % ("oneDNN" if mkldnn == "1" else "ATen-native", size, reps,
+                                 "measured at full size" if size == full_size else
+                                 "scaled by voxel count to %d^3" % full_size)}
+        except Exception:
+            continue
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3_3d192_f8_b4", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="per-kernel time table on stderr")
+    ap.add_argument("--cpu-baseline-child", type=int, default=0)
+    ap.add_argument("--cpu-reps", type=int, default=2)
+    args = ap.parse_args()
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(args.cpu_baseline_child, args.cpu_reps)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import uresnet_amd  # noqa: F401
+    from uresnet_amd import uresnet, _lib
+    from uresnet_amd import synthetic_io as sio
+    import ctypes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")   # RCCL over xGMI
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    dims, base, ncls, batch, gen = WORKLOADS[args.workload]
+    if args.batch:
+        batch = args.batch
+    net = uresnet(dims=list(dims), num_class=ncls, base_num_outputs=base)
+    net.construct(trainable=True, use_weight=True, learning_rate=1e-4, seed=1234)
+
+    # device-resident synthetic batch, per rank its own entries (weak scaling: per-GPU work fixed)
+    g = sio.GENERATORS[gen]
+    dsz, lsz = int(np.prod(dims)), int(np.prod(dims[:-1]))
+    data = np.empty((batch, dsz), np.float32)
+    label = np.empty((batch, lsz), np.float32)
+    weight = np.empty((batch, lsz), np.float32)
+    for i in range(batch):
+        d, l, w = g(dims, ncls, rank * batch + i)
+        data[i], label[i], weight[i] = d, l, w / w.sum()   # lib/ssnet_trainval.py:173
+    dev = torch.device("cuda", local_rank)
+    data_d, label_d, weight_d = (torch.from_numpy(a).to(dev) for a in (data, label, weight))
+
+    def step():
+        net.zero_gradients(None)
+        net.accum_gradients(None, data_d, label_d, weight_d, fetch=False)
+        net.apply_gradients(None)   # all-reduce(sum) over ranks happens inside when world > 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    lib = _lib.load()
+    _lib.check(lib.ursn_profile_enable(net._handle, 1))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    metrics = net.read_metrics()
+
+    # per-launch HIP-event records of the timed region (rank 0)
+    cnt = ctypes.c_int64(0)
+    _lib.check(lib.ursn_profile_read(net._handle, None, 0, ctypes.byref(cnt)))
+    nrec = 1 << 20
+    recs = (_lib.ursn_prof_rec * nrec)()
+    _lib.check(lib.ursn_profile_read(net._handle, recs, nrec, ctypes.byref(cnt)))
+    _lib.check(lib.ursn_profile_enable(net._handle, 0))
+    by_kernel, t_roof_ms, conv_flops, conv_bytes, all_ms = {}, 0.0, 0.0, 0.0, 0.0
+    for i in range(cnt.value):
+        r = recs[i]
+        k = r.kernel.decode()
+        e = by_kernel.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, conv=r.pass_ <= 2))
+        e["ms"] += r.ms; e["flops"] += r.flops; e["bytes"] += r.bytes; e["launches"] += 1
+        all_ms += r.ms
+        if r.pass_ <= 2:
+            t_roof_ms += max(r.flops / (PEAK_FP32_TFLOPS * 1e9), r.bytes / (PEAK_HBM_GBS * 1e6))
+            conv_flops += r.flops; conv_bytes += r.bytes
+    ms_per_step = elapsed / args.steps * 1e3
+    value = batch * world * args.steps / elapsed
+
+    roofline = None
+    if by_kernel:
+        dom_name, dom = max(((k, v) for k, v in by_kernel.items() if v["conv"]), key=lambda kv: kv[1]["ms"])
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                    "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                    "kernel_share_of_step": round(dom["ms"] / max(all_ms, 1e-9), 3),
+                    # whole-step view: sum over the 58 layers of max(F/P, B/BW) vs measured
+                    "step_T_roof_ms": round(t_roof_ms / args.steps, 3),
+                    "step_frac_of_fp32_roofline": round((t_roof_ms / args.steps) / ms_per_step, 4),
+                    "step_algorithmic_TFLOPs": round(conv_flops / args.steps / 1e12, 3),
+                    "step_HBM_GBs_algorithmic": round(conv_bytes / args.steps / 1e9 / (ms_per_step * 1e-3), 1)}
+    if rank == 0 and args.breakdown:
+        for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"]):
+            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 and v["flops"] else 0.0
+            gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
+            sys.stderr.write("%-24s %8.2f ms/step %6d launches/step %8.2f TFLOP/s %9.1f GB/s(alg)\n" % (
+                k, v["ms"] / args.steps, v["launches"] // args.steps, tf, gb))
+        sys.stderr.write("sum of timed launches %.2f ms/step, wall %.2f ms/step\n" % (all_ms / args.steps, ms_per_step))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and len(dims) == 4:
+        cpu = run_cpu_baseline(int(dims[0]))
+
+    if rank == 0:
+        out = {
+            "metric": "fwd+bwd images/sec on 3D 192^3x1 U-ResNet" if args.workload.startswith("cfg3")
+                      else "fwd+bwd images/sec (%s)" % args.workload,
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "dims": list(dims), "base_filters": base, "num_class": ncls,
+                       "batch_per_gpu": batch, "global_batch": batch * world,
+                       "step": "zero_gradients+accum_gradients(fwd+loss+bwd)+allreduce+adam",
+                       "parallelism": "dp%d" % world},
+            "last_metrics": {"loss": metrics[0], "acc_all": metrics[1], "acc_nonzero": metrics[2]},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,6 +114,21 @@ int ursn_set_adam_step(ursn_net* net, int64_t t);
 int ursn_tensor(const ursn_net* net, const char* name, float** ptr, int64_t* voxels, int32_t* channels,
                 int32_t* cstride);
 
+/* Per-launch timing with HIP events recorded on the launch stream (bench.py roofline leg; the
+ * reference has no counterpart: lib/ssnet_trainval.py:48-49 only reports peak bytes).
+ * pass: 0 conv fwd, 1 conv dgrad, 2 conv wgrad, 3 bn stats, 4 bn apply, 5 bn backward, 6 head. */
+typedef struct ursn_prof_rec {
+  char kernel[48];
+  char layer[96];
+  int32_t pass;
+  float ms;
+  double flops; /* algorithmic: 2*MACs of the layer */
+  double bytes; /* algorithmic: x + y + w (fwd), dy + w + dx (dgrad), x + dy + dw (wgrad) */
+} ursn_prof_rec;
+int ursn_profile_enable(ursn_net* net, int32_t on);
+/* out == NULL: only counts.  Otherwise fills up to max_recs records and clears the log. */
+int ursn_profile_read(ursn_net* net, ursn_prof_rec* out, int64_t max_recs, int64_t* n_out);
+
 /* ---- op-level entry points (unit parity tests; same kernels the net-level calls use) ----- */
 typedef struct ursn_conv_desc {
   int32_t ndim;        /* 2 or 3                                                                   */

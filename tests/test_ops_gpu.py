@@ -106,7 +106,8 @@ def test_conv_channel_strides():
     lib = _lib.load()
     xoff = ctypes.c_void_p(xg.data_ptr() + 8 * 4)
     yoff = ctypes.c_void_p(yfull.data_ptr() + 4 * 4)
-    _lib.check(lib.ursn_conv_forward(ctypes.byref(d), xoff, P(dev(w)), yoff, stream()))
+    wg = dev(w)
+    _lib.check(lib.ursn_conv_forward(ctypes.byref(d), xoff, P(wg), yoff, stream()))
     torch.cuda.synchronize()
     got = yfull.cpu().numpy()
     assert rel_err(got[..., 4:12], y) < TOL
@@ -141,7 +142,8 @@ def test_bn_forward_backward(C, relu, res):
     dz, dbeta = O.bn_bwd(cache, g)
     dzg = torch.empty((V, C), dtype=torch.float32, device="cuda")
     dbg = torch.zeros(C, dtype=torch.float32, device="cuda")
-    _lib.check(lib.ursn_bn_backward(P(dev(dy)), P(yg), P(zg), P(dzg), P(dbg), V, C, 1e-3, relu, P(scratch), nb,
+    dyg = dev(dy)
+    _lib.check(lib.ursn_bn_backward(P(dyg), P(yg), P(zg), P(dzg), P(dbg), V, C, 1e-3, relu, P(scratch), nb,
                                     stream()))
     torch.cuda.synchronize()
     assert rel_err(dzg.cpu().numpy(), dz) < 2e-5
@@ -163,8 +165,10 @@ def test_softmax_ce_head(ncls, use_w):
     sm = torch.empty((n, pix, ncls), dtype=torch.float32, device="cuda")
     dl = torch.empty((n, pix, ncls), dtype=torch.float32, device="cuda")
     out = (ctypes.c_float * 3)()
-    _lib.check(lib.ursn_softmax_ce(P(dev(logits)), P(dev(data)), P(dev(label)), P(dev(w)) if use_w else None, n, pix,
-                                   ncls, P(sm), P(dl), out, P(scratch), 1 << 20, stream()))
+    zg, dg, lg = dev(logits), dev(data), dev(label)  # keep references: P() only holds the raw pointer
+    wg = dev(w) if use_w else None
+    _lib.check(lib.ursn_softmax_ce(P(zg), P(dg), P(lg), P(wg), n, pix, ncls, P(sm), P(dl), out, P(scratch), 1 << 20,
+                                   stream()))
     assert abs(out[0] - m["loss"]) / abs(m["loss"]) < 1e-5
     assert abs(out[1] - m["acc_all"]) < 1e-6
     assert abs(out[2] - m["acc_nonzero"]) < 1e-6
@@ -178,8 +182,9 @@ def test_head_no_nonzero_pixels_gives_nan():
     scratch = torch.empty(1 << 16, dtype=torch.uint8, device="cuda")
     out = (ctypes.c_float * 3)()
     z = torch.zeros((n, pix, ncls), device="cuda")
-    _lib.check(lib.ursn_softmax_ce(P(z), P(torch.zeros(n, pix, device="cuda")), P(torch.zeros(n, pix, device="cuda")),
-                                   None, n, pix, ncls, None, None, out, P(scratch), 1 << 16, stream()))
+    d0, l0 = torch.zeros(n, pix, device="cuda"), torch.zeros(n, pix, device="cuda")
+    _lib.check(lib.ursn_softmax_ce(P(z), P(d0), P(l0), None, n, pix, ncls, None, None, out, P(scratch), 1 << 16,
+                                   stream()))
     assert np.isnan(out[2]) and out[1] == 1.0 and abs(out[0] - pix * np.log(3)) < 1e-3
 
 
@@ -193,7 +198,9 @@ def test_adam_tf_form():
     for t in range(1, 4):
         g = rng.standard_normal(n) * 10.0 ** rng.integers(-6, 2, n)
         opt.apply(p, {"a": g})
-        _lib.check(lib.ursn_adam(P(pg), P(dev(g)), P(mg), P(vg), n, 1e-3, 0.9, 0.999, 1e-8, t, stream()))
+        gg = dev(g)
+        _lib.check(lib.ursn_adam(P(pg), P(gg), P(mg), P(vg), n, 1e-3, 0.9, 0.999, 1e-8, t, stream()))
+        torch.cuda.synchronize()
     torch.cuda.synchronize()
     assert rel_err(pg.cpu().numpy(), p["a"]) < 1e-6
 

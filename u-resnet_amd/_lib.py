@@ -29,6 +29,11 @@ class ursn_conv_desc(C.Structure):
                 ("in_cstride", C.c_int32), ("out_cstride", C.c_int32), ("algo", C.c_int32)]
 
 
+class ursn_prof_rec(C.Structure):
+    _fields_ = [("kernel", C.c_char * 48), ("layer", C.c_char * 96), ("pass_", C.c_int32), ("ms", C.c_float),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
 _P = C.c_void_p
 _SIGS = {
     "ursn_abi_version": (C.c_int, []),
@@ -48,6 +53,8 @@ _SIGS = {
     "ursn_set_adam_step": (C.c_int, [_P, C.c_int64]),
     "ursn_tensor": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                               C.POINTER(C.c_int32)]),
+    "ursn_profile_enable": (C.c_int, [_P, C.c_int32]),
+    "ursn_profile_read": (C.c_int, [_P, C.POINTER(ursn_prof_rec), C.c_int64, C.POINTER(C.c_int64)]),
     "ursn_conv_forward": (C.c_int, [C.POINTER(ursn_conv_desc), _P, _P, _P, _P]),
     "ursn_conv_backward_data": (C.c_int, [C.POINTER(ursn_conv_desc), _P, _P, _P, C.c_int32, _P]),
     "ursn_conv_backward_weight": (C.c_int, [C.POINTER(ursn_conv_desc), _P, _P, _P, _P, C.c_size_t, _P]),

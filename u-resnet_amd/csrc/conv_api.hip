@@ -13,6 +13,9 @@ void ursn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* ursn_last_error(void) { return g_err; }
+static thread_local const char* g_kernel = "";
+void ursn_note_kernel(const char* name) { g_kernel = name; }
+extern "C" const char* ursn_last_kernel_name() { return g_kernel; }
 extern "C" int ursn_abi_version(void) { return URSN_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------------------------

@@ -44,6 +44,7 @@ __global__ void gconv_naive_kernel(GatherGeom g, const float* __restrict__ in, c
 }
 
 int launch_gconv_naive(const GatherGeom& g, const float* in, const float* w, float* out, hipStream_t s) {
+  ursn_note_kernel("gconv_naive");
   int64_t total = (int64_t)g.N * g.q_d[0] * g.q_d[1] * g.q_d[2] * g.Nn;
   if (total == 0) return 0;
   int blocks = (int)(cdiv64(total, 256) < 65536 ? cdiv64(total, 256) : 65536);
@@ -235,12 +236,14 @@ int launch_gconv_mfma(const GatherGeom& g, const float* in, const float* w, floa
   int steps = g.ntaps * ((g.K + 3) / 4);
   bool ksplit = blocks_ks1 < 512 && steps >= 16;
   if (!ksplit) {
-    if (bn == 4) return launch_gconv_t<4, 4, 1>(g, in, w, out, s);
-    if (bn == 2) return launch_gconv_t<4, 2, 1>(g, in, w, out, s);
+    if (bn == 4) { ursn_note_kernel("gconv_mfma<4,4,1>"); return launch_gconv_t<4, 4, 1>(g, in, w, out, s); }
+    if (bn == 2) { ursn_note_kernel("gconv_mfma<4,2,1>"); return launch_gconv_t<4, 2, 1>(g, in, w, out, s); }
+    ursn_note_kernel("gconv_mfma<4,1,1>");
     return launch_gconv_t<4, 1, 1>(g, in, w, out, s);
   }
-  if (bn == 4) return launch_gconv_t<1, 4, 4>(g, in, w, out, s);
-  if (bn == 2) return launch_gconv_t<1, 2, 4>(g, in, w, out, s);
+  if (bn == 4) { ursn_note_kernel("gconv_mfma<1,4,4>"); return launch_gconv_t<1, 4, 4>(g, in, w, out, s); }
+  if (bn == 2) { ursn_note_kernel("gconv_mfma<1,2,4>"); return launch_gconv_t<1, 2, 4>(g, in, w, out, s); }
+  ursn_note_kernel("gconv_mfma<1,1,4>");
   return launch_gconv_t<1, 1, 4>(g, in, w, out, s);
 }
 
@@ -412,10 +415,10 @@ int launch_wgrad_mfma(const GatherGeom& g, const float* S, const float* C, float
   // by handing out one geom with all taps.
   float* slab = (float*)scratch;
   int rc;
-  if (p.BN == 4) rc = launch_wgrad_t<4, 4>(g, p, S, C, slab, s);
-  else if (p.BN == 2) rc = launch_wgrad_t<7, 2>(g, p, S, C, slab, s);
-  else if (p.RT == 14) rc = launch_wgrad_t<14, 1>(g, p, S, C, slab, s);
-  else rc = launch_wgrad_t<7, 1>(g, p, S, C, slab, s);
+  if (p.BN == 4) { ursn_note_kernel("wgrad_mfma<4,4>"); rc = launch_wgrad_t<4, 4>(g, p, S, C, slab, s); }
+  else if (p.BN == 2) { ursn_note_kernel("wgrad_mfma<7,2>"); rc = launch_wgrad_t<7, 2>(g, p, S, C, slab, s); }
+  else if (p.RT == 14) { ursn_note_kernel("wgrad_mfma<14,1>"); rc = launch_wgrad_t<14, 1>(g, p, S, C, slab, s); }
+  else { ursn_note_kernel("wgrad_mfma<7,1>"); rc = launch_wgrad_t<7, 1>(g, p, S, C, slab, s); }
   if (rc) return rc;
   int64_t per = (int64_t)p.rows * g.Nn;
   int blocks = (int)(cdiv64(per, 256) < 2048 ? cdiv64(per, 256) : 2048);

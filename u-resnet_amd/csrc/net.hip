@@ -30,6 +30,8 @@ struct Arena {
   float* floats(int64_t n) { return (float*)take((size_t)n * sizeof(float)); }
 };
 
+const char* g_last_kernel_dummy = "";
+
 struct Act {       // activation tensor view (+ gradient view with identical layout)
   float* p = nullptr;
   float* g = nullptr;
@@ -76,6 +78,12 @@ struct ursn_net {
   size_t wg_scratch_bytes = 0;
   int64_t adam_t = 0;
   int last_n = 0;
+  // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
+  bool profile = false;
+  struct ProfRec { int layer; int pass; const char* kernel; double flops; double bytes; hipEvent_t e0, e1; };
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
   std::map<std::string, Act> named;       // debug lookup: activations
   std::map<std::string, int> named_z;     // layer name -> layer index
 };
@@ -248,6 +256,42 @@ int plan(ursn_net* n, Arena& A) {
   return 0;
 }
 
+// ---- profiling ------------------------------------------------------------------------------
+extern "C" const char* ursn_last_kernel_name();
+hipEvent_t prof_event(ursn_net* n) {
+  if (n->ev_used == n->ev_pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    n->ev_pool.push_back(e);
+  }
+  return n->ev_pool[n->ev_used++];
+}
+struct ProfScope {
+  ursn_net* n; hipStream_t s; int idx = -1;
+  ProfScope(ursn_net* n_, hipStream_t s_, int layer, int pass, double flops, double bytes) : n(n_), s(s_) {
+    if (!n->profile || n->prof.size() > 200000) return;
+    ursn_net::ProfRec r{layer, pass, "", flops, bytes, prof_event(n), prof_event(n)};
+    if (!r.e0 || !r.e1) return;
+    hipEventRecord(r.e0, s);
+    n->prof.push_back(r);
+    idx = (int)n->prof.size() - 1;
+  }
+  void done(const char* kernel) {
+    if (idx < 0) return;
+    n->prof[idx].kernel = kernel;
+    hipEventRecord(n->prof[idx].e1, s);
+  }
+};
+double layer_macs(const ursn_net* n, const Layer& L, int N) {
+  double taps = 1;
+  for (int j = 0; j < n->cfg.ndim; ++j) taps *= L.k;
+  double vox = (double)N * (L.kind ? n->lvox[L.lin] : n->lvox[L.lout]);
+  return vox * taps * L.cin * L.cout;
+}
+double layer_bytes(const ursn_net* n, const Layer& L, int N) {  // x + y + w  (== dy + w + dx == x + dy + dw)
+  return 4.0 * ((double)N * n->lvox[L.lin] * L.cin + (double)N * n->lvox[L.lout] * L.cout + (double)L.w_n);
+}
+
 // ---- forward pieces -----------------------------------------------------------------------
 int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s) {
   Layer& L = n->layers[li];
@@ -255,9 +299,17 @@ int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s) {
   d.n = N;
   d.in_cstride = in.cs;
   d.out_cstride = L.cout;
-  URSN_TRY(conv_dispatch(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, s));
-  URSN_TRY(launch_bn_stats(L.z, L.cout, (int64_t)N * n->lvox[L.lout], L.cout, n->cfg.bn_eps, L.mean, L.rstd,
-                           n->red_scratch, s));
+  {
+    ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
+    URSN_TRY(conv_dispatch(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, s));
+    ps.done(ursn_last_kernel_name());
+  }
+  {
+    ProfScope ps(n, s, li, 3, 0.0, 4.0 * N * n->lvox[L.lout] * L.cout);
+    URSN_TRY(launch_bn_stats(L.z, L.cout, (int64_t)N * n->lvox[L.lout], L.cout, n->cfg.bn_eps, L.mean, L.rstd,
+                             n->red_scratch, s));
+    ps.done("bn_stats");
+  }
   return 0;
 }
 
@@ -272,7 +324,10 @@ int bn_out(ursn_net* n, int li, const Act& out, int relu, int N, int li2, const 
   }
   a.res = res; a.rescs = rescs;
   a.y = out.p; a.ycs = out.cs; a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.cout; a.relu = relu;
-  return launch_bn_act(a, s);
+  ProfScope ps(n, s, li, 4, 0.0, 4.0 * a.V * a.C * (2 + (li2 >= 0) + (res != nullptr)));
+  URSN_TRY(launch_bn_act(a, s));
+  ps.done("bn_act");
+  return 0;
 }
 
 int unit_fwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
@@ -319,7 +374,10 @@ int head(ursn_net* n, const float* data, const float* label, const float* weight
   a.label = label; a.weight = weight; a.n = N; a.pix = n->lvox[0]; a.ncls = n->cfg.num_class;
   a.softmax_out = softmax_out; a.dlogits = want_grad ? n->dlog : nullptr;
   a.scratch = n->head_scratch; a.metrics = n->metrics;
-  return launch_head(a, s);
+  ProfScope ps(n, s, n->conv2, 6, 0.0, 4.0 * N * n->lvox[0] * (2.0 * a.ncls + 3));
+  URSN_TRY(launch_head(a, s));
+  ps.done("head");
+  return 0;
 }
 
 // ---- backward pieces ----------------------------------------------------------------------
@@ -337,9 +395,13 @@ int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStre
   d.out_cstride = L.cout;
   if (need_dgrad) {
     bool acc = take_flag(n, in);
+    ProfScope ps(n, s, li, 1, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
     URSN_TRY(conv_dispatch(d, PASS_DGRAD, L.dz, n->params + L.w_off, in.g, acc ? 1 : 0, s));
+    ps.done(ursn_last_kernel_name());
   }
+  ProfScope ps(n, s, li, 2, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
   URSN_TRY(wgrad_dispatch(d, in.p, L.dz, n->grads + L.w_off, n->wg_scratch, n->wg_scratch_bytes, s));
+  ps.done(ursn_last_kernel_name());
   return 0;
 }
 
@@ -358,7 +420,10 @@ int bn_back(ursn_net* n, int li, const float* dy, int dycs, const float* y, int 
   }
   a.dres = dres; a.drescs = drescs; a.dres_accumulate = dres_acc;
   a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.cout; a.relu = relu; a.scratch = n->red_scratch;
-  return launch_bn_bwd(a, s);
+  ProfScope ps(n, s, li, 5, 0.0, 4.0 * a.V * a.C * (2.0 * (2 + relu + (li2 >= 0)) + 1 + (li2 >= 0) + (dres != nullptr)));
+  URSN_TRY(launch_bn_bwd(a, s));
+  ps.done("bn_bwd");
+  return 0;
 }
 
 int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
@@ -583,5 +648,35 @@ extern "C" int ursn_tensor(const ursn_net* net, const char* name, float** ptr, i
   *voxels = net->lvox[it->second.lvl];
   *channels = it->second.C;
   *cstride = it->second.cs;
+  return 0;
+}
+
+// ---- profiling C-ABI --------------------------------------------------------------------------
+extern "C" int ursn_profile_enable(ursn_net* net, int32_t on) {
+  URSN_REQUIRE(net, "null handle");
+  net->profile = on != 0;
+  net->prof.clear();
+  net->ev_used = 0;
+  return 0;
+}
+
+extern "C" int ursn_profile_read(ursn_net* net, ursn_prof_rec* out, int64_t max_recs, int64_t* n_out) {
+  URSN_REQUIRE(net && n_out, "null argument");
+  int64_t cnt = 0;
+  for (size_t i = 0; i < net->prof.size() && cnt < max_recs; ++i) {
+    const ursn_net::ProfRec& r = net->prof[i];
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    if (out) {
+      ursn_prof_rec& o = out[cnt];
+      memset(&o, 0, sizeof(o));
+      snprintf(o.kernel, sizeof(o.kernel), "%s", r.kernel);
+      snprintf(o.layer, sizeof(o.layer), "%s", net->layers[r.layer].name.c_str());
+      o.pass = r.pass; o.ms = ms; o.flops = r.flops; o.bytes = r.bytes;
+    }
+    ++cnt;
+  }
+  *n_out = cnt;
+  if (out) { net->prof.clear(); net->ev_used = 0; }
   return 0;
 }

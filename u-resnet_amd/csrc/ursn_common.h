@@ -7,6 +7,7 @@
 #include "../../include/uresnet_hip.h"
 
 void ursn_set_error(const char* fmt, ...);
+void ursn_note_kernel(const char* name);  // remembered per thread for the profiling log
 
 #define URSN_HIP(expr)                                                                   \
   do {                                                                                   \
