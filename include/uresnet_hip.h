@@ -145,6 +145,10 @@ typedef struct ursn_conv_desc {
 
 /* y = conv(x, w).  w layout [k..,Cin,Cout] (transposed: [k..,Cout,Cin]). */
 int ursn_conv_forward(const ursn_conv_desc* d, const float* x, const float* w, float* y, void* stream);
+/* y = conv(x, w) plus the batch statistics BatchNorm needs: mean[cout], rstd[cout] = rsqrt(var+eps)
+ * (slim.batch_norm as normalizer_fn, lib/uresnet.py:42).  scratch >= ursn_bn_scratch_bytes(out voxels, cout). */
+int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, const float* w, float* y, float* mean,
+                            float* rstd, float eps, void* scratch, size_t scratch_bytes, void* stream);
 /* dx (=|+=) conv^T(dy, w); accumulate != 0 adds into dx. */
 int ursn_conv_backward_data(const ursn_conv_desc* d, const float* dy, const float* w, float* dx,
                             int32_t accumulate, void* stream);

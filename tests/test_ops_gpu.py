@@ -226,3 +226,62 @@ def test_mfma_probe_layouts():
     assert np.array_equal(res[3], np.repeat((12 + np.arange(4) + 1)[None, :], 64, 0).astype(np.float32))
     # cbsz=2, abid=1: blocks 4g..4g+3 use A of block 4g+1
     assert np.array_equal(res[4], (4 * (4 * (lane[:, None] >> 4) + 1) + np.arange(4)[None, :] + 1).astype(np.float32))
+
+
+TILED_CASES = [
+    # ndim, N, S, cin, cout  (k3 s1; shapes chosen to hit partial tiles, segment seams and image borders)
+    (3, 1, (16, 8, 32), 8, 8),
+    (3, 2, (16, 24, 64), 8, 8),
+    (3, 1, (19, 13, 45), 16, 8),      # ragged: partial tiles in y and x, odd z
+    (3, 1, (32, 16, 32), 8, 16),
+    (3, 1, (16, 16, 48), 16, 16),
+    (2, 2, (16, 256), 16, 16),
+    (2, 1, (37, 300), 16, 16),        # ragged 2-D
+    (2, 1, (16, 512), 32, 16),
+    (2, 1, (24, 256), 8, 8),
+]
+
+
+@pytest.mark.parametrize("case", TILED_CASES)
+def test_tiled_conv_fwd_dgrad(case):
+    """Family-I kernels (v_mfma_f32_4x4x1_16b, LDS plane ring) forced with algo=3."""
+    ndim, N, S, ci, co = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (3,) * ndim + (ci, co)) * 0.2
+    y = O.conv_fwd(x, w, 1)
+    dy = _rand(rng, y.shape)
+    dx, _ = O.conv_bwd(x, w, 1, dy)
+    d = desc(ndim, N, S, ci, co, 3, 1, algo=3)
+    xg, wg, dyg = dev(x), dev(w), dev(dy)
+    assert rel_err(conv_forward(d, xg, wg, y.shape).cpu().numpy(), y) < TOL
+    assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
+    base = torch.ones(x.shape, dtype=torch.float32, device="cuda")
+    dxa = conv_backward_data(d, dyg, wg, x.shape, accumulate=1, dx_init=base)
+    assert rel_err(dxa.cpu().numpy(), dx + 1.0) < TOL
+
+
+@pytest.mark.parametrize("case", [(3, 2, (16, 16, 16), 8, 8), (3, 1, (19, 13, 45), 16, 8), (3, 2, (8, 12, 16), 8, 16),
+                                  (2, 1, (37, 300), 16, 16), (2, 2, (16, 24), 16, 16)])
+def test_conv_forward_fused_statistics(case):
+    """BN statistics produced by the conv epilogue (tiled shapes) / the reduction kernel (others)."""
+    ndim, N, S, ci, co = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = _rand(rng, (N,) + S + (ci,)) + 0.7
+    w = _rand(rng, (3,) * ndim + (ci, co)) * 0.2
+    y = O.conv_fwd(x, w, 1)
+    ax = tuple(range(y.ndim - 1))
+    mu, var = y.mean(axis=ax), y.var(axis=ax)
+    lib = _lib.load()
+    d = desc(ndim, N, S, ci, co, 3, 1)
+    xg, wg = dev(x), dev(w)
+    yg = torch.empty(y.shape, dtype=torch.float32, device="cuda")
+    mg, rg = torch.empty(co, device="cuda"), torch.empty(co, device="cuda")
+    nb = 1 << 22
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.ursn_conv_forward_stats(ctypes.byref(d), P(xg), P(wg), P(yg), P(mg), P(rg), 1e-3, P(scratch), nb,
+                                           stream()))
+    torch.cuda.synchronize()
+    assert rel_err(yg.cpu().numpy(), y) < TOL
+    assert np.abs(mg.cpu().numpy() - mu).max() < 2e-6 * np.sqrt(var.max())  + 1e-6 * np.abs(mu).max()
+    assert rel_err(rg.cpu().numpy(), 1 / np.sqrt(var + 1e-3)) < 1e-5

@@ -56,6 +56,7 @@ _SIGS = {
     "ursn_profile_enable": (C.c_int, [_P, C.c_int32]),
     "ursn_profile_read": (C.c_int, [_P, C.POINTER(ursn_prof_rec), C.c_int64, C.POINTER(C.c_int64)]),
     "ursn_conv_forward": (C.c_int, [C.POINTER(ursn_conv_desc), _P, _P, _P, _P]),
+    "ursn_conv_forward_stats": (C.c_int, [C.POINTER(ursn_conv_desc), _P, _P, _P, _P, _P, C.c_float, _P, C.c_size_t, _P]),
     "ursn_conv_backward_data": (C.c_int, [C.POINTER(ursn_conv_desc), _P, _P, _P, C.c_int32, _P]),
     "ursn_conv_backward_weight": (C.c_int, [C.POINTER(ursn_conv_desc), _P, _P, _P, _P, C.c_size_t, _P]),
     "ursn_conv_wgrad_scratch_bytes": (C.c_size_t, [C.POINTER(ursn_conv_desc)]),

@@ -6,7 +6,8 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "liburesnet_hip.so")
-SOURCES = ["conv_generic.hip", "conv_tiled.hip", "elementwise.hip", "conv_api.hip", "net.hip"]
+SOURCES = ["conv_generic.hip", "conv_tiled.hip", "conv_tiled_3d.hip", "conv_tiled_2d.hip", "elementwise.hip",
+           "conv_api.hip", "net.hip"]
 
 
 def needs_build():
@@ -22,8 +23,27 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-pass-failed", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-Wno-unused-value"]
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(CSRC, "..", "..", "include", "uresnet_hip.h")]
+    hdr_t = max(os.path.getmtime(h) for h in hdrs)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        srcp = os.path.join(CSRC, src)
+        if not force and os.path.isfile(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), hdr_t):
+            return obj
+        cmd = [hipcc] + flags + ["-c", srcp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

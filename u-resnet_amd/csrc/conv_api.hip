@@ -239,6 +239,29 @@ extern "C" int ursn_conv_forward(const ursn_conv_desc* d, const float* x, const 
   return conv_dispatch(*d, PASS_FWD, x, w, y, 0, (hipStream_t)stream);
 }
 
+// conv + batch statistics of its output (mean, rstd = rsqrt(var+eps)); the tiled kernels fuse the
+// statistics partials into the conv epilogue, other shapes run the separate reduction.
+extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, const float* w, float* y, float* mean,
+                                       float* rstd, float eps, void* scratch, size_t scratch_bytes, void* stream) {
+  URSN_REQUIRE(d && x && w && y && mean && rstd && scratch, "conv_forward_stats: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  GatherGeom g[8];
+  URSN_REQUIRE(build_geoms(*d, PASS_FWD, g) >= 1, "conv_forward_stats: bad descriptor");
+  int64_t V = (int64_t)d->n;
+  for (int j = 0; j < 3; ++j) V *= g[0].out_d[j];
+  if (d->transposed) { V = (int64_t)d->n; for (int j = 0; j < d->ndim; ++j) V *= 2 * d->in_sp[j]; }
+  const int ocs = d->out_cstride > 0 ? d->out_cstride : d->cout;
+  if ((d->algo == 0 || d->algo == 3) && tiled_conv_supported(*d, PASS_FWD)) {
+    int nb = tiled_conv_stats_blocks(*d);
+    URSN_REQUIRE((size_t)nb * 2 * d->cout * sizeof(double) <= scratch_bytes, "conv_forward_stats: scratch too small");
+    URSN_TRY(launch_tiled_conv_stats(*d, PASS_FWD, x, w, y, 0, (double*)scratch, s));
+    return launch_bn_stats_final((const double*)scratch, nb, d->cout, V, eps, mean, rstd, s);
+  }
+  URSN_REQUIRE(reduce_scratch_bytes(V, d->cout, 2) <= scratch_bytes, "conv_forward_stats: scratch too small");
+  URSN_TRY(conv_dispatch(*d, PASS_FWD, x, w, y, 0, s));
+  return launch_bn_stats(y, ocs, V, d->cout, eps, mean, rstd, scratch, s);
+}
+
 extern "C" int ursn_conv_backward_data(const ursn_conv_desc* d, const float* dy, const float* w, float* dx,
                                        int32_t accumulate, void* stream) {
   URSN_REQUIRE(d && dy && w && dx, "conv_backward_data: null argument");

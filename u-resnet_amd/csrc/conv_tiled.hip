@@ -1,12 +1,81 @@
-// LDS-tiled small-channel convolution kernels (family I).  Placeholder: reports "unsupported" so every
-// layer takes the generic path until the tiled kernels land.
-#include "ursn_common.h"
+// Host side of the LDS-tiled small-channel convolution kernels (kernel: conv_tiled_kernel.h).
+#include "conv_tiled_kernel.h"
 
-int tiled_conv_supported(const ursn_conv_desc&, ConvPass) { return 0; }
-int launch_tiled_conv(const ursn_conv_desc&, ConvPass, const float*, const float*, float*, int, hipStream_t) {
-  ursn_set_error("tiled conv: not built");
-  return 3;
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+static bool tiled_shape_ok(int cin, int cout, int mode) {
+  // register budget: weights (27|9)*cin*cout/64 VGPRs must leave room for two waves per SIMD
+  int taps = mode == 3 ? 27 : 9;
+  if (cin % 4 || cout % 4 || cin < 4 || cout < 4) return false;
+  // instantiated shapes (weights + accumulators must fit 256 VGPRs for two waves per SIMD)
+  if (mode == 3) return (cin == 8 || cin == 16) && (cout == 8 || cout == 16);
+  if ((cin == 8 || cin == 16) && (cout == 8 || cout == 16)) return true;
+  return (cin == 32 && cout == 16) || (cin == 16 && cout == 32);
 }
+
+static bool make_plan(const ursn_conv_desc& d, ConvPass pass, TPlan& p) {
+  if (d.transposed || d.k != 3 || d.stride != 1) return false;
+  if (pass != PASS_FWD && pass != PASS_DGRAD) return false;
+  p.mode = d.ndim;
+  p.flip = (pass == PASS_DGRAD);
+  p.cin = p.flip ? d.cout : d.cin;
+  p.cout = p.flip ? d.cin : d.cout;
+  if (!tiled_shape_ok(p.cin, p.cout, p.mode)) return false;
+  const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+  if ((ics & 3) || (ocs & 3)) return false;
+  if (d.ndim == 3) { p.Z = d.in_sp[0]; p.Y = d.in_sp[1]; p.X = d.in_sp[2]; }
+  else { p.Z = d.in_sp[0]; p.Y = 1; p.X = d.in_sp[1]; }
+  const int TX = p.mode == 3 ? 32 : 256, TY = p.mode == 3 ? 8 : 1;
+  // only worth it when tiles are reasonably full
+  if (p.X < TX / 2 || p.Y < TY || p.Z < 8) return false;
+  p.ntx = (p.X + TX - 1) / TX;
+  p.nty = (p.Y + TY - 1) / TY;
+  // enough workgroups to fill 256 CUs x 2, but long marches to amortise the prologue and weight load
+  int64_t base = (int64_t)d.n * p.ntx * p.nty;
+  int nz = 1;
+  while (base * nz < 1024 && p.Z / (nz * 2) >= 8) nz *= 2;
+  p.zseg = (p.Z + nz - 1) / nz;
+  p.nzseg = (p.Z + p.zseg - 1) / p.zseg;
+  const int PX = TX + 2, PY = TY + (p.mode == 3 ? 2 : 0);
+  p.lds = (size_t)4 * (p.cin / 4) * PX * PY * 16;
+  if (p.lds > 160 * 1024) return false;
+  p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
+  return true;
+}
+
+int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass) {
+  TPlan p;
+  return make_plan(d, pass, p) ? 1 : 0;
+}
+
+int tiled_conv_stats_blocks(const ursn_conv_desc& d) {
+  TPlan p;
+  return make_plan(d, PASS_FWD, p) ? p.grid : 0;
+}
+
+int launch_tiled_conv_stats(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
+                            int accumulate, double* stats_partial, hipStream_t s) {
+  TPlan p;
+  URSN_REQUIRE(make_plan(d, pass, p), "tiled conv: unsupported shape");
+  TConvArgs a;
+  a.in = in; a.w = w; a.out = out; a.stats_partial = stats_partial;
+  a.N = d.n; a.Z = p.Z; a.Y = p.Y; a.X = p.X;
+  const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+  a.in_cs = p.flip ? ocs : ics;
+  a.out_cs = p.flip ? ics : ocs;
+  a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
+  a.accumulate = accumulate;
+  a.cin_w = d.cin; a.cout_w = d.cout;
+  return p.mode == 3 ? tconv_dispatch_3d(p, a, s) : tconv_dispatch_2d(p, a, s);
+}
+
+int launch_tiled_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
+                      int accumulate, hipStream_t s) {
+  return launch_tiled_conv_stats(d, pass, in, w, out, accumulate, nullptr, s);
+}
+
+// weight gradient: not yet tiled
 int tiled_wgrad_supported(const ursn_conv_desc&) { return 0; }
 size_t tiled_wgrad_scratch_bytes(const ursn_conv_desc&) { return 0; }
 int launch_tiled_wgrad(const ursn_conv_desc&, const float*, const float*, float*, void*, size_t, hipStream_t) {

@@ -1,0 +1,235 @@
+// LDS-tiled direct convolution for the full-resolution, small-channel layers (k3, stride 1) -- gfx950.
+//
+// These layers carry ~70 % of the network's FLOPs with Cin/Cout in {8,16,32}: too narrow for the 16- or
+// 32-wide MFMA shapes (half of every tile would be padding).  v_mfma_f32_4x4x1_16b_f32 has the right
+// granularity: 16 independent 4x4 outer products per instruction, at the full fp32 rate (64 FLOP/clk/SIMD).
+//
+//   lane  = one output voxel (B operand: x[voxel + tap][ci], one float per lane)
+//   A     = 4 output channels of one (tap, ci) weight row, BROADCAST from one 4-lane block to all 16 blocks
+//           (cbsz = 4, abid = block): one VGPR holds 16 (tap,ci) rows x 4 cout, so ALL weights of a layer
+//           (27*Cin*Cout/64 VGPRs) stay in registers for the whole kernel -- no weight traffic in the loop
+//   D     = 4 cout of the lane's voxel per accumulator; Cout/4 accumulators per lane
+//
+// A workgroup (4 waves) owns a TYxTX tile of the two fastest axes and marches along the slowest axis,
+// keeping a ring of 4 input planes (with halo) in LDS as [cin/4][y][x] float4 so every ds_read_b128 of a
+// wave is 1 KiB contiguous (bank-conflict free).  Plane z+2 is fetched into registers before the
+// MFMA block of plane z and written to LDS after it (one barrier per plane).  BatchNorm statistics
+// (sum, sum of squares per channel) are accumulated per lane in the epilogue and reduced once per
+// workgroup, which removes the separate statistics pass over the conv output.
+//
+// The same kernel evaluates the stride-1 data gradient (taps flipped, weight matrix transposed at
+// register-load time).
+#pragma once
+#include <utility>
+
+#include "ursn_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: the MFMA broadcast selector (abid) must be an integer constant expression
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+struct TConvArgs {
+  const float* in;
+  const float* w;
+  float* out;
+  double* stats_partial;  // [grid][2][cout] or null
+  int N, Z, Y, X;         // 2-D problems: Z = H, Y = 1, X = W
+  int in_cs, out_cs;
+  int zseg;               // planes per workgroup
+  int nzseg, nty, ntx;
+  int accumulate;
+  int cin_w, cout_w;      // dims of the weight tensor as stored: [t][cin_w][cout_w]
+};
+
+template <int MODE> struct Tile;
+template <> struct Tile<3> { static constexpr int TX = 32, TY = 8, NTY = 3, NT = 27; };
+template <> struct Tile<2> { static constexpr int TX = 256, TY = 1, NTY = 1, NT = 9; };
+
+// CIN = contraction channels, COUT = produced channels (already swapped for the data gradient).
+template <int CIN, int COUT, int MODE, bool FLIP>
+__global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
+  constexpr bool STATS = !FLIP;  // the data gradient never feeds a BatchNorm
+  using TL = Tile<MODE>;
+  constexpr int TX = TL::TX, TY = TL::TY, NTY = TL::NTY, NT = TL::NT;
+  constexpr int PX = TX + 2, PY = TY + (NTY == 3 ? 2 : 0), PS = PX * PY;
+  constexpr int NQ = CIN / 4, CQ = COUT / 4;
+  constexpr int KTOT = NT * CIN, R = (KTOT + 15) / 16;
+  constexpr int NSTAGE = (NQ * PS + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];  // [4 ring slots][NQ][PS]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  int bid = blockIdx.x;
+  const int xt = bid % a.ntx; bid /= a.ntx;
+  const int yt = bid % a.nty; bid /= a.nty;
+  const int zs = bid % a.nzseg;
+  const int n = bid / a.nzseg;
+  const int x0 = xt * TX, y0 = yt * TY;
+  const int z0 = zs * a.zseg;
+  const int z1 = (z0 + a.zseg < a.Z) ? z0 + a.zseg : a.Z;
+  const int ty = tid / TX, tx = tid % TX;
+  const int gy = y0 + ty, gx = x0 + tx;
+  const bool vox_ok = gy < a.Y && gx < a.X;
+
+  // ---- weights -> registers: wreg[cq][r], lane l holds W'[k = 16r + (l>>2)][co = 4cq + (l&3)] -------------
+  float wreg[CQ][R];
+  {
+    const int kl = lane >> 2, cl = lane & 3;
+#pragma unroll
+    for (int cq = 0; cq < CQ; ++cq)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int k = 16 * r + kl;
+        int t = k / CIN, kk = k - t * CIN;
+        int co = 4 * cq + cl;
+        float v = 0.f;
+        if (k < KTOT) {
+          if (!FLIP) v = a.w[((size_t)t * a.cin_w + kk) * a.cout_w + co];        // W[t][ci=kk][co]
+          else v = a.w[((size_t)(NT - 1 - t) * a.cin_w + co) * a.cout_w + kk];   // W[T-1-t][ci=co][co=kk]
+        }
+        wreg[cq][r] = v;
+      }
+  }
+
+  // ---- plane staging --------------------------------------------------------------------------------------
+  f32x4 stage[NSTAGE];
+  auto stage_load = [&](int zin) {
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+      int idx = tid + i * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < NQ * PS) {
+        int q = idx / PS, s = idx - q * PS;
+        int yy = s / PX, xx = s - yy * PX;
+        int py = y0 + yy - (NTY == 3 ? 1 : 0), px = x0 + xx - 1;
+        if (zin >= 0 && zin < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
+          v = *(const f32x4*)(a.in + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.in_cs + 4 * q);
+      }
+      stage[i] = v;
+    }
+  };
+  auto stage_store = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+      int idx = tid + i * 256;
+      if (idx < NQ * PS) lds[(size_t)slot * NQ * PS + idx] = stage[i];
+    }
+  };
+
+  float s1[STATS ? COUT : 1], s2[STATS ? COUT : 1];
+#pragma unroll
+  for (int c = 0; c < (STATS ? COUT : 1); ++c) s1[c] = s2[c] = 0.f;
+
+  // prologue: planes z0-1, z0, z0+1
+  for (int p = -1; p <= 1; ++p) {
+    stage_load(z0 + p);
+    stage_store((z0 + p) & 3);
+  }
+  __syncthreads();
+
+  const int lane_slot = ty * PX + tx;  // top-left of the lane's 3x3 window in a plane
+  for (int z = z0; z < z1; ++z) {
+    stage_load(z + 2);
+    f32x4 acc[CQ];
+#pragma unroll
+    for (int cq = 0; cq < CQ; ++cq) acc[cq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    static_for<3>([&](auto TZ) {
+      constexpr int tz = decltype(TZ)::value;
+      const f32x4* plane = lds + (size_t)((z - 1 + tz) & 3) * NQ * PS + lane_slot;
+      static_for<NTY * 3>([&](auto TYX) {
+        constexpr int tyy = decltype(TYX)::value / 3, txx = decltype(TYX)::value % 3;
+        constexpr int t = (tz * NTY + tyy) * 3 + txx;
+        static_for<NQ>([&](auto Q) {
+          constexpr int q = decltype(Q)::value;
+          f32x4 xv = plane[q * PS + tyy * PX + txx];
+          static_for<4>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            constexpr int k = t * CIN + 4 * q + j;
+            static_for<CQ>([&](auto C) {
+              constexpr int cq = decltype(C)::value;
+              acc[cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[cq][k / 16], xv[j], acc[cq], 4, k % 16, 0);
+            });
+          });
+        });
+      });
+    });
+    if (vox_ok) {
+      float* op = a.out + ((((size_t)n * a.Z + z) * a.Y + gy) * a.X + gx) * a.out_cs;
+#pragma unroll
+      for (int cq = 0; cq < CQ; ++cq) {
+        f32x4 v = acc[cq];
+        if (a.accumulate) v += *(f32x4*)(op + 4 * cq);
+        *(f32x4*)(op + 4 * cq) = v;
+        if constexpr (STATS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            s1[4 * cq + j] += acc[cq][j];
+            s2[4 * cq + j] += acc[cq][j] * acc[cq][j];
+          }
+        }
+      }
+    }
+    stage_store((z + 2) & 3);
+    __syncthreads();
+  }
+
+  if constexpr (STATS) if (a.stats_partial) {  // workgroup partial sums (double) -> finalised by bn_stats_final_kernel
+    __shared__ float red[4][2 * COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+      float u = s1[c], v = s2[c];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        u += __shfl_xor(u, o);
+        v += __shfl_xor(v, o);
+      }
+      if (lane == 0) {
+        red[tid >> 6][c] = u;
+        red[tid >> 6][COUT + c] = v;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * COUT) {
+      double t = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
+      a.stats_partial[(size_t)blockIdx.x * 2 * COUT + tid] = t;
+    }
+  }
+}
+
+
+struct TPlan {
+  int mode, cin, cout;  // kernel-view channels (swapped for the data gradient)
+  bool flip;
+  int Z, Y, X, zseg, nzseg, nty, ntx;
+  size_t lds;
+  int grid;
+};
+
+template <int CIN, int COUT, int MODE, bool FLIP>
+static int launch_t(const TPlan& p, const TConvArgs& a, hipStream_t s) {
+  auto kern = tconv_kernel<CIN, COUT, MODE, FLIP>;
+  static size_t attr_lds = 48 * 1024;  // dynamic LDS above the default limit must be opted into per kernel
+  if (p.lds > attr_lds) {
+    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    attr_lds = p.lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds, s, a);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+#define URSN_TC(ci, co)                                  \
+  if (p.cin == ci && p.cout == co) {                     \
+    ursn_note_kernel(flip ? "tconv_dgrad<" #ci "," #co ">" : "tconv<" #ci "," #co ">"); \
+    return flip ? launch_t<ci, co, MODE, true>(p, a, s) : launch_t<ci, co, MODE, false>(p, a, s); \
+  }
+
+int tconv_dispatch_3d(const TPlan& p, const TConvArgs& a, hipStream_t s);
+int tconv_dispatch_2d(const TPlan& p, const TConvArgs& a, hipStream_t s);

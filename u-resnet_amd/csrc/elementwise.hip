@@ -112,20 +112,50 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   block_reduce_store<2, VEC>(acc, CP, C, partial + (size_t)blockIdx.x * 2 * C);
 }
 
-__global__ void bn_stats_final_kernel(const double* __restrict__ partial, int nblocks, int C, int64_t V, float eps,
-                                      float* __restrict__ mean, float* __restrict__ rstd) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
-    s += partial[(size_t)b * 2 * C + c];
-    q += partial[(size_t)b * 2 * C + C + c];
+// One block per channel: 256 threads stride over the per-block partials, tree-reduce in LDS (double).
+template <int NS>
+__device__ inline void reduce_partials(const double* __restrict__ partial, int nblocks, int C, int c, double (&out)[NS]) {
+  __shared__ double sm[NS][256];
+  double acc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] += partial[((size_t)b * NS + k) * C + c];
   }
-  double mu = s / (double)V;
-  double var = q / (double)V - mu * mu;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sm[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (threadIdx.x < st) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) sm[k][threadIdx.x] += sm[k][threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) out[k] = sm[k][0];
+}
+
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ partial, int nblocks, int C,
+                                                             int64_t V, float eps, float* __restrict__ mean,
+                                                             float* __restrict__ rstd) {
+  const int c = blockIdx.x;
+  double s[2];
+  reduce_partials<2>(partial, nblocks, C, c, s);
+  if (threadIdx.x != 0) return;
+  double mu = s[0] / (double)V;
+  double var = s[1] / (double)V - mu * mu;
   if (var < 0.0) var = 0.0;
   mean[c] = (float)mu;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+int launch_bn_stats_final(const double* partial, int nblocks, int C, int64_t V, float eps, float* mean, float* rstd,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, partial, nblocks, C, V, eps, mean, rstd);
+  URSN_HIP(hipGetLastError());
+  return 0;
 }
 
 int launch_bn_stats(const float* z, int zcs, int64_t V, int C, float eps, float* mean, float* rstd, void* scratch,
@@ -137,8 +167,8 @@ int launch_bn_stats(const float* z, int zcs, int64_t V, int C, float eps, float*
   if (v4) hipLaunchKernelGGL(bn_stats_partial_kernel<4>, dim3(m.grid), dim3(256), 0, s, z, zcs, V, C, m.shift, partial);
   else hipLaunchKernelGGL(bn_stats_partial_kernel<1>, dim3(m.grid), dim3(256), 0, s, z, zcs, V, C, m.shift, partial);
   URSN_HIP(hipGetLastError());
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, (const double*)partial, m.grid, C, V,
-                     eps, mean, rstd);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, (const double*)partial, m.grid, C, V, eps, mean,
+                     rstd);
   URSN_HIP(hipGetLastError());
   return 0;
 }
@@ -234,23 +264,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int shi
 }
 
 // finals: [3][C] doubles = mean(g), mean(g*xhat), mean(g*xhat2); dbeta(+2) += sum g
-__global__ void bn_bwd_final_kernel(const double* __restrict__ partial, int nblocks, int C, int64_t V,
-                                    double* __restrict__ finals, float* __restrict__ dbeta,
-                                    float* __restrict__ dbeta2) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0, s1 = 0, s2 = 0;
-  for (int b = 0; b < nblocks; ++b) {
-    const double* p = partial + (size_t)b * 3 * C;
-    s0 += p[c];
-    s1 += p[C + c];
-    s2 += p[2 * C + c];
-  }
-  finals[c] = s0 / (double)V;
-  finals[C + c] = s1 / (double)V;
-  finals[2 * C + c] = s2 / (double)V;
-  if (dbeta) dbeta[c] += (float)s0;
-  if (dbeta2) dbeta2[c] += (float)s0;
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ partial, int nblocks, int C,
+                                                           int64_t V, double* __restrict__ finals,
+                                                           float* __restrict__ dbeta, float* __restrict__ dbeta2) {
+  const int c = blockIdx.x;
+  double s[3];
+  reduce_partials<3>(partial, nblocks, C, c, s);
+  if (threadIdx.x != 0) return;
+  finals[c] = s[0] / (double)V;
+  finals[C + c] = s[1] / (double)V;
+  finals[2 * C + c] = s[2] / (double)V;
+  if (dbeta) dbeta[c] += (float)s[0];
+  if (dbeta2) dbeta2[c] += (float)s[0];
 }
 
 template <int VEC>
@@ -307,8 +332,8 @@ int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
   if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(m.grid), dim3(256), 0, s, a, m.shift, partial);
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(m.grid), dim3(256), 0, s, a, m.shift, partial);
   URSN_HIP(hipGetLastError());
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((a.C + 63) / 64), dim3(64), 0, s, (const double*)partial, m.grid, a.C,
-                     a.V, finals, a.dbeta, a.z2 ? a.dbeta2 : nullptr);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(a.C), dim3(256), 0, s, (const double*)partial, m.grid, a.C, a.V, finals,
+                     a.dbeta, a.z2 ? a.dbeta2 : nullptr);
   URSN_HIP(hipGetLastError());
   if (v4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(m.grid), dim3(256), 0, s, a, m.shift, (const double*)finals);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(m.grid), dim3(256), 0, s, a, m.shift, (const double*)finals);

@@ -98,6 +98,14 @@ int reduce_nblocks(int64_t voxels, int channels);
 // sum z, sum z^2 over voxels -> mean[C], rstd[C] (fp32), two kernels.
 int launch_bn_stats(const float* z, int zcs, int64_t V, int C, float eps, float* mean, float* rstd,
                     void* scratch, hipStream_t s);
+// finalise [nblocks][2][C] double partials (as written by the conv epilogue) into mean/rstd
+int launch_bn_stats_final(const double* partial, int nblocks, int C, int64_t V, float eps, float* mean, float* rstd,
+                          hipStream_t s);
+// tiled small-channel conv (conv_tiled.hip): forward with fused BN-statistics partials
+int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass);
+int tiled_conv_stats_blocks(const ursn_conv_desc& d);
+int launch_tiled_conv_stats(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
+                            int accumulate, double* stats_partial, hipStream_t s);
 // y = act(bn(z) [+ bn(z2) | + res]); any of z2/res may be null.
 struct BnActArgs {
   const float* z; int zcs; const float* mean; const float* rstd; const float* beta;
