@@ -69,12 +69,12 @@ def param_specs(ndim, cin, base, num_class, num_strides=5):
     return specs
 
 
-def init_params(ndim, cin, base, num_class, seed=1234, dtype=np.float64, beta_scale=0.0):
+def init_params(ndim, cin, base, num_class, seed=1234, dtype=np.float64, beta_scale=0.0, num_strides=5):
     """Xavier-uniform weights, beta = 0 (or small random if
     beta_scale > 0, useful to exercise the beta path in parity tests)."""
     rng = np.random.default_rng(seed)
     P = OrderedDict()
-    for l in layer_table(ndim, cin, base, num_class):
+    for l in layer_table(ndim, cin, base, num_class, num_strides):
         k = l["k"]
         fan = k ** ndim
         lim = math.sqrt(6.0 / (fan * (l["cin"] + l["cout"])))
@@ -347,13 +347,13 @@ def reshape_inputs(dims, data, label=None, weight=None):
     return d, l, w
 
 
-def step_gradients(P, dims, base, data, label, weight=None, eps=BN_EPS, keep_acts=False):
+def step_gradients(P, dims, base, data, label, weight=None, eps=BN_EPS, keep_acts=False, num_strides=5):
     """One `accum_gradients` fetch-set (lib/ssnet.py:103-115): returns
     (grads, dict(loss, acc_all, acc_nonzero, softmax, pred, logits[, acts]))."""
     dt = next(iter(P.values())).dtype
     d, l, w = reshape_inputs(dims, data, label, weight)
     d = d.astype(dt)
-    logits, tape = forward(P, d, base, eps=eps, keep_acts=keep_acts)
+    logits, tape = forward(P, d, base, num_strides=num_strides, eps=eps, keep_acts=keep_acts)
     m = loss_and_metrics(logits, d, l, w)
     grads, _ = backward(P, tape, m["dlogits"])
     m["logits"] = logits

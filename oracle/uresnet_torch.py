@@ -129,14 +129,14 @@ def metrics(logits, data, label):
     return acc_all, acc_nz
 
 
-def step_gradients(P, dims, base, data, label, weight=None, eps=BN_EPS, acts=None):
+def step_gradients(P, dims, base, data, label, weight=None, eps=BN_EPS, acts=None, num_strides=5):
     """One accum_gradients-equivalent.  P values must be leaf tensors with requires_grad."""
     dt = next(iter(P.values())).dtype
     dims = tuple(int(d) for d in dims)
     d = torch.as_tensor(data).reshape((-1,) + dims).to(dt)
     l = torch.as_tensor(label).reshape((-1,) + dims[:-1])
     w = None if weight is None else torch.as_tensor(weight).reshape((-1,) + dims[:-1]).to(dt)
-    logits = forward(P, d, base, eps=eps, acts=acts)
+    logits = forward(P, d, base, num_strides=num_strides, eps=eps, acts=acts)
     loss = loss_fn(logits, l, w)
     grads = torch.autograd.grad(loss, list(P.values()))
     acc_all, acc_nz = metrics(logits.detach(), d, l)

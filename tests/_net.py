@@ -17,8 +17,9 @@ def make_inputs(dims, ncls, N, seed, sparse=True):
     return data.astype(np.float32), label, weight.astype(np.float32)
 
 
-def oracle_params(dims, base, ncls, seed=11, beta_scale=0.2, dtype=np.float64):
-    return O.init_params(len(dims) - 1, dims[-1], base, ncls, seed=seed, dtype=dtype, beta_scale=beta_scale)
+def oracle_params(dims, base, ncls, seed=11, beta_scale=0.2, dtype=np.float64, num_strides=5):
+    return O.init_params(len(dims) - 1, dims[-1], base, ncls, seed=seed, dtype=dtype, beta_scale=beta_scale,
+                         num_strides=num_strides)
 
 
 def max_rel(a, b):
@@ -27,14 +28,14 @@ def max_rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-def fp32_noise_floor(P64, dims, base, data, label, weight):
+def fp32_noise_floor(P64, dims, base, data, label, weight, num_strides=5):
     """Per-tensor deviation of an INDEPENDENT fp32 evaluation (the numpy oracle run end-to-end in
     float32, different summation order from the GPU) from the fp64 oracle.  Gradients of this
     58-layer batch-stat-BN network are ill-conditioned on the tiny test shapes (8..16 samples per
     BN at the bottleneck), so a fixed tolerance is either vacuous or flaky; parity tests require
     the GPU error to stay within a small multiple of this floor instead."""
     P32 = {k: v.astype(np.float32) for k, v in P64.items()}
-    g32, m32 = O.step_gradients(P32, dims, base, data, label, weight)
+    g32, m32 = O.step_gradients(P32, dims, base, data, label, weight, num_strides=num_strides)
     return g32, m32
 
 
@@ -42,3 +43,9 @@ def as_f32_exact(P):
     """Round parameters to fp32-representable values so the fp64 oracle and the fp32 device see
     bit-identical inputs."""
     return type(P)((k, v.astype(np.float32).astype(np.float64)) for k, v in P.items())
+
+
+def l2_rel(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))

@@ -8,35 +8,39 @@ import pytest
 import torch
 
 from oracle import uresnet_np as O
-from _net import as_f32_exact, fp32_noise_floor, make_inputs, max_rel, oracle_params
+from _net import as_f32_exact, fp32_noise_floor, l2_rel, make_inputs, max_rel, oracle_params
 from uresnet_amd import uresnet
 
 pytestmark = pytest.mark.gpu
 
 CASES = [
-    # dims, base filters, classes, batch, use_weight
-    ((64, 64, 1), 4, 3, 2, False),     # train2d.cfg shape class (USE_WEIGHTS False), reduced
-    ((32, 64, 64, 1), 4, 3, 2, True),  # train3d.cfg shape class, reduced (a 1^3 bottleneck makes BN over 2 samples chaotic)
-    ((64, 64, 64, 1), 4, 3, 1, True),
-    ((64, 96, 1), 8, 5, 3, True),      # 5 classes, non-square
+    # dims, base filters, classes, batch, use_weight, num_strides
+    ((64, 64, 1), 4, 3, 2, False, 5),       # train2d.cfg shape class (USE_WEIGHTS False), reduced
+    ((32, 64, 64, 1), 8, 3, 2, True, 3),    # 3-D, F=8: level 0 runs the tiled fwd/dgrad/wgrad kernels + concat views
+    ((64, 64, 64, 1), 4, 3, 1, True, 5),    # train3d.cfg shape class at full depth, reduced
+    ((64, 96, 1), 8, 5, 3, True, 5),        # 5 classes, non-square
+    ((32, 256, 1), 16, 3, 2, True, 2),      # 2-D wide rows: tiled 2-D kernels at level 0
 ]
+# Full-depth (5 strides) cases on these small inputs end in an 8..16-sample bottleneck where ONE ReLU-mask flip
+# moves weight gradients by 0.1-0.5 % (measured on the fp64 oracle with 1-ulp parameter perturbations), so
+# their gradient check is relative to the fp32 noise floor; the shallow cases are well conditioned.
 
 
-def build(dims, base, ncls, use_weight, trainable=True, lr=None):
-    net = uresnet(dims=list(dims), num_class=ncls, base_num_outputs=base)
+def build(dims, base, ncls, use_weight, trainable=True, lr=None, num_strides=5):
+    net = uresnet(dims=list(dims), num_class=ncls, base_num_outputs=base, num_strides=num_strides)
     net.construct(trainable=trainable, use_weight=use_weight, learning_rate=lr)
     return net
 
 
 @pytest.mark.parametrize("case", CASES)
 def test_accum_gradients_parity(case):
-    dims, base, ncls, N, use_w = case
-    P = as_f32_exact(oracle_params(dims, base, ncls))
+    dims, base, ncls, N, use_w, ns = case
+    P = as_f32_exact(oracle_params(dims, base, ncls, num_strides=ns))
     data, label, weight = make_inputs(dims, ncls, N, seed=3)
-    g_ref, m = O.step_gradients(P, dims, base, data, label, weight if use_w else None, keep_acts=True)
-    g_np32, _ = fp32_noise_floor(P, dims, base, data, label, weight if use_w else None)
+    g_ref, m = O.step_gradients(P, dims, base, data, label, weight if use_w else None, keep_acts=True, num_strides=ns)
+    g_np32, _ = fp32_noise_floor(P, dims, base, data, label, weight if use_w else None, num_strides=ns)
 
-    net = build(dims, base, ncls, use_w)
+    net = build(dims, base, ncls, use_w, num_strides=ns)
     net.set_variables(P)
     net.zero_gradients(None)
     res, doc = net.accum_gradients(None, data, label, weight if use_w else None)
@@ -45,8 +49,8 @@ def test_accum_gradients_parity(case):
     # forward tensors
     z0 = net.debug_tensor("UResNet/conv0:z")
     assert max_rel(z0, m["acts"]["UResNet/conv0:z"]) < 1e-5
-    for name in ["UResNet/conv0", "UResNet/resnet_module0/module1", "UResNet/resnet_module4/module2",
-                 "UResNet/deconv0", "UResNet/resnet_module9/module2", "UResNet/conv1"]:
+    for name in ["UResNet/conv0", "UResNet/resnet_module0/module1", "UResNet/resnet_module%d/module2" % (ns - 1),
+                 "UResNet/deconv0", "UResNet/resnet_module%d/module2" % (ns + 4), "UResNet/conv1"]:
         assert max_rel(net.debug_tensor(name), m["acts"][name]) < 1e-3, name
     # labels: exact where the oracle margin is not a near-tie
     zl = net.debug_tensor("UResNet/conv2:z")
@@ -62,13 +66,15 @@ def test_accum_gradients_parity(case):
     assert abs(res[2] - m["acc_all"]) <= (n_unsafe + 0.5) / safe.size
     # gradients
     g = net.get_gradients()
-    # gradients: within 2e-3 of each tensor's max, or -- where fp32 itself cannot do better on this tiny,
-    # ill-conditioned shape -- within 4x the deviation of an independent fp32 evaluation; never worse than 5e-2
+    # gradients, relative L2 per tensor: within 2e-3, or -- on these tiny shapes, where a single ReLU-mask flip
+    # at the 8-sample bottleneck moves a weight gradient by percents in ANY fp32 evaluation -- within 4x the
+    # deviation of an independent fp32 evaluation of the oracle (numpy float32); never worse than 5e-2.
+    # (Kernel-level backward parity is pinned tightly in test_ops_gpu.py.)
     bad = []
     for k in g_ref:
         if np.abs(g_ref[k]).max() <= 1e-12:
             continue
-        e, floor = max_rel(g[k], g_ref[k]), max_rel(g_np32[k], g_ref[k])
+        e, floor = l2_rel(g[k], g_ref[k]), l2_rel(g_np32[k], g_ref[k])
         if e > min(max(2e-3, 4 * floor), 5e-2):
             bad.append((k, e, floor))
     assert not bad, bad

@@ -251,7 +251,7 @@ def test_tiled_conv_fwd_dgrad(case):
     w = _rand(rng, (3,) * ndim + (ci, co)) * 0.2
     y = O.conv_fwd(x, w, 1)
     dy = _rand(rng, y.shape)
-    dx, _ = O.conv_bwd(x, w, 1, dy)
+    dx, dw = O.conv_bwd(x, w, 1, dy)
     d = desc(ndim, N, S, ci, co, 3, 1, algo=3)
     xg, wg, dyg = dev(x), dev(w), dev(dy)
     assert rel_err(conv_forward(d, xg, wg, y.shape).cpu().numpy(), y) < TOL
@@ -259,6 +259,11 @@ def test_tiled_conv_fwd_dgrad(case):
     base = torch.ones(x.shape, dtype=torch.float32, device="cuda")
     dxa = conv_backward_data(d, dyg, wg, x.shape, accumulate=1, dx_init=base)
     assert rel_err(dxa.cpu().numpy(), dx + 1.0) < TOL
+    if not (ndim == 2 and ci == 32):   # 2-D 32->16 weight gradient exceeds the LDS budget of the tiled kernel
+        dwg = conv_backward_weight(d, xg, dyg, w.shape)
+        assert rel_err(dwg.cpu().numpy(), dw) < 5e-5
+        dwa = conv_backward_weight(d, xg, dyg, w.shape, dw_init=dwg)
+        assert rel_err(dwa.cpu().numpy(), 2 * dw) < 5e-5
 
 
 @pytest.mark.parametrize("case", [(3, 2, (16, 16, 16), 8, 8), (3, 1, (19, 13, 45), 16, 8), (3, 2, (8, 12, 16), 8, 16),

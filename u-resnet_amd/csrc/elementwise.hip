@@ -485,17 +485,31 @@ int launch_fill(float* p, float value, int64_t n, hipStream_t s) {
   return 0;
 }
 
-__global__ void reduce_accum_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n, int nchunks) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += src[(int64_t)c * n + i];
-    dst[i] += s;
+// dst[i] += sum_c src[c*n + i]; a block owns 64 elements, its 4 waves split the chunks (coalesced 256-B rows),
+// chunk order inside a wave and the 4-way combine are fixed -> bitwise reproducible.
+__global__ __launch_bounds__(256) void reduce_accum_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                           int64_t n, int nchunks) {
+  __shared__ float sm[4][64];
+  const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int c = cg;
+    for (; c + 12 < nchunks; c += 16) {
+      s0 += src[(int64_t)c * n + i];
+      s1 += src[(int64_t)(c + 4) * n + i];
+      s2 += src[(int64_t)(c + 8) * n + i];
+      s3 += src[(int64_t)(c + 12) * n + i];
+    }
+    for (; c < nchunks; c += 4) s0 += src[(int64_t)c * n + i];
   }
+  sm[cg][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (cg == 0 && i < n) dst[i] += (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
 }
 int launch_reduce_accum(float* dst, const float* src, int64_t n, int nchunks, hipStream_t s) {
   if (n == 0) return 0;
-  int blocks = (int)(cdiv64(n, 256) < 2048 ? cdiv64(n, 256) : 2048);
-  hipLaunchKernelGGL(reduce_accum_kernel, dim3(blocks), dim3(256), 0, s, dst, src, n, nchunks);
+  hipLaunchKernelGGL(reduce_accum_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, dst, src, n, nchunks);
   URSN_HIP(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,229 @@
+// LDS-tiled weight gradient for the full-resolution small-channel k3 s1 layers -- gfx950.
+//
+//   dW[t][ci][co] = sum_{n,v} x[n, v + t - 1][ci] * dz[n, v][co]
+//
+// v_mfma_f32_16x16x4_f32 with M = (tap, ci) rows, N = co columns, K = 4 consecutive voxels:
+//   A (16 rows x 4 vox): lane l -> row (l&15), voxel (l>>4): x[v0 + (l>>4) + tap(row)][ci(row)]
+//   B (4 vox x 16 cols): lane l -> voxel (l>>4), col (l&15):  dz[v0 + (l>>4)][co]
+//   D (16 x 16)        : lane l, reg r -> row 4*(l>>4)+r, col l&15
+// One wave keeps the accumulators of ALL taps (27*Cin/16 tiles, or two taps per tile when Cin = 8), so
+// every x plane and dz plane is read from HBM exactly once.  A workgroup owns a TYxTX tile and marches
+// along the slowest axis with a ring of 4 x planes (halo included) + a double-buffered dz plane in LDS,
+// voxel-major ([slot][channel], a straight copy of the NDHWC rows).  Each wave takes a quarter of the
+// tile's voxels; per-wave partial slabs go to scratch and are summed (and ADDED into the gradient buffer,
+// the assign_add of lib/ssnet.py:77) by a deterministic second kernel.
+#pragma once
+#include <utility>
+
+#include "ursn_common.h"
+
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+
+struct TWgradArgs {
+  const float* x;
+  const float* dz;
+  float* slab;  // [grid*4][taps][cin][cout]
+  int N, Z, Y, X;
+  int x_cs, dz_cs;
+  int zseg, nzseg, nty, ntx;
+};
+
+template <int MODE> struct WTile;
+template <> struct WTile<3> { static constexpr int TX = 32, TY = 8, NTY = 3, NT = 27; };
+template <> struct WTile<2> { static constexpr int TX = 256, TY = 1, NTY = 1, NT = 9; };
+
+template <int... Is, class F>
+__device__ __forceinline__ void wg_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void wg_static_for(F&& f) {
+  wg_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+template <int CIN, int COUT, int MODE>
+__global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
+  using TL = WTile<MODE>;
+  constexpr int TX = TL::TX, TY = TL::TY, NTY = TL::NTY, NT = TL::NT;
+  constexpr int PX = TX + 2, PY = TY + (NTY == 3 ? 2 : 0), PS = PX * PY;
+  constexpr int MT = CIN >= 16 ? CIN / 16 : 1;                 // row tiles per tap
+  constexpr int NA = CIN >= 16 ? NT * MT : (NT + 1) / 2;       // A operands (= row tiles) per voxel group
+  constexpr int CT = (COUT + 15) / 16;                         // col tiles
+  constexpr int XQ = CIN / 4, DQ = COUT / 4;                   // float4 per voxel
+  constexpr int NSX = (XQ * PS + 255) / 256;                   // staging float4 per thread (x plane)
+  constexpr int NSD = (DQ * TX * TY + 255) / 256;              // staging float4 per thread (dz plane)
+  constexpr int XPLANE = PS * CIN, DPLANE = TX * TY * COUT;    // floats
+  constexpr int GPR = TX / 4 / (MODE == 3 ? 1 : 4);            // voxel groups per tile row handled by one wave
+  extern __shared__ __attribute__((aligned(16))) float wlds[];  // [4][XPLANE] then [2][DPLANE]
+  float* xr = wlds;
+  float* dr = wlds + 4 * XPLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 15, kl = lane >> 4;
+  int bid = blockIdx.x;
+  const int xt = bid % a.ntx; bid /= a.ntx;
+  const int yt = bid % a.nty; bid /= a.nty;
+  const int zs = bid % a.nzseg;
+  const int n = bid / a.nzseg;
+  const int x0 = xt * TX, y0 = yt * TY;
+  const int z0 = zs * a.zseg;
+  const int z1 = (z0 + a.zseg < a.Z) ? z0 + a.zseg : a.Z;
+
+  // per-lane operand geometry
+  int a_off[NA], a_tz[NA];  // float offset inside an x plane (tap shift + channel), plane selector
+#pragma unroll
+  for (int m = 0; m < NA; ++m) {
+    int tap, ci;
+    if (CIN >= 16) { tap = m / MT; ci = (m % MT) * 16 + il; }
+    else { tap = 2 * m + (il >> 3); ci = il & 7; }
+    bool ok = tap < NT;
+    if (!ok) tap = 0;
+    int tz = tap / (NTY * 3), tyy = (tap / 3) % NTY, txx = tap % 3;
+    a_tz[m] = ok ? tz : -1;
+    a_off[m] = (tyy * PX + txx) * CIN + ci;
+  }
+  // this wave's first voxel: 3-D: rows 2*wave, 2*wave+1 of the tile; 2-D: x in [64*wave, 64*wave+64)
+  const int wrow = (MODE == 3) ? 2 * wave : 0;
+  const int wcol = (MODE == 3) ? 0 : 64 * wave;
+  const int a_lane = ((wrow * PX) + wcol + kl) * CIN;
+  const int b_lane = ((wrow * TX) + wcol + kl) * COUT + il;
+
+  wg_f32x4 acc[NA][CT];
+#pragma unroll
+  for (int m = 0; m < NA; ++m)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[m][c] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  wg_f32x4 sx[NSX], sd[NSD];
+  auto load_x = [&](int zin) {
+#pragma unroll
+    for (int i = 0; i < NSX; ++i) {
+      int idx = tid + i * 256;
+      wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < XQ * PS) {
+        int s = idx / XQ, q = idx - s * XQ;
+        int yy = s / PX, xx = s - yy * PX;
+        int py = y0 + yy - (NTY == 3 ? 1 : 0), px = x0 + xx - 1;
+        if (zin >= 0 && zin < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
+          v = *(const wg_f32x4*)(a.x + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.x_cs + 4 * q);
+      }
+      sx[i] = v;
+    }
+  };
+  auto store_x = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < NSX; ++i) {
+      int idx = tid + i * 256;
+      if (idx < XQ * PS) *(wg_f32x4*)(xr + (size_t)slot * XPLANE + idx * 4) = sx[i];
+    }
+  };
+  auto load_d = [&](int zin) {
+#pragma unroll
+    for (int i = 0; i < NSD; ++i) {
+      int idx = tid + i * 256;
+      wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < DQ * TX * TY) {
+        int s = idx / DQ, q = idx - s * DQ;
+        int yy = s / TX, xx = s - yy * TX;
+        int py = y0 + yy, px = x0 + xx;
+        if (zin < z1 && py < a.Y && px < a.X)
+          v = *(const wg_f32x4*)(a.dz + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.dz_cs + 4 * q);
+      }
+      sd[i] = v;
+    }
+  };
+  auto store_d = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < NSD; ++i) {
+      int idx = tid + i * 256;
+      if (idx < DQ * TX * TY) *(wg_f32x4*)(dr + (size_t)slot * DPLANE + idx * 4) = sd[i];
+    }
+  };
+
+  for (int p = -1; p <= 1; ++p) {
+    load_x(z0 + p);
+    store_x((z0 + p) & 3);
+  }
+  load_d(z0);
+  store_d(z0 & 1);
+  __syncthreads();
+
+  for (int z = z0; z < z1; ++z) {
+    load_x(z + 2);
+    load_d(z + 1);
+    int abase[NA];
+#pragma unroll
+    for (int m = 0; m < NA; ++m) {
+      int tz = a_tz[m] < 0 ? 0 : a_tz[m];
+      abase[m] = ((z - 1 + tz) & 3) * XPLANE + a_lane + a_off[m];
+    }
+    const float* dcur = dr + (size_t)(z & 1) * DPLANE + b_lane;
+    wg_static_for<16>([&](auto G) {
+      constexpr int g = decltype(G)::value;
+      constexpr int grow = (MODE == 3) ? g / 8 : 0;
+      constexpr int gcol = (MODE == 3) ? (g % 8) * 4 : g * 4;
+      float b[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        float v = dcur[(grow * TX + gcol) * COUT + c * 16];
+        b[c] = (c * 16 + il < COUT) ? v : 0.f;
+      }
+#pragma unroll
+      for (int m = 0; m < NA; ++m) {
+        float av = xr[abase[m] + (grow * PX + gcol) * CIN];
+        if (a_tz[m] < 0) av = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[c], acc[m][c], 0, 0, 0);
+      }
+    });
+    store_x((z + 2) & 3);
+    store_d((z + 1) & 1);
+    __syncthreads();
+  }
+
+  // per-wave partial slab
+  float* slab = a.slab + ((size_t)blockIdx.x * 4 + wave) * (size_t)(NT * CIN * COUT);
+#pragma unroll
+  for (int m = 0; m < NA; ++m)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      int col = c * 16 + il;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = 4 * kl + r;
+        int tap, ci;
+        if (CIN >= 16) { tap = m / MT; ci = (m % MT) * 16 + row; }
+        else { tap = 2 * m + (row >> 3); ci = row & 7; }
+        if (tap < NT && col < COUT) slab[((size_t)tap * CIN + ci) * COUT + col] = acc[m][c][r];
+      }
+    }
+}
+
+struct TWPlan {
+  int mode, cin, cout;
+  int Z, Y, X, zseg, nzseg, nty, ntx;
+  size_t lds;
+  int grid;
+};
+
+template <int CIN, int COUT, int MODE>
+static int launch_tw(const TWPlan& p, const TWgradArgs& a, hipStream_t s) {
+  auto kern = twgrad_kernel<CIN, COUT, MODE>;
+  static size_t attr_lds = 48 * 1024;
+  if (p.lds > attr_lds) {
+    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    attr_lds = p.lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds, s, a);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+#define URSN_TW(ci, co)                              \
+  if (p.cin == ci && p.cout == co) {                 \
+    ursn_note_kernel("twgrad<" #ci "," #co ">");     \
+    return launch_tw<ci, co, MODE>(p, a, s);         \
+  }
+
+int twgrad_dispatch_3d(const TWPlan& p, const TWgradArgs& a, hipStream_t s);
+int twgrad_dispatch_2d(const TWPlan& p, const TWgradArgs& a, hipStream_t s);
