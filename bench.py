@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="per-kernel time table on stderr")
+    ap.add_argument("--layers", action="store_true", help="per-(layer, pass) time table on stderr")
     ap.add_argument("--cpu-baseline-child", type=int, default=0)
     ap.add_argument("--cpu-reps", type=int, default=2)
     args = ap.parse_args()
@@ -170,9 +171,12 @@ def main():
     _lib.check(lib.ursn_profile_read(net._handle, recs, nrec, ctypes.byref(cnt)))
     _lib.check(lib.ursn_profile_enable(net._handle, 0))
     by_kernel, t_roof_ms, conv_flops, conv_bytes, all_ms = {}, 0.0, 0.0, 0.0, 0.0
+    by_layer = {}
     for i in range(cnt.value):
         r = recs[i]
         k = r.kernel.decode()
+        le = by_layer.setdefault((r.layer.decode(), r.pass_, k), [0.0, r.flops, r.bytes])
+        le[0] += r.ms
         e = by_kernel.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, conv=r.pass_ <= 2))
         e["ms"] += r.ms; e["flops"] += r.flops; e["bytes"] += r.bytes; e["launches"] += 1
         all_ms += r.ms
@@ -203,6 +207,12 @@ def main():
                 k, v["ms"] / args.steps, v["launches"] // args.steps, tf, gb))
         sys.stderr.write("sum of timed launches %.2f ms/step, wall %.2f ms/step\n" % (all_ms / args.steps, ms_per_step))
 
+    if rank == 0 and args.layers:
+        pn = ["fwd", "dgrad", "wgrad", "bn_stats", "bn_act", "bn_bwd", "head"]
+        for (lname, ps, k), (ms, fl, by) in sorted(by_layer.items(), key=lambda kv: -kv[1][0])[:60]:
+            ms /= args.steps
+            sys.stderr.write("%-52s %-8s %-20s %8.3f ms %8.2f TFLOP/s %8.1f GB/s\n" % (
+                lname, pn[ps], k, ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0, by / (ms * 1e-3) / 1e9 if ms > 0 else 0))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and len(dims) == 4:
         cpu = run_cpu_baseline(int(dims[0]))

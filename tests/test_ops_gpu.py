@@ -290,3 +290,24 @@ def test_conv_forward_fused_statistics(case):
     assert rel_err(yg.cpu().numpy(), y) < TOL
     assert np.abs(mg.cpu().numpy() - mu).max() < 2e-6 * np.sqrt(var.max())  + 1e-6 * np.abs(mu).max()
     assert rel_err(rg.cpu().numpy(), 1 / np.sqrt(var + 1e-3)) < 1e-5
+
+
+@pytest.mark.parametrize("ndim,S,ci,co", [(3, (16, 16, 32), 8, 3), (2, (16, 256), 16, 3), (2, (16, 256), 16, 5)])
+def test_tiled_conv_padded_classes(ndim, S, ci, co):
+    """conv2 (F -> num_class): the logits buffers are padded to 4|8 channels so the tiled kernels apply."""
+    rng = np.random.default_rng(co)
+    N, pc = 2, (co + 3) // 4 * 4
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (3,) * ndim + (ci, co)) * 0.2
+    y = O.conv_fwd(x, w, 1)
+    dy = _rand(rng, y.shape)
+    dx, dw = O.conv_bwd(x, w, 1, dy)
+    d = desc(ndim, N, S, ci, co, 3, 1, out_cs=pc, algo=3)
+    xg, wg = dev(x), dev(w)
+    yg = conv_forward(d, xg, wg, y.shape[:-1] + (pc,)).cpu().numpy()
+    assert rel_err(yg[..., :co], y) < TOL and np.all(yg[..., co:] == 0)
+    dyp = np.zeros(y.shape[:-1] + (pc,))
+    dyp[..., :co] = dy
+    dyg = dev(dyp)
+    assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
+    assert rel_err(conv_backward_weight(d, xg, dyg, w.shape).cpu().numpy(), dw) < 5e-5

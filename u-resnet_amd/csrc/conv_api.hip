@@ -253,9 +253,10 @@ extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, 
   const int ocs = d->out_cstride > 0 ? d->out_cstride : d->cout;
   if ((d->algo == 0 || d->algo == 3) && tiled_conv_supported(*d, PASS_FWD)) {
     int nb = tiled_conv_stats_blocks(*d);
-    URSN_REQUIRE((size_t)nb * 2 * d->cout * sizeof(double) <= scratch_bytes, "conv_forward_stats: scratch too small");
+    const int pc = (d->cout + 3) & ~3;
+    URSN_REQUIRE((size_t)nb * 2 * pc * sizeof(double) <= scratch_bytes, "conv_forward_stats: scratch too small");
     URSN_TRY(launch_tiled_conv_stats(*d, PASS_FWD, x, w, y, 0, (double*)scratch, s));
-    return launch_bn_stats_final((const double*)scratch, nb, d->cout, V, eps, mean, rstd, s);
+    return launch_bn_stats_final((const double*)scratch, nb, d->cout, pc, V, eps, mean, rstd, s);
   }
   URSN_REQUIRE(reduce_scratch_bytes(V, d->cout, 2) <= scratch_bytes, "conv_forward_stats: scratch too small");
   URSN_TRY(conv_dispatch(*d, PASS_FWD, x, w, y, 0, s));
@@ -356,7 +357,7 @@ extern "C" int ursn_softmax_ce(const float* logits, const float* data, const flo
   hipStream_t s = (hipStream_t)stream;
   HeadArgs a;
   memset(&a, 0, sizeof(a));
-  a.z = logits; a.data = data; a.data_cs = 1; a.label = label; a.weight = weight;
+  a.z = logits; a.z_cs = ncls; a.data = data; a.data_cs = 1; a.label = label; a.weight = weight;
   a.n = n; a.pix = pix; a.ncls = ncls; a.softmax_out = softmax_out; a.dlogits = dlogits;
   a.scratch = scratch;
   a.metrics = (float*)((char*)scratch + ((head_scratch_bytes(n, pix) + 15) & ~(size_t)15));

@@ -8,13 +8,11 @@
 // host side
 // ---------------------------------------------------------------------------------------------------------
 static bool tiled_shape_ok(int cin, int cout, int mode) {
-  // register budget: weights (27|9)*cin*cout/64 VGPRs must leave room for two waves per SIMD
-  int taps = mode == 3 ? 27 : 9;
   if (cin % 4 || cout % 4 || cin < 4 || cout < 4) return false;
   // instantiated shapes (weights + accumulators must fit 256 VGPRs for two waves per SIMD)
-  if (mode == 3) return (cin == 8 || cin == 16) && (cout == 8 || cout == 16);
   if ((cin == 8 || cin == 16) && (cout == 8 || cout == 16)) return true;
-  return (cin == 32 && cout == 16) || (cin == 16 && cout == 32);
+  if (mode == 3) return (cin == 8 && cout == 4) || (cin == 4 && cout == 8);     // conv2 (8 -> 3 classes) and its dgrad
+  return (cin == 32 && cout == 16) || (cin == 16 && cout == 32) || (cin == 16 && cout == 4) || (cin == 4 && cout == 16);
 }
 
 static bool tiled_disabled() {  // URSN_DISABLE_TILED=1: route everything through the generic kernels (A/B debugging)
@@ -29,8 +27,8 @@ static bool make_plan(const ursn_conv_desc& d, ConvPass pass, TPlan& p) {
   if (pass != PASS_FWD && pass != PASS_DGRAD) return false;
   p.mode = d.ndim;
   p.flip = (pass == PASS_DGRAD);
-  p.cin = p.flip ? d.cout : d.cin;
-  p.cout = p.flip ? d.cin : d.cout;
+  p.cin = ((p.flip ? d.cout : d.cin) + 3) & ~3;   // kernel view: channel counts padded to 4 (buffers are padded too)
+  p.cout = ((p.flip ? d.cin : d.cout) + 3) & ~3;
   if (!tiled_shape_ok(p.cin, p.cout, p.mode)) return false;
   const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
   if ((ics & 3) || (ocs & 3)) return false;
@@ -91,9 +89,11 @@ int launch_tiled_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, c
 static bool make_wplan(const ursn_conv_desc& d, TWPlan& p) {
   if (tiled_disabled() && d.algo != 3) return false;
   if (d.transposed || d.k != 3 || d.stride != 1) return false;
-  p.mode = d.ndim; p.cin = d.cin; p.cout = d.cout;
-  bool c816 = (d.cin == 8 || d.cin == 16) && (d.cout == 8 || d.cout == 16);
-  if (!(c816 || (d.ndim == 2 && d.cin == 16 && d.cout == 32))) return false;
+  p.mode = d.ndim; p.cin = d.cin; p.cout = (d.cout + 3) & ~3;
+  bool c816 = (d.cin == 8 || d.cin == 16) && (p.cout == 8 || p.cout == 16);
+  bool extra = d.ndim == 3 ? (d.cin == 8 && p.cout == 4)
+                           : ((d.cin == 16 && p.cout == 32) || (d.cin == 16 && p.cout == 4));
+  if (!(c816 || extra)) return false;
   const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
   if ((ics & 3) || (ocs & 3)) return false;
   if (d.ndim == 3) { p.Z = d.in_sp[0]; p.Y = d.in_sp[1]; p.X = d.in_sp[2]; }
@@ -108,7 +108,7 @@ static bool make_wplan(const ursn_conv_desc& d, TWPlan& p) {
   p.zseg = (p.Z + nz - 1) / nz;
   p.nzseg = (p.Z + p.zseg - 1) / p.zseg;
   const int PX = TX + 2, PY = TY + (p.mode == 3 ? 2 : 0);
-  p.lds = ((size_t)4 * PX * PY * d.cin + (size_t)2 * TX * TY * d.cout) * sizeof(float) + 256;
+  p.lds = ((size_t)4 * PX * PY * d.cin + (size_t)2 * TX * TY * p.cout) * sizeof(float) + 256;
   if (p.lds > 160 * 1024) return false;
   p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
   return true;
@@ -138,6 +138,7 @@ int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy,
   a.x_cs = d.in_cstride > 0 ? d.in_cstride : d.cin;
   a.dz_cs = d.out_cstride > 0 ? d.out_cstride : d.cout;
   a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
+  a.cout_w = d.cout;
   URSN_TRY(p.mode == 3 ? twgrad_dispatch_3d(p, a, s) : twgrad_dispatch_2d(p, a, s));
   int taps = d.ndim == 3 ? 27 : 9;
   return launch_reduce_accum(dw, (const float*)scratch, (int64_t)taps * d.cin * d.cout, p.grid * 4, s);

@@ -90,9 +90,9 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
         int t = k / CIN, kk = k - t * CIN;
         int co = 4 * cq + cl;
         float v = 0.f;
-        if (k < KTOT) {
-          if (!FLIP) v = a.w[((size_t)t * a.cin_w + kk) * a.cout_w + co];        // W[t][ci=kk][co]
-          else v = a.w[((size_t)(NT - 1 - t) * a.cin_w + co) * a.cout_w + kk];   // W[T-1-t][ci=co][co=kk]
+        if (k < KTOT) {  // channel counts padded to 4 in registers: rows/cols beyond the stored tensor are 0
+          if (!FLIP) { if (kk < a.cin_w && co < a.cout_w) v = a.w[((size_t)t * a.cin_w + kk) * a.cout_w + co]; }
+          else if (co < a.cin_w && kk < a.cout_w) v = a.w[((size_t)(NT - 1 - t) * a.cin_w + co) * a.cout_w + kk];
         }
         wreg[cq][r] = v;
       }
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
         if constexpr (STATS) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            s1[4 * cq + j] += acc[cq][j];
-            s2[4 * cq + j] += acc[cq][j] * acc[cq][j];
+            s1[4 * cq + j] += v[j];
+            s2[4 * cq + j] += v[j] * v[j];
           }
         }
       }

@@ -121,7 +121,7 @@ __device__ inline void reduce_partials(const double* __restrict__ partial, int n
   for (int k = 0; k < NS; ++k) acc[k] = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 256) {
 #pragma unroll
-    for (int k = 0; k < NS; ++k) acc[k] += partial[((size_t)b * NS + k) * C + c];
+    for (int k = 0; k < NS; ++k) acc[k] += partial[((size_t)b * NS + k) * C + c];  // C = channel stride of the partials
   }
 #pragma unroll
   for (int k = 0; k < NS; ++k) sm[k][threadIdx.x] = acc[k];
@@ -137,12 +137,12 @@ __device__ inline void reduce_partials(const double* __restrict__ partial, int n
   for (int k = 0; k < NS; ++k) out[k] = sm[k][0];
 }
 
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ partial, int nblocks, int C,
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ partial, int nblocks, int PC,
                                                              int64_t V, float eps, float* __restrict__ mean,
                                                              float* __restrict__ rstd) {
   const int c = blockIdx.x;
   double s[2];
-  reduce_partials<2>(partial, nblocks, C, c, s);
+  reduce_partials<2>(partial, nblocks, PC, c, s);
   if (threadIdx.x != 0) return;
   double mu = s[0] / (double)V;
   double var = s[1] / (double)V - mu * mu;
@@ -151,9 +151,9 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __res
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-int launch_bn_stats_final(const double* partial, int nblocks, int C, int64_t V, float eps, float* mean, float* rstd,
-                          hipStream_t s) {
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, partial, nblocks, C, V, eps, mean, rstd);
+int launch_bn_stats_final(const double* partial, int nblocks, int C, int PC, int64_t V, float eps, float* mean,
+                          float* rstd, hipStream_t s) {
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, partial, nblocks, PC, V, eps, mean, rstd);
   URSN_HIP(hipGetLastError());
   return 0;
 }
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a, double* __restric
 #pragma unroll
     for (int k = 0; k < URSN_MAX_CLASS; ++k) {
       if (k < a.ncls) {
-        z[k] = fmaf(a.z[p * a.ncls + k], sc[k], sh[k]);
+        z[k] = fmaf(a.z[p * a.z_cs + k], sc[k], sh[k]);
         if (z[k] > m) { m = z[k]; arg = k; }  // strict '>' keeps the lowest index on ties
       }
     }

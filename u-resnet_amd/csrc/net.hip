@@ -46,6 +46,7 @@ struct Layer {
   int64_t w_off = 0, b_off = 0, w_n = 0;
   ursn_conv_desc desc;
   float *z = nullptr, *dz = nullptr, *mean = nullptr, *rstd = nullptr;
+  int zcs = 0;  // channel stride of z / dz: cout rounded up to 4 (only conv2's 3|5 classes differ), pad lanes stay 0
 };
 
 struct Unit {
@@ -130,7 +131,9 @@ int add_layer(ursn_net* n, Arena& A, const std::string& name, int kind, int k, i
   L.desc.n = n->cfg.max_batch;
   for (int j = 0; j < n->cfg.ndim; ++j) L.desc.in_sp[j] = n->ldim[lin][3 - n->cfg.ndim + j];
   L.desc.cin = ci; L.desc.cout = co; L.desc.k = k; L.desc.stride = s; L.desc.transposed = kind;
-  int64_t e = (int64_t)n->cfg.max_batch * n->lvox[lout] * co;
+  L.zcs = (co + 3) & ~3;
+  L.desc.out_cstride = L.zcs;
+  int64_t e = (int64_t)n->cfg.max_batch * n->lvox[lout] * L.zcs;
   L.z = A.floats(e);
   L.dz = n->cfg.trainable ? A.floats(e) : nullptr;
   L.mean = A.floats(co);
@@ -240,7 +243,7 @@ int plan(ursn_net* n, Arena& A) {
   for (const Layer& L : n->layers) {
     size_t r = reduce_scratch_bytes((int64_t)c.max_batch * n->lvox[L.lout], L.cout, 3);
     if (r > red) red = r;
-    size_t rt = (size_t)tiled_conv_stats_blocks(L.desc) * 2 * L.cout * sizeof(double);
+    size_t rt = (size_t)tiled_conv_stats_blocks(L.desc) * 2 * L.zcs * sizeof(double);
     if (rt > red) red = rt;
     if (tr) {
       size_t w = ursn_conv_wgrad_scratch_bytes(&L.desc);
@@ -300,7 +303,7 @@ int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s) {
   ursn_conv_desc d = L.desc;
   d.n = N;
   d.in_cstride = in.cs;
-  d.out_cstride = L.cout;
+  d.out_cstride = L.zcs;
   if (tiled_conv_supported(d, PASS_FWD)) {  // conv + BN-statistics partials in one pass
     int nb = tiled_conv_stats_blocks(d);
     {
@@ -309,7 +312,7 @@ int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s) {
       ps.done(ursn_last_kernel_name());
     }
     ProfScope ps(n, s, li, 3, 0.0, 0.0);
-    URSN_TRY(launch_bn_stats_final((const double*)n->red_scratch, nb, L.cout, (int64_t)N * n->lvox[L.lout],
+    URSN_TRY(launch_bn_stats_final((const double*)n->red_scratch, nb, L.cout, L.zcs, (int64_t)N * n->lvox[L.lout],
                                    n->cfg.bn_eps, L.mean, L.rstd, s));
     ps.done("bn_stats_final");
     return 0;
@@ -321,7 +324,7 @@ int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s) {
   }
   {
     ProfScope ps(n, s, li, 3, 0.0, 4.0 * N * n->lvox[L.lout] * L.cout);
-    URSN_TRY(launch_bn_stats(L.z, L.cout, (int64_t)N * n->lvox[L.lout], L.cout, n->cfg.bn_eps, L.mean, L.rstd,
+    URSN_TRY(launch_bn_stats(L.z, L.zcs, (int64_t)N * n->lvox[L.lout], L.cout, n->cfg.bn_eps, L.mean, L.rstd,
                              n->red_scratch, s));
     ps.done("bn_stats");
   }
@@ -332,7 +335,7 @@ int bn_out(ursn_net* n, int li, const Act& out, int relu, int N, int li2, const 
   Layer& L = n->layers[li];
   BnActArgs a;
   memset(&a, 0, sizeof(a));
-  a.z = L.z; a.zcs = L.cout; a.mean = L.mean; a.rstd = L.rstd; a.beta = n->params + L.b_off;
+  a.z = L.z; a.zcs = L.zcs; a.mean = L.mean; a.rstd = L.rstd; a.beta = n->params + L.b_off;
   if (li2 >= 0) {
     Layer& L2 = n->layers[li2];
     a.z2 = L2.z; a.z2cs = L2.cout; a.mean2 = L2.mean; a.rstd2 = L2.rstd; a.beta2 = n->params + L2.b_off;
@@ -383,7 +386,7 @@ int head(ursn_net* n, const float* data, const float* label, const float* weight
   Layer& L = n->layers[n->conv2];
   HeadArgs a;
   memset(&a, 0, sizeof(a));
-  a.z = L.z; a.mean = L.mean; a.rstd = L.rstd; a.beta = n->params + L.b_off;
+  a.z = L.z; a.z_cs = L.zcs; a.mean = L.mean; a.rstd = L.rstd; a.beta = n->params + L.b_off;
   a.data = (n->cfg.cin == 1) ? data : nullptr;  // acc_nonzero needs one input channel (lib/ssnet.py:59)
   a.data_cs = n->cfg.cin;
   a.label = label; a.weight = weight; a.n = N; a.pix = n->lvox[0]; a.ncls = n->cfg.num_class;
@@ -407,7 +410,7 @@ int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStre
   ursn_conv_desc d = L.desc;
   d.n = N;
   d.in_cstride = in.cs;
-  d.out_cstride = L.cout;
+  d.out_cstride = L.zcs;
   if (need_dgrad) {
     bool acc = take_flag(n, in);
     ProfScope ps(n, s, li, 1, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
@@ -426,7 +429,7 @@ int bn_back(ursn_net* n, int li, const float* dy, int dycs, const float* y, int 
   BnBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.dy = dy; a.dycs = dycs; a.y = y; a.ycs = ycs;
-  a.z = L.z; a.zcs = L.cout; a.mean = L.mean; a.rstd = L.rstd; a.dz = L.dz; a.dzcs = L.cout;
+  a.z = L.z; a.zcs = L.zcs; a.mean = L.mean; a.rstd = L.rstd; a.dz = L.dz; a.dzcs = L.zcs;
   a.dbeta = n->grads + L.b_off;
   if (li2 >= 0) {
     Layer& L2 = n->layers[li2];
@@ -532,6 +535,15 @@ extern "C" int ursn_create(const ursn_config* cfg, float* params, float* grads, 
   }
   if (rc) { delete n; return rc; }
   n->params = params; n->grads = grads; n->adam_m = adam_m; n->adam_v = adam_v;
+  for (const Layer& L : n->layers) {  // pad channels of z/dz are never written afterwards: keep them 0 (not NaN)
+    if (L.zcs == L.cout) continue;
+    size_t bytes = (size_t)n->cfg.max_batch * n->lvox[L.lout] * L.zcs * sizeof(float);
+    if (hipMemset(L.z, 0, bytes) != hipSuccess || (L.dz && hipMemset(L.dz, 0, bytes) != hipSuccess)) {
+      ursn_set_error("create: hipMemset of padded logits buffers failed");
+      delete n;
+      return 1;
+    }
+  }
   *out = n;
   return 0;
 }
@@ -654,7 +666,7 @@ extern "C" int ursn_tensor(const ursn_net* net, const char* name, float** ptr, i
     *ptr = want_z ? L.z : L.dz;
     *voxels = net->lvox[L.lout];
     *channels = L.cout;
-    *cstride = L.cout;
+    *cstride = L.zcs;
     return 0;
   }
   auto it = net->named.find(s);

@@ -99,8 +99,8 @@ int reduce_nblocks(int64_t voxels, int channels);
 int launch_bn_stats(const float* z, int zcs, int64_t V, int C, float eps, float* mean, float* rstd,
                     void* scratch, hipStream_t s);
 // finalise [nblocks][2][C] double partials (as written by the conv epilogue) into mean/rstd
-int launch_bn_stats_final(const double* partial, int nblocks, int C, int64_t V, float eps, float* mean, float* rstd,
-                          hipStream_t s);
+int launch_bn_stats_final(const double* partial, int nblocks, int C, int PC, int64_t V, float eps, float* mean,
+                          float* rstd, hipStream_t s);  // PC = channel stride of the partials (C padded to 4)
 // tiled small-channel conv (conv_tiled.hip): forward with fused BN-statistics partials
 int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass);
 int tiled_conv_stats_blocks(const ursn_conv_desc& d);
@@ -132,7 +132,7 @@ int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
 
 // Head: logits = bn(z) (mean/rstd/beta may be null => z are logits already).
 struct HeadArgs {
-  const float* z; const float* mean; const float* rstd; const float* beta;
+  const float* z; int z_cs; const float* mean; const float* rstd; const float* beta;
   const float* data; int data_cs; const float* label; const float* weight;
   int n; int64_t pix; int ncls;
   float* softmax_out; float* dlogits;  // nullable

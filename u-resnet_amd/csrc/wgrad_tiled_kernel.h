@@ -26,6 +26,7 @@ struct TWgradArgs {
   int N, Z, Y, X;
   int x_cs, dz_cs;
   int zseg, nzseg, nty, ntx;
+  int cout_w;  // stored output channels (<= COUT, which is padded to 4)
 };
 
 template <int MODE> struct WTile;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         float v = dcur[(grow * TX + gcol) * COUT + c * 16];
-        b[c] = (c * 16 + il < COUT) ? v : 0.f;
+        b[c] = (c * 16 + il < a.cout_w) ? v : 0.f;
       }
 #pragma unroll
       for (int m = 0; m < NA; ++m) {
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
   }
 
   // per-wave partial slab
-  float* slab = a.slab + ((size_t)blockIdx.x * 4 + wave) * (size_t)(NT * CIN * COUT);
+  float* slab = a.slab + ((size_t)blockIdx.x * 4 + wave) * (size_t)(NT * CIN * a.cout_w);
 #pragma unroll
   for (int m = 0; m < NA; ++m)
 #pragma unroll
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
         int tap, ci;
         if (CIN >= 16) { tap = m / MT; ci = (m % MT) * 16 + row; }
         else { tap = 2 * m + (row >> 3); ci = row & 7; }
-        if (tap < NT && col < COUT) slab[((size_t)tap * CIN + ci) * COUT + col] = acc[m][c][r];
+        if (tap < NT && col < a.cout_w) slab[((size_t)tap * CIN + ci) * a.cout_w + col] = acc[m][c][r];
       }
     }
 }
