@@ -311,3 +311,36 @@ def test_tiled_conv_padded_classes(ndim, S, ci, co):
     dyg = dev(dyp)
     assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
     assert rel_err(conv_backward_weight(d, xg, dyg, w.shape).cpu().numpy(), dw) < 5e-5
+
+
+@pytest.mark.parametrize("case", [(3, 2, (24, 48, 48), 32, 16), (3, 2, (24, 24, 48), 32, 32), (3, 1, (48, 48, 48), 64, 32),
+                                  (3, 1, (48, 48, 32), 16, 48)])
+def test_tiled_conv_channel_blocks(case):
+    """Layers wider than the instantiated kernels run as 16x16 channel blocks (accumulating launches)."""
+    ndim, N, S, ci, co = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (3,) * ndim + (ci, co)) * 0.1
+    y = O.conv_fwd(x, w, 1)
+    dy = _rand(rng, y.shape)
+    dx, dw = O.conv_bwd(x, w, 1, dy)
+    d = desc(ndim, N, S, ci, co, 3, 1, algo=3)
+    xg, wg, dyg = dev(x), dev(w), dev(dy)
+    lib = _lib.load()
+    yg = torch.empty(y.shape, dtype=torch.float32, device="cuda")
+    mg, rg = torch.empty(co, device="cuda"), torch.empty(co, device="cuda")
+    nb = 1 << 24
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.ursn_conv_forward_stats(ctypes.byref(d), P(xg), P(wg), P(yg), P(mg), P(rg), 1e-3, P(scratch), nb,
+                                           stream()))
+    torch.cuda.synchronize()
+    assert rel_err(yg.cpu().numpy(), y) < TOL
+    ax = tuple(range(y.ndim - 1))
+    assert rel_err(mg.cpu().numpy(), y.mean(axis=ax)) < 1e-4
+    assert rel_err(rg.cpu().numpy(), 1 / np.sqrt(y.var(axis=ax) + 1e-3)) < 1e-5
+    assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
+    base = torch.ones(x.shape, dtype=torch.float32, device="cuda")
+    assert rel_err(conv_backward_data(d, dyg, wg, x.shape, accumulate=1, dx_init=base).cpu().numpy(), dx + 1.0) < TOL
+    dwg = conv_backward_weight(d, xg, dyg, w.shape)
+    assert rel_err(dwg.cpu().numpy(), dw) < 5e-5
+    assert rel_err(conv_backward_weight(d, xg, dyg, w.shape, dw_init=dwg).cpu().numpy(), 2 * dw) < 5e-5

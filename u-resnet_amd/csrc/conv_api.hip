@@ -252,11 +252,9 @@ extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, 
   if (d->transposed) { V = (int64_t)d->n; for (int j = 0; j < d->ndim; ++j) V *= 2 * d->in_sp[j]; }
   const int ocs = d->out_cstride > 0 ? d->out_cstride : d->cout;
   if ((d->algo == 0 || d->algo == 3) && tiled_conv_supported(*d, PASS_FWD)) {
-    int nb = tiled_conv_stats_blocks(*d);
-    const int pc = (d->cout + 3) & ~3;
-    URSN_REQUIRE((size_t)nb * 2 * pc * sizeof(double) <= scratch_bytes, "conv_forward_stats: scratch too small");
-    URSN_TRY(launch_tiled_conv_stats(*d, PASS_FWD, x, w, y, 0, (double*)scratch, s));
-    return launch_bn_stats_final((const double*)scratch, nb, d->cout, pc, V, eps, mean, rstd, s);
+    URSN_REQUIRE(tiled_conv_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
+                 "conv_forward_stats: scratch too small");
+    return launch_tiled_conv_bn(*d, x, w, y, (double*)scratch, eps, mean, rstd, s);
   }
   URSN_REQUIRE(reduce_scratch_bytes(V, d->cout, 2) <= scratch_bytes, "conv_forward_stats: scratch too small");
   URSN_TRY(conv_dispatch(*d, PASS_FWD, x, w, y, 0, s));

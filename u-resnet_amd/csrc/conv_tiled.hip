@@ -1,12 +1,16 @@
-// Host side of the LDS-tiled small-channel convolution kernels (kernel: conv_tiled_kernel.h).
+// Host side of the LDS-tiled small-channel convolution kernels (kernels: conv_tiled_kernel.h,
+// wgrad_tiled_kernel.h).
+//
+// Shapes the kernels are instantiated for run as one launch.  Wider layers (kernel-view channel counts that
+// are multiples of 16, up to 64) run as a grid of 16x16 channel blocks: each launch reads a 16-channel slice
+// of the input (channel stride = the tensor's) and accumulates into a 16-channel slice of the output, so a
+// 32->16 conv is two launches, 32->32 four.  The extra read-modify-write of the output is cheap next to
+// falling back to the gather kernel (25-35 TFLOP/s vs ~90).
 #include <stdlib.h>
 
 #include "conv_tiled_kernel.h"
 #include "wgrad_tiled_kernel.h"
 
-// ---------------------------------------------------------------------------------------------------------
-// host side
-// ---------------------------------------------------------------------------------------------------------
 static bool tiled_shape_ok(int cin, int cout, int mode) {
   if (cin % 4 || cout % 4 || cin < 4 || cout < 4) return false;
   // instantiated shapes (weights + accumulators must fit 256 VGPRs for two waves per SIMD)
@@ -21,7 +25,28 @@ static bool tiled_disabled() {  // URSN_DISABLE_TILED=1: route everything throug
   return v == 1;
 }
 
-static bool make_plan(const ursn_conv_desc& d, ConvPass pass, TPlan& p) {
+struct Blocking {
+  int nbi = 1, nbo = 1;  // channel blocks of the contraction / produced dims (kernel view); block = 16 when > 1
+};
+
+static bool spatial_plan(const ursn_conv_desc& d, int& Z, int& Y, int& X, int& ntx, int& nty, int& zseg, int& nzseg,
+                         int target_blocks) {
+  if (d.ndim == 3) { Z = d.in_sp[0]; Y = d.in_sp[1]; X = d.in_sp[2]; }
+  else { Z = d.in_sp[0]; Y = 1; X = d.in_sp[1]; }
+  const int TX = d.ndim == 3 ? 32 : 256, TY = d.ndim == 3 ? 8 : 1;
+  if (X < TX / 2 || Y < TY || Z < 8) return false;  // only worth it when tiles are reasonably full
+  ntx = (X + TX - 1) / TX;
+  nty = (Y + TY - 1) / TY;
+  // enough workgroups to fill the chip, but long marches to amortise the prologue and the weight load
+  int64_t base = (int64_t)d.n * ntx * nty;
+  int nz = 1;
+  while (base * nz < target_blocks && Z / (nz * 2) >= 8) nz *= 2;
+  zseg = (Z + nz - 1) / nz;
+  nzseg = (Z + zseg - 1) / zseg;
+  return true;
+}
+
+static bool make_plan(const ursn_conv_desc& d, ConvPass pass, TPlan& p, Blocking& b) {
   if (tiled_disabled() && d.algo != 3) return false;
   if (d.transposed || d.k != 3 || d.stride != 1) return false;
   if (pass != PASS_FWD && pass != PASS_DGRAD) return false;
@@ -29,117 +54,154 @@ static bool make_plan(const ursn_conv_desc& d, ConvPass pass, TPlan& p) {
   p.flip = (pass == PASS_DGRAD);
   p.cin = ((p.flip ? d.cout : d.cin) + 3) & ~3;   // kernel view: channel counts padded to 4 (buffers are padded too)
   p.cout = ((p.flip ? d.cin : d.cout) + 3) & ~3;
-  if (!tiled_shape_ok(p.cin, p.cout, p.mode)) return false;
   const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
   if ((ics & 3) || (ocs & 3)) return false;
-  if (d.ndim == 3) { p.Z = d.in_sp[0]; p.Y = d.in_sp[1]; p.X = d.in_sp[2]; }
-  else { p.Z = d.in_sp[0]; p.Y = 1; p.X = d.in_sp[1]; }
+  if (!spatial_plan(d, p.Z, p.Y, p.X, p.ntx, p.nty, p.zseg, p.nzseg, 1024)) return false;
+  p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
+  b = Blocking();
+  if (!tiled_shape_ok(p.cin, p.cout, p.mode)) {
+    if ((p.cin % 16) || (p.cout % 16) || p.cin > 64 || p.cout > 64 || (p.grid < 192 && d.algo != 3)) return false;
+    b.nbi = p.cin / 16;
+    b.nbo = p.cout / 16;
+    p.cin = p.cout = 16;
+  }
   const int TX = p.mode == 3 ? 32 : 256, TY = p.mode == 3 ? 8 : 1;
-  // only worth it when tiles are reasonably full
-  if (p.X < TX / 2 || p.Y < TY || p.Z < 8) return false;
-  p.ntx = (p.X + TX - 1) / TX;
-  p.nty = (p.Y + TY - 1) / TY;
-  // enough workgroups to fill 256 CUs x 2, but long marches to amortise the prologue and weight load
-  int64_t base = (int64_t)d.n * p.ntx * p.nty;
-  int nz = 1;
-  while (base * nz < 1024 && p.Z / (nz * 2) >= 8) nz *= 2;
-  p.zseg = (p.Z + nz - 1) / nz;
-  p.nzseg = (p.Z + p.zseg - 1) / p.zseg;
   const int PX = TX + 2, PY = TY + (p.mode == 3 ? 2 : 0);
   p.lds = (size_t)4 * (p.cin / 4) * PX * PY * 16;
-  if (p.lds > 160 * 1024) return false;
-  p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
-  return true;
+  return p.lds <= 160 * 1024;
 }
 
 int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass) {
   TPlan p;
-  return make_plan(d, pass, p) ? 1 : 0;
+  Blocking b;
+  return make_plan(d, pass, p, b) ? 1 : 0;
 }
 
-int tiled_conv_stats_blocks(const ursn_conv_desc& d) {
+// doubles of scratch the fused-statistics forward needs
+size_t tiled_conv_stats_scratch_doubles(const ursn_conv_desc& d) {
   TPlan p;
-  return make_plan(d, PASS_FWD, p) ? p.grid : 0;
+  Blocking b;
+  if (!make_plan(d, PASS_FWD, p, b)) return 0;
+  return (size_t)p.grid * 2 * p.cout;
 }
 
-int launch_tiled_conv_stats(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
-                            int accumulate, double* stats_partial, hipStream_t s) {
-  TPlan p;
-  URSN_REQUIRE(make_plan(d, pass, p), "tiled conv: unsupported shape");
-  TConvArgs a;
-  a.in = in; a.w = w; a.out = out; a.stats_partial = stats_partial;
-  a.N = d.n; a.Z = p.Z; a.Y = p.Y; a.X = p.X;
+static int launch_blocks(const ursn_conv_desc& d, const TPlan& p, const Blocking& b, const float* in, const float* w,
+                         float* out, int accumulate, double* stats_partial, float eps, float* mean, float* rstd,
+                         hipStream_t s) {
   const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+  TConvArgs a;
+  a.N = d.n; a.Z = p.Z; a.Y = p.Y; a.X = p.X;
   a.in_cs = p.flip ? ocs : ics;
   a.out_cs = p.flip ? ics : ocs;
   a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
-  a.accumulate = accumulate;
   a.cin_w = d.cin; a.cout_w = d.cout;
-  return p.mode == 3 ? tconv_dispatch_3d(p, a, s) : tconv_dispatch_2d(p, a, s);
+  const int64_t V = (int64_t)d.n * p.Z * p.Y * p.X;
+  const int real_out = p.flip ? d.cin : d.cout;
+  for (int bo = 0; bo < b.nbo; ++bo)
+    for (int bi = 0; bi < b.nbi; ++bi) {
+      const bool last = (bi == b.nbi - 1);
+      a.in = in + 16 * bi;
+      a.out = out + 16 * bo;
+      // W[t][ci][co]: forward contracts ci (block bi) and produces co (block bo); the data gradient contracts co
+      // (block bi) and produces ci (block bo)
+      a.w = p.flip ? w + (size_t)16 * bo * d.cout + 16 * bi : w + (size_t)16 * bi * d.cout + 16 * bo;
+      a.accumulate = (accumulate || bi > 0) ? 1 : 0;
+      a.stats_partial = (stats_partial && last) ? stats_partial : nullptr;
+      URSN_TRY(p.mode == 3 ? tconv_dispatch_3d(p, a, s) : tconv_dispatch_2d(p, a, s));
+      if (stats_partial && last) {
+        int cb = (b.nbo > 1) ? 16 : real_out;  // real channels produced by this block
+        URSN_TRY(launch_bn_stats_final(stats_partial, p.grid, cb, p.cout, V, eps, mean + 16 * bo, rstd + 16 * bo, s));
+      }
+    }
+  if (b.nbi > 1 || b.nbo > 1) ursn_note_kernel(p.flip ? "tconv_dgrad<16,16>xB" : "tconv<16,16>xB");
+  return 0;
+}
+
+// forward conv + batch statistics (mean, rstd) of its output, statistics fused into the conv epilogue
+int launch_tiled_conv_bn(const ursn_conv_desc& d, const float* in, const float* w, float* out, double* scratch,
+                         float eps, float* mean, float* rstd, hipStream_t s) {
+  TPlan p;
+  Blocking b;
+  URSN_REQUIRE(make_plan(d, PASS_FWD, p, b), "tiled conv: unsupported shape");
+  return launch_blocks(d, p, b, in, w, out, 0, scratch, eps, mean, rstd, s);
 }
 
 int launch_tiled_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
                       int accumulate, hipStream_t s) {
-  return launch_tiled_conv_stats(d, pass, in, w, out, accumulate, nullptr, s);
+  TPlan p;
+  Blocking b;
+  URSN_REQUIRE(make_plan(d, pass, p, b), "tiled conv: unsupported shape");
+  return launch_blocks(d, p, b, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------------------
-static bool make_wplan(const ursn_conv_desc& d, TWPlan& p) {
+static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
   if (tiled_disabled() && d.algo != 3) return false;
   if (d.transposed || d.k != 3 || d.stride != 1) return false;
   p.mode = d.ndim; p.cin = d.cin; p.cout = (d.cout + 3) & ~3;
+  const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+  if ((ics & 3) || (ocs & 3)) return false;
+  if (!spatial_plan(d, p.Z, p.Y, p.X, p.ntx, p.nty, p.zseg, p.nzseg, 512)) return false;
+  p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
+  b = Blocking();
   bool c816 = (d.cin == 8 || d.cin == 16) && (p.cout == 8 || p.cout == 16);
   bool extra = d.ndim == 3 ? (d.cin == 8 && p.cout == 4)
                            : ((d.cin == 16 && p.cout == 32) || (d.cin == 16 && p.cout == 4));
-  if (!(c816 || extra)) return false;
-  const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
-  if ((ics & 3) || (ocs & 3)) return false;
-  if (d.ndim == 3) { p.Z = d.in_sp[0]; p.Y = d.in_sp[1]; p.X = d.in_sp[2]; }
-  else { p.Z = d.in_sp[0]; p.Y = 1; p.X = d.in_sp[1]; }
+  if (!(c816 || extra)) {
+    if ((d.cin % 16) || (d.cout % 16) || d.cin > 64 || d.cout > 64 || (p.grid < 96 && d.algo != 3)) return false;
+    b.nbi = d.cin / 16;
+    b.nbo = d.cout / 16;
+    p.cin = p.cout = 16;
+  }
   const int TX = p.mode == 3 ? 32 : 256, TY = p.mode == 3 ? 8 : 1;
-  if (p.X < TX / 2 || p.Y < TY || p.Z < 8) return false;
-  p.ntx = (p.X + TX - 1) / TX;
-  p.nty = (p.Y + TY - 1) / TY;
-  int64_t base = (int64_t)d.n * p.ntx * p.nty;
-  int nz = 1;
-  while (base * nz < 512 && p.Z / (nz * 2) >= 8) nz *= 2;
-  p.zseg = (p.Z + nz - 1) / nz;
-  p.nzseg = (p.Z + p.zseg - 1) / p.zseg;
   const int PX = TX + 2, PY = TY + (p.mode == 3 ? 2 : 0);
-  p.lds = ((size_t)4 * PX * PY * d.cin + (size_t)2 * TX * TY * p.cout) * sizeof(float) + 256;
-  if (p.lds > 160 * 1024) return false;
-  p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
-  return true;
+  p.lds = ((size_t)4 * PX * PY * p.cin + (size_t)2 * TX * TY * p.cout) * sizeof(float) + 256;
+  return p.lds <= 160 * 1024;
 }
 
 int tiled_wgrad_supported(const ursn_conv_desc& d) {
   TWPlan p;
-  return make_wplan(d, p) ? 1 : 0;
+  Blocking b;
+  return make_wplan(d, p, b) ? 1 : 0;
 }
 
 size_t tiled_wgrad_scratch_bytes(const ursn_conv_desc& d) {
   TWPlan p;
-  if (!make_wplan(d, p)) return 0;
+  Blocking b;
+  if (!make_wplan(d, p, b)) return 0;
   int taps = d.ndim == 3 ? 27 : 9;
-  return (size_t)p.grid * 4 * taps * d.cin * d.cout * sizeof(float);
+  int ci = (b.nbi > 1 || b.nbo > 1) ? 16 : d.cin, co = (b.nbi > 1 || b.nbo > 1) ? 16 : d.cout;
+  return (size_t)p.grid * 4 * taps * ci * co * sizeof(float);
 }
 
 int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
                        size_t scratch_bytes, hipStream_t s) {
   TWPlan p;
-  URSN_REQUIRE(make_wplan(d, p), "tiled wgrad: unsupported shape");
+  Blocking b;
+  URSN_REQUIRE(make_wplan(d, p, b), "tiled wgrad: unsupported shape");
   size_t need = tiled_wgrad_scratch_bytes(d);
   URSN_REQUIRE(scratch && scratch_bytes >= need, "tiled wgrad: scratch too small (%zu < %zu)", scratch_bytes, need);
+  const bool blocked = b.nbi > 1 || b.nbo > 1;
   TWgradArgs a;
-  a.x = x; a.dz = dy; a.slab = (float*)scratch;
+  a.slab = (float*)scratch;
   a.N = d.n; a.Z = p.Z; a.Y = p.Y; a.X = p.X;
   a.x_cs = d.in_cstride > 0 ? d.in_cstride : d.cin;
   a.dz_cs = d.out_cstride > 0 ? d.out_cstride : d.cout;
   a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
-  a.cout_w = d.cout;
-  URSN_TRY(p.mode == 3 ? twgrad_dispatch_3d(p, a, s) : twgrad_dispatch_2d(p, a, s));
-  int taps = d.ndim == 3 ? 27 : 9;
-  return launch_reduce_accum(dw, (const float*)scratch, (int64_t)taps * d.cin * d.cout, p.grid * 4, s);
+  a.cout_w = blocked ? 16 : d.cout;
+  const int taps = d.ndim == 3 ? 27 : 9;
+  for (int bi = 0; bi < b.nbi; ++bi)
+    for (int bo = 0; bo < b.nbo; ++bo) {
+      a.x = x + 16 * bi;
+      a.dz = dy + 16 * bo;
+      URSN_TRY(p.mode == 3 ? twgrad_dispatch_3d(p, a, s) : twgrad_dispatch_2d(p, a, s));
+      if (!blocked) return launch_reduce_accum(dw, (const float*)scratch, (int64_t)taps * d.cin * d.cout, p.grid * 4, s);
+      // slab [tap][16][16] -> dw[tap][16*bi + r][16*bo + c]
+      URSN_TRY(launch_reduce_accum_blocked(dw + (size_t)16 * bi * d.cout + 16 * bo, (const float*)scratch, taps, 16, 16,
+                                           (int64_t)d.cin * d.cout, d.cout, p.grid * 4, s));
+    }
+  ursn_note_kernel("twgrad<16,16>xB");
+  return 0;
 }

@@ -514,6 +514,42 @@ int launch_reduce_accum(float* dst, const float* src, int64_t n, int nchunks, hi
   return 0;
 }
 
+// dst[t*dst_tap_stride + r*dst_row_stride + c] += sum_k src[k*(taps*rows*cols) + (t*rows + r)*cols + c]
+__global__ __launch_bounds__(256) void reduce_accum_blocked_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                                   int taps, int rows, int cols, int64_t dst_tap_stride,
+                                                                   int dst_row_stride, int nchunks) {
+  __shared__ float sm[4][64];
+  const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int64_t n = (int64_t)taps * rows * cols;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < n) {
+    int c = cg;
+    for (; c + 4 < nchunks; c += 8) {
+      s0 += src[(int64_t)c * n + i];
+      s1 += src[(int64_t)(c + 4) * n + i];
+    }
+    for (; c < nchunks; c += 4) s0 += src[(int64_t)c * n + i];
+  }
+  sm[cg][e] = s0 + s1;
+  __syncthreads();
+  if (cg == 0 && i < n) {
+    int col = (int)(i % cols);
+    int64_t tr = i / cols;
+    int r = (int)(tr % rows);
+    int t = (int)(tr / rows);
+    dst[(int64_t)t * dst_tap_stride + (int64_t)r * dst_row_stride + col] += (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
+  }
+}
+int launch_reduce_accum_blocked(float* dst, const float* src, int taps, int rows, int cols, int64_t dst_tap_stride,
+                                int dst_row_stride, int nchunks, hipStream_t s) {
+  int64_t n = (int64_t)taps * rows * cols;
+  hipLaunchKernelGGL(reduce_accum_blocked_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, dst, src, taps, rows,
+                     cols, dst_tap_stride, dst_row_stride, nchunks);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // MFMA lane-layout probe (tests/test_mfma_probe.py decodes it)
 //   which 1: 4x4x1_16B, a = lane+1, b = 1          -> D = source A lane + 1

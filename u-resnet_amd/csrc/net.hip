@@ -243,7 +243,7 @@ int plan(ursn_net* n, Arena& A) {
   for (const Layer& L : n->layers) {
     size_t r = reduce_scratch_bytes((int64_t)c.max_batch * n->lvox[L.lout], L.cout, 3);
     if (r > red) red = r;
-    size_t rt = (size_t)tiled_conv_stats_blocks(L.desc) * 2 * L.zcs * sizeof(double);
+    size_t rt = tiled_conv_stats_scratch_doubles(L.desc) * sizeof(double);
     if (rt > red) red = rt;
     if (tr) {
       size_t w = ursn_conv_wgrad_scratch_bytes(&L.desc);
@@ -305,16 +305,10 @@ int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s) {
   d.in_cstride = in.cs;
   d.out_cstride = L.zcs;
   if (tiled_conv_supported(d, PASS_FWD)) {  // conv + BN-statistics partials in one pass
-    int nb = tiled_conv_stats_blocks(d);
-    {
-      ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
-      URSN_TRY(launch_tiled_conv_stats(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)n->red_scratch, s));
-      ps.done(ursn_last_kernel_name());
-    }
-    ProfScope ps(n, s, li, 3, 0.0, 0.0);
-    URSN_TRY(launch_bn_stats_final((const double*)n->red_scratch, nb, L.cout, L.zcs, (int64_t)N * n->lvox[L.lout],
-                                   n->cfg.bn_eps, L.mean, L.rstd, s));
-    ps.done("bn_stats_final");
+    ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
+    URSN_TRY(launch_tiled_conv_bn(d, in.p, n->params + L.w_off, L.z, (double*)n->red_scratch, n->cfg.bn_eps, L.mean,
+                                  L.rstd, s));
+    ps.done(ursn_last_kernel_name());
     return 0;
   }
   {

@@ -103,9 +103,11 @@ int launch_bn_stats_final(const double* partial, int nblocks, int C, int PC, int
                           float* rstd, hipStream_t s);  // PC = channel stride of the partials (C padded to 4)
 // tiled small-channel conv (conv_tiled.hip): forward with fused BN-statistics partials
 int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass);
-int tiled_conv_stats_blocks(const ursn_conv_desc& d);
-int launch_tiled_conv_stats(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
-                            int accumulate, double* stats_partial, hipStream_t s);
+size_t tiled_conv_stats_scratch_doubles(const ursn_conv_desc& d);
+int launch_tiled_conv_bn(const ursn_conv_desc& d, const float* in, const float* w, float* out, double* scratch,
+                         float eps, float* mean, float* rstd, hipStream_t s);
+int launch_reduce_accum_blocked(float* dst, const float* src, int taps, int rows, int cols, int64_t dst_tap_stride,
+                                int dst_row_stride, int nchunks, hipStream_t s);
 // y = act(bn(z) [+ bn(z2) | + res]); any of z2/res may be null.
 struct BnActArgs {
   const float* z; int zcs; const float* mean; const float* rstd; const float* beta;
