@@ -383,14 +383,15 @@ class Adam:
             P[k] -= lr_t * self.m[k] / (np.sqrt(self.v[k]) + self.eps)
 
 
-def train_step(P, opt, dims, base, minibatches, use_weight=True, eps=BN_EPS):
+def train_step(P, opt, dims, base, minibatches, use_weight=True, eps=BN_EPS, num_strides=5):
     """lib/ssnet_trainval.py:164-191: zero, accumulate (SUM) over minibatches, one Adam apply.
     `minibatches` = list of (data, label, weight) flat arrays (weights already normalised).
     Returns mean metrics over minibatches (:211) and the summed gradients."""
     acc = OrderedDict((k, np.zeros_like(v)) for k, v in P.items())
     mets = []
     for data, label, weight in minibatches:
-        g, m = step_gradients(P, dims, base, data, label, weight if use_weight else None, eps)
+        g, m = step_gradients(P, dims, base, data, label, weight if use_weight else None, eps,
+                              num_strides=num_strides)
         for k in acc:
             acc[k] += g[k]
         mets.append((m["loss"], m["acc_all"], m["acc_nonzero"]))

@@ -1,0 +1,180 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU, no compute calls)."""
+import ctypes
+import io
+import os
+import re
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+import uresnet_amd  # noqa: E402,F401
+from uresnet_amd import _lib, ssnet_base, ssnet_config, uresnet  # noqa: E402
+from uresnet_amd import synthetic_io as sio  # noqa: E402
+
+
+# ---- config (lib/config.py) --------------------------------------------------------------------------------
+def test_config_defaults_match_reference():
+    c = ssnet_config()
+    assert (c.NUM_CLASS, c.BASE_NUM_FILTERS, c.LEARNING_RATE, c.MINIBATCH_SIZE, c.NUM_MINIBATCHES) == (3, 16, -1, 10, 5)
+    assert (c.TF_RANDOM_SEED, c.TRAIN, c.USE_WEIGHTS, c.REPORT_STEPS, c.CHECKPOINT_NHOUR) == (1234, True, True, 200, 0.4)
+    assert c.KEYWORD_DATA == 'data' and c.AVOID_LOAD_PARAMS == []
+
+
+def test_config_override_and_errors(tmp_path):
+    p = tmp_path / "a.cfg"
+    p.write_text("NUM_CLASS 5  # comment\n  BASE_NUM_FILTERS\t8\nLEARNING_RATE 0.0001\nSAVE_FILE 'x/y'\n"
+                 "AVOID_LOAD_PARAMS ['a', 'b']\nDUMP_IMAGE False\nthis line has three words\n\nTRAIN False\n")
+    c = ssnet_config()
+    with redirect_stdout(io.StringIO()) as out:
+        c.override(str(p))
+    assert (c.NUM_CLASS, c.BASE_NUM_FILTERS, c.LEARNING_RATE, c.SAVE_FILE, c.TRAIN) == (5, 8, 0.0001, 'x/y', False)
+    assert c.AVOID_LOAD_PARAMS == ['a', 'b']
+    assert 'Ignoring a parameter in file: DUMP_IMAGE' in out.getvalue()   # reference crashes here (lib/config.py:57-61)
+    assert ssnet_config().NUM_CLASS == 3                                    # instance override, class defaults intact
+    bad = tmp_path / "b.cfg"
+    bad.write_text("NUM_CLASS 'three'\n")
+    with redirect_stdout(io.StringIO()), pytest.raises(TypeError):
+        ssnet_config().override(str(bad))
+    with redirect_stdout(io.StringIO()), pytest.raises(IOError):
+        ssnet_config().override(str(tmp_path / "missing.cfg"))
+
+
+def test_shipped_configs_parse():
+    for name in ["train3d.cfg", "train2d.cfg", "ana3d.cfg"]:
+        c = ssnet_config()
+        with redirect_stdout(io.StringIO()):
+            c.override(os.path.join(ROOT, "config", name))
+            c.dump()
+    assert c.TRAIN is False and c.BASE_NUM_FILTERS == 8
+
+
+# ---- topology / debug prints (lib/uresnet.py:22-123) ------------------------------------------------------------
+def test_debug_print_sequence_3d():
+    net = uresnet(dims=[128, 128, 128, 1], num_class=3, debug=True)   # the reference's own smoke shape (:128-130)
+    with redirect_stdout(io.StringIO()) as out:
+        net.construct(trainable=True, use_weight=True, allocate=False)
+    lines = out.getvalue().strip().split("\n")
+    tags = [l.split(") ", 1)[1] for l in lines]
+    want = ['input shape', 'after conv0'] + ['after resnet_module%d' % i for i in range(5)]
+    for i in range(5):
+        want += ['after deconv%d' % i, 'after concat%d' % i, 'after resnet_module%d' % (i + 5)]
+    want += ['after conv1', 'after conv2']
+    assert tags == want
+    assert lines[1].startswith("(-1, 128, 128, 128, 16)") and lines[6].startswith("(-1, 4, 4, 4, 512)")
+    assert lines[-1].startswith("(-1, 128, 128, 128, 3)")
+
+
+def test_parameter_layout_and_counts():
+    for dims, F, ncls, want in [([192, 192, 192, 1], 8, 3, 12468083), ([256, 256, 1], 16, 3, 16858979),
+                                ([512, 512, 1], 16, 5, 16859269)]:
+        net = uresnet(dims=dims, num_class=ncls, base_num_outputs=F)
+        net.construct(allocate=False)
+        assert net._n_params == want and len(net._specs) == 116
+    names = net.variable_names()
+    assert names[:2] == ['UResNet/conv0/weights', 'UResNet/conv0/BatchNorm/beta']
+    assert names[-2:] == ['UResNet/conv2/weights', 'UResNet/conv2/BatchNorm/beta']
+    deconv = [s for s in net._specs if s[0] == 'UResNet/deconv0/weights'][0]
+    assert deconv[1] == (3, 3, 256, 512)          # [k,k,Cout,Cin]
+
+
+def test_reference_error_behaviour():
+    with redirect_stdout(io.StringIO()), pytest.raises(NotImplementedError):
+        ssnet_base(dims=[4, 4], num_class=3)                       # lib/ssnet.py:12-14
+    with pytest.raises(NotImplementedError):
+        ssnet_base(dims=[32, 32, 1], num_class=3).construct(allocate=False)   # abstract _build, lib/ssnet.py:17-18
+
+    class other(uresnet):
+        def _build(self, input_tensor):
+            from uresnet_amd.resnet_module import conv
+            return conv(input_tensor, self._num_class, 3, 1, 'only')
+    with pytest.raises(NotImplementedError):
+        other(dims=[32, 32, 1], num_class=3).construct(allocate=False)
+    net = uresnet(dims=[32, 32, 1], num_class=3)
+    net.construct(trainable=True, use_weight=True, allocate=False)
+    net._params = object()
+    with pytest.raises(TypeError):                                  # lib/ssnet.py:143-145
+        net.feed_dict(np.zeros((1, 1024), np.float32), np.zeros((1, 1024), np.float32), None)
+    assert net._opt._lr == 0.001                                     # AdamOptimizer() default when lr <= 0
+    net2 = uresnet(dims=[32, 32, 1], num_class=3)
+    net2.construct(trainable=True, use_weight=False, learning_rate=1e-4, allocate=False)
+    assert net2._opt._lr == 1e-4
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    net = uresnet(dims=[32, 32, 1], num_class=3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net.construct(trainable=True, use_weight=False)
+
+
+# ---- C-ABI ---------------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "uresnet_hip.h")).read()
+    declared = set(re.findall(r"\b(ursn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(_lib.EXPORTS) <= declared
+    assert lib.ursn_abi_version() == 1
+
+
+def test_query_sizes_and_errors():
+    lib = _lib.load()
+    net = uresnet(dims=[192, 192, 192, 1], num_class=3, base_num_outputs=8)
+    net.construct(allocate=False)
+    cfg = net._native_config(4)
+    s = _lib.ursn_sizes()
+    assert lib.ursn_query(ctypes.byref(cfg), ctypes.byref(s)) == 0
+    assert (s.n_params, s.n_layers, s.n_tensors) == (12468083, 58, 116)
+    assert 20e9 < s.workspace_bytes < 80e9
+    cfg.spatial[0] = 100                                # not divisible by 32: deconv/skip shapes would differ
+    assert lib.ursn_query(ctypes.byref(cfg), ctypes.byref(s)) != 0
+    assert b"divisible" in lib.ursn_last_error()
+    assert lib.ursn_conv_forward(None, None, None, None, None) != 0 and b"null" in lib.ursn_last_error()
+    d = _lib.ursn_conv_desc()
+    d.ndim, d.n, d.cin, d.cout, d.k, d.stride = 3, 4, 16, 16, 3, 1
+    d.in_sp[0] = d.in_sp[1] = d.in_sp[2] = 96
+    assert lib.ursn_conv_wgrad_scratch_bytes(ctypes.byref(d)) > 0
+
+
+# ---- synthetic IO (larcv_threadio protocol) ------------------------------------------------------------------------
+def test_synthetic_threadio_protocol():
+    io_ = sio.synthetic_threadio()
+    io_.configure({'filler_name': 'MainIO', 'verbosity': 0,
+                   'filler_cfg': {'Dims': [32, 32, 32, 1], 'NumClass': 3, 'Generator': 'lartpc_sparse'}})
+    io_.start_manager(2)
+    io_.next(store_entries=True, store_event_ids=True)
+    d = io_.fetch_data('data')
+    assert d.dim() == [2, 32, 32, 32, 1] and d.data().shape == (2, 32768) and d.data().dtype == np.float32
+    assert io_.fetch_data('label').dim() == [2, 32, 32, 32]
+    lab, w = io_.fetch_data('label').data(), io_.fetch_data('weight').data()
+    assert set(np.unique(lab)) <= {0.0, 1.0, 2.0} and (lab > 0).any()
+    assert np.all((d.data() > 0) == (lab > 0)) and d.data().max() <= 500 and d.data()[d.data() > 0].min() >= 1
+    assert io_.fetch_entries() == [0, 1]
+    io_.next()
+    assert io_.fetch_entries() == [2, 3]
+    again = sio.lartpc_sparse([32, 32, 32, 1], 3, 2)[0]
+    assert np.array_equal(again, io_.fetch_data('data').data()[0])       # entry k is reproducible anywhere
+    with pytest.raises(KeyError):
+        io_.fetch_data('nope')
+    io_.reset()
+
+
+def test_rank_sharding_of_entries():
+    seen = []
+    for rank in range(2):
+        io_ = sio.synthetic_threadio()
+        io_.configure({'filler_cfg': {'Dims': [16, 16, 1], 'NumClass': 3, 'Generator': 'dense_uniform',
+                                      'FirstEntry': rank, 'EntryStride': 2}})
+        io_.start_manager(3)
+        io_.next()
+        seen.append(io_.fetch_entries())
+        io_.reset()
+    assert seen == [[0, 2, 4], [1, 3, 5]]

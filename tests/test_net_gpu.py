@@ -139,3 +139,82 @@ def test_ana_mode_net_is_not_trainable():
     assert net.inference(None, data, label)[0].shape == (1, 64, 64, 3)
     with pytest.raises(RuntimeError):
         net.accum_gradients(None, data, label)
+
+
+@pytest.mark.parametrize("name", ["net2d_32x32_f4_ns3", "net3d_16x16x16_f4_ns2"])
+def test_hip_path_against_committed_golden(name):
+    """Same checks against the committed fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py)."""
+    import os
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")) as f:
+        G = {k: f[k] for k in f.files}
+    dims, base, ns = tuple(int(d) for d in G["dims"]), int(G["base"]), int(G["num_strides"])
+    use_w = bool(int(G["use_weight"]))
+    P = {k[6:]: G[k] for k in G if k.startswith("param:")}
+    net = build(dims, base, int(G["num_class"]), use_w, lr=1e-3, num_strides=ns)
+    net.set_variables(P)
+    w = G["weight"] if use_w else None
+    net.zero_gradients(None)
+    res, _ = net.accum_gradients(None, G["data"], G["label"], w)
+    assert abs(res[1] - float(G["loss"])) < 1e-4 * abs(float(G["loss"]))
+    assert abs(res[2] - float(G["acc_all"])) < 2e-3 and abs(res[3] - float(G["acc_nonzero"])) < 5e-3
+    sm = net.inference(None, G["data"])[0]
+    assert max_rel(sm, G["softmax"]) < 1e-3
+    srt = np.sort(G["logits"], axis=-1)
+    safe = (srt[..., -1] - srt[..., -2]) > 1e-3
+    assert np.array_equal(sm.argmax(-1)[safe], G["logits"].argmax(-1)[safe])
+    g = net.get_gradients()
+    for k in P:
+        ref = G["grad:" + k]
+        if np.abs(ref).max() > 1e-12:
+            assert l2_rel(g[k], ref) < 5e-3, k
+    # two Adam iterations on the same batch (NUM_MINIBATCHES = 1)
+    net.apply_gradients(None)
+    net.zero_gradients(None)
+    res2, _ = net.accum_gradients(None, G["data"], G["label"], w)
+    net.apply_gradients(None)
+    assert abs(res2[1] - G["adam_losses"][1]) < 1e-3 * abs(G["adam_losses"][1])
+    V = net.get_variables()
+    diff = np.concatenate([np.abs(V[k] - G["adam2:" + k]).ravel() for k in P])
+    assert np.quantile(diff, 0.99) < 1e-4
+
+
+def test_driver_call_sequence_checkpoint_and_resume(tmp_path, capsys):
+    """override_config -> initialize -> batch_process -> reset (run_ssnet.py:11-19) on the synthetic source,
+    stdout report format (lib/ssnet_trainval.py:207-215), npz snapshot + resume by file-name iteration."""
+    from uresnet_amd.ssnet_trainval import ssnet_trainval
+    inp = tmp_path / "input.cfg"
+    inp.write_text("Dims [32, 32, 32, 1]\nNumClass 3\nGenerator 'lartpc_sparse'\nNumEntries 64\n"
+                   "Keys {'data': 'data', 'label': 'label', 'weight': 'weight'}\n")
+    cfg = tmp_path / "train.cfg"
+    cfg.write_text("NUM_CLASS 3\nBASE_NUM_FILTERS 4\nMAIN_INPUT_CONFIG '%s'\nLOGDIR '%s'\nSAVE_FILE '%s'\n"
+                   "ITERATIONS 3\nMINIBATCH_SIZE 2\nNUM_MINIBATCHES 2\nLEARNING_RATE 0.001\nTRAIN True\n"
+                   "USE_WEIGHTS True\nREPORT_STEPS 1\nSUMMARY_STEPS 2\nCHECKPOINT_STEPS 2\n"
+                   % (inp, tmp_path / "log", tmp_path / "ckpt" / "uresnet"))
+    t = ssnet_trainval()
+    t.override_config(str(cfg))
+    t.initialize()
+    t.batch_process()
+    out = capsys.readouterr().out
+    assert out.count("@ iteration") == 3 and "Train set: loss=" in out and "acc. nonzero=" in out
+    assert "saved @" in out
+    snap = tmp_path / "ckpt" / "uresnet-1.npz"
+    assert snap.is_file() and (tmp_path / "log" / "train" / "scalars.jsonl").is_file()
+    want = t._net.get_variables() if t.current_iteration() == 1 else None
+    with np.load(str(snap)) as f:
+        saved = {k: f[k] for k in f.files}
+    assert set(saved) == set(t._net.variable_names())
+    t.reset()
+    cfg2 = tmp_path / "ana.cfg"
+    cfg2.write_text("NUM_CLASS 3\nBASE_NUM_FILTERS 4\nMAIN_INPUT_CONFIG '%s'\nLOGDIR ''\nSAVE_FILE ''\n"
+                    "LOAD_FILE '%s'\nITERATIONS 2\nMINIBATCH_SIZE 2\nTRAIN False\nUSE_WEIGHTS False\n"
+                    "SUMMARY_STEPS 0\nCHECKPOINT_STEPS 0\n" % (inp, tmp_path / "ckpt" / "uresnet-1"))
+    a = ssnet_trainval()
+    a.override_config(str(cfg2))
+    a.initialize()
+    assert a.current_iteration() == 1                       # parsed from the file name (lib/ssnet_trainval.py:41-42)
+    got = a._net.get_variables()
+    assert all(np.array_equal(got[k], saved[k]) for k in saved)
+    r = a.ana_step()
+    assert set(r) == {'entries', 'input', 'label', 'softmax', 'acc_all', 'acc_nonzero'}
+    assert r['softmax'].shape == (2, 32, 32, 32, 3) and r['input'].shape == (2, 32, 32, 32, 1)
+    a.reset()
