@@ -378,17 +378,29 @@ WgradPlan wgrad_plan(const GatherGeom& g) {
   return p;
 }
 
-__global__ void slab_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slab, GatherGeom g, int nchunks) {
-  // slab element index e over [t_local][m][n] of THIS geom (rows_total*Nn), written at tap_w-based rows.
-  int64_t per = (int64_t)g.ntaps * g.K * g.Nn;
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < per; e += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = e / ((int64_t)g.K * g.Nn);
-    int64_t rem = e - t * (int64_t)g.K * g.Nn;
-    int64_t idx = (int64_t)g.tap_w[t] * g.K * g.Nn + rem;
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += slab[(int64_t)c * per + idx];
-    dw[idx] += s;
+// dw[tap_w[t]][m][n] += sum over chunk slabs; a block owns 64 elements, its 4 waves split the chunks
+// (fixed order -> bitwise reproducible).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slab,
+                                                          GatherGeom g, int nchunks) {
+  __shared__ float sm[4][64];
+  const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int64_t per = (int64_t)g.ntaps * g.K * g.Nn;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  int64_t idx = 0;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < per) {
+    int64_t t = i / ((int64_t)g.K * g.Nn);
+    idx = (int64_t)g.tap_w[t] * g.K * g.Nn + (i - t * (int64_t)g.K * g.Nn);
+    int c = cg;
+    for (; c + 4 < nchunks; c += 8) {
+      s0 += slab[(int64_t)c * per + idx];
+      s1 += slab[(int64_t)(c + 4) * per + idx];
+    }
+    for (; c < nchunks; c += 4) s0 += slab[(int64_t)c * per + idx];
   }
+  sm[cg][e] = s0 + s1;
+  __syncthreads();
+  if (cg == 0 && i < per) dw[idx] += (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
 }
 
 template <int RT, int BN>
@@ -421,8 +433,8 @@ int launch_wgrad_mfma(const GatherGeom& g, const float* S, const float* C, float
   else { ursn_note_kernel("wgrad_mfma<7,1>"); rc = launch_wgrad_t<7, 1>(g, p, S, C, slab, s); }
   if (rc) return rc;
   int64_t per = (int64_t)p.rows * g.Nn;
-  int blocks = (int)(cdiv64(per, 256) < 2048 ? cdiv64(per, 256) : 2048);
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, dw, (const float*)slab, g, p.nchunks);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdiv64(per, 64)), dim3(256), 0, s, dw, (const float*)slab, g,
+                     p.nchunks);
   URSN_HIP(hipGetLastError());
   return 0;
 }
