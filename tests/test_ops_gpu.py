@@ -344,3 +344,19 @@ def test_tiled_conv_channel_blocks(case):
     dwg = conv_backward_weight(d, xg, dyg, w.shape)
     assert rel_err(dwg.cpu().numpy(), dw) < 5e-5
     assert rel_err(conv_backward_weight(d, xg, dyg, w.shape, dw_init=dwg).cpu().numpy(), 2 * dw) < 5e-5
+
+
+@pytest.mark.parametrize("ndim,S,co", [(3, (16, 16, 32), 8), (3, (19, 13, 45), 8), (2, (24, 300), 16)])
+def test_tiled_conv0_single_input_channel(ndim, S, co):
+    """conv0 (1 -> F): scalar input fetch in the tiled forward, taps-as-rows in the tiled weight gradient."""
+    rng = np.random.default_rng(co + ndim)
+    N = 2
+    x = _rand(rng, (N,) + S + (1,))
+    w = _rand(rng, (3,) * ndim + (1, co)) * 0.3
+    y = O.conv_fwd(x, w, 1)
+    dy = _rand(rng, y.shape)
+    _, dw = O.conv_bwd(x, w, 1, dy)
+    d = desc(ndim, N, S, 1, co, 3, 1, algo=3)
+    xg, wg, dyg = dev(x), dev(w), dev(dy)
+    assert rel_err(conv_forward(d, xg, wg, y.shape).cpu().numpy(), y) < TOL
+    assert rel_err(conv_backward_weight(d, xg, dyg, w.shape).cpu().numpy(), dw) < 5e-5

@@ -241,7 +241,14 @@ int launch_gconv_mfma(const GatherGeom& g, const float* in, const float* w, floa
     ursn_note_kernel("gconv_mfma<4,1,1>");
     return launch_gconv_t<4, 1, 1>(g, in, w, out, s);
   }
-  if (bn == 4) { ursn_note_kernel("gconv_mfma<1,4,4>"); return launch_gconv_t<1, 4, 4>(g, in, w, out, s); }
+  if (bn == 4) {
+    // more voxel tiles per wave = more reuse of every weight operand fetched through L1 (the k-split form is
+    // L1-bound at one tile: 5 loads per 4 MFMAs); keep >= ~256 workgroups
+    if (vtiles / 4 * gy >= 256) { ursn_note_kernel("gconv_mfma<4,4,4>"); return launch_gconv_t<4, 4, 4>(g, in, w, out, s); }
+    if (vtiles / 2 * gy >= 200) { ursn_note_kernel("gconv_mfma<2,4,4>"); return launch_gconv_t<2, 4, 4>(g, in, w, out, s); }
+    ursn_note_kernel("gconv_mfma<1,4,4>");
+    return launch_gconv_t<1, 4, 4>(g, in, w, out, s);
+  }
   if (bn == 2) { ursn_note_kernel("gconv_mfma<1,2,4>"); return launch_gconv_t<1, 2, 4>(g, in, w, out, s); }
   ursn_note_kernel("gconv_mfma<1,1,4>");
   return launch_gconv_t<1, 1, 4>(g, in, w, out, s);

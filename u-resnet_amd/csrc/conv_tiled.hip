@@ -15,8 +15,9 @@ static bool tiled_shape_ok(int cin, int cout, int mode) {
   if (cin % 4 || cout % 4 || cin < 4 || cout < 4) return false;
   // instantiated shapes (weights + accumulators must fit 256 VGPRs for two waves per SIMD)
   if ((cin == 8 || cin == 16) && (cout == 8 || cout == 16)) return true;
-  if (mode == 3) return (cin == 8 && cout == 4) || (cin == 4 && cout == 8);     // conv2 (8 -> 3 classes) and its dgrad
-  return (cin == 32 && cout == 16) || (cin == 16 && cout == 32) || (cin == 16 && cout == 4) || (cin == 4 && cout == 16);
+  if (mode == 3) return (cin == 8 && cout == 4) || (cin == 4 && cout == 8);     // conv2 (8 -> 3 classes), its dgrad, conv0
+  return (cin == 32 && cout == 16) || (cin == 16 && cout == 32) || (cin == 16 && cout == 4) || (cin == 4 && cout == 16) ||
+         (cin == 4 && cout == 8);
 }
 
 static bool tiled_disabled() {  // URSN_DISABLE_TILED=1: route everything through the generic kernels (A/B debugging)
@@ -55,7 +56,9 @@ static bool make_plan(const ursn_conv_desc& d, ConvPass pass, TPlan& p, Blocking
   p.cin = ((p.flip ? d.cout : d.cin) + 3) & ~3;   // kernel view: channel counts padded to 4 (buffers are padded too)
   p.cout = ((p.flip ? d.cin : d.cout) + 3) & ~3;
   const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
-  if ((ics & 3) || (ocs & 3)) return false;
+  const bool single_in = (d.cin == 1 && ics == 1 && !p.flip);   // conv0: scalar input fetch, kernel view Cin = 4
+  if (((ics & 3) && !single_in) || (ocs & 3)) return false;
+  if (d.cin == 1 && p.flip) return false;
   if (!spatial_plan(d, p.Z, p.Y, p.X, p.ntx, p.nty, p.zseg, p.nzseg, 1024)) return false;
   p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
   b = Blocking();
@@ -142,13 +145,13 @@ static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
   if (d.transposed || d.k != 3 || d.stride != 1) return false;
   p.mode = d.ndim; p.cin = d.cin; p.cout = (d.cout + 3) & ~3;
   const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
-  if ((ics & 3) || (ocs & 3)) return false;
+  if (((ics & 3) && !(d.cin == 1 && ics == 1)) || (ocs & 3)) return false;
   if (!spatial_plan(d, p.Z, p.Y, p.X, p.ntx, p.nty, p.zseg, p.nzseg, 512)) return false;
   p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
   b = Blocking();
   bool c816 = (d.cin == 8 || d.cin == 16) && (p.cout == 8 || p.cout == 16);
-  bool extra = d.ndim == 3 ? (d.cin == 8 && p.cout == 4)
-                           : ((d.cin == 16 && p.cout == 32) || (d.cin == 16 && p.cout == 4));
+  bool extra = d.ndim == 3 ? ((d.cin == 8 && p.cout == 4) || (d.cin == 1 && p.cout == 8))
+                           : ((d.cin == 16 && p.cout == 32) || (d.cin == 16 && p.cout == 4) || (d.cin == 1 && p.cout == 16));
   if (!(c816 || extra)) {
     if ((d.cin % 16) || (d.cout % 16) || d.cin > 64 || d.cout > 64 || (p.grid < 96 && d.algo != 3)) return false;
     b.nbi = d.cin / 16;

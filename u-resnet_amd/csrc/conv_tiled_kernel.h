@@ -109,8 +109,11 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
         int q = idx / PS, s = idx - q * PS;
         int yy = s / PX, xx = s - yy * PX;
         int py = y0 + yy - (NTY == 3 ? 1 : 0), px = x0 + xx - 1;
-        if (zin >= 0 && zin < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
-          v = *(const f32x4*)(a.in + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.in_cs + 4 * q);
+        if (zin >= 0 && zin < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X) {
+          const float* src = a.in + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.in_cs + 4 * q;
+          if (a.cin_w == 1 && !FLIP) v[0] = *src;   // single-channel input (conv0): scalar fetch, lanes 1..3 stay 0
+          else v = *(const f32x4*)src;
+        }
       }
       stage[i] = v;
     }

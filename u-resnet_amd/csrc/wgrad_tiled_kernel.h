@@ -48,10 +48,11 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
   constexpr int TX = TL::TX, TY = TL::TY, NTY = TL::NTY, NT = TL::NT;
   constexpr int PX = TX + 2, PY = TY + (NTY == 3 ? 2 : 0), PS = PX * PY;
   constexpr int MT = CIN >= 16 ? CIN / 16 : 1;                 // row tiles per tap
-  constexpr int NA = CIN >= 16 ? NT * MT : (NT + 1) / 2;       // A operands (= row tiles) per voxel group
+  // A operands (= 16-row tiles) per voxel group: Cin>=16: Cin/16 per tap; Cin=8: two taps per tile; Cin=1: 16 taps
+  constexpr int NA = CIN >= 16 ? NT * MT : (CIN == 1 ? (NT + 15) / 16 : (NT + 1) / 2);
   constexpr int CT = (COUT + 15) / 16;                         // col tiles
-  constexpr int XQ = CIN / 4, DQ = COUT / 4;                   // float4 per voxel
-  constexpr int NSX = (XQ * PS + 255) / 256;                   // staging float4 per thread (x plane)
+  constexpr int XQ = CIN >= 4 ? CIN / 4 : 1, DQ = COUT / 4;    // float4 per voxel (Cin = 1: one scalar)
+  constexpr int NSX = (XQ * PS + 255) / 256;                   // staging elements per thread (x plane)
   constexpr int NSD = (DQ * TX * TY + 255) / 256;              // staging float4 per thread (dz plane)
   constexpr int XPLANE = PS * CIN, DPLANE = TX * TY * COUT;    // floats
   constexpr int GPR = TX / 4 / (MODE == 3 ? 1 : 4);            // voxel groups per tile row handled by one wave
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
   for (int m = 0; m < NA; ++m) {
     int tap, ci;
     if (CIN >= 16) { tap = m / MT; ci = (m % MT) * 16 + il; }
+    else if (CIN == 1) { tap = 16 * m + il; ci = 0; }
     else { tap = 2 * m + (il >> 3); ci = il & 7; }
     bool ok = tap < NT;
     if (!ok) tap = 0;
@@ -105,8 +107,11 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
         int s = idx / XQ, q = idx - s * XQ;
         int yy = s / PX, xx = s - yy * PX;
         int py = y0 + yy - (NTY == 3 ? 1 : 0), px = x0 + xx - 1;
-        if (zin >= 0 && zin < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
-          v = *(const wg_f32x4*)(a.x + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.x_cs + 4 * q);
+        if (zin >= 0 && zin < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X) {
+          const float* src = a.x + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.x_cs + 4 * q;
+          if (CIN == 1) v[0] = *src;
+          else v = *(const wg_f32x4*)src;
+        }
       }
       sx[i] = v;
     }
@@ -115,7 +120,10 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
 #pragma unroll
     for (int i = 0; i < NSX; ++i) {
       int idx = tid + i * 256;
-      if (idx < XQ * PS) *(wg_f32x4*)(xr + (size_t)slot * XPLANE + idx * 4) = sx[i];
+      if (idx < XQ * PS) {
+        if (CIN == 1) xr[(size_t)slot * XPLANE + idx] = sx[i][0];
+        else *(wg_f32x4*)(xr + (size_t)slot * XPLANE + idx * 4) = sx[i];
+      }
     }
   };
   auto load_d = [&](int zin) {
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
         int row = 4 * kl + r;
         int tap, ci;
         if (CIN >= 16) { tap = m / MT; ci = (m % MT) * 16 + row; }
+        else if (CIN == 1) { tap = 16 * m + row; ci = 0; }
         else { tap = 2 * m + (row >> 3); ci = row & 7; }
         if (tap < NT && col < a.cout_w) slab[((size_t)tap * CIN + ci) * a.cout_w + col] = acc[m][c][r];
       }
