@@ -342,6 +342,7 @@ extern "C" int ursn_bn_backward(const float* dy, const float* y, const float* z,
   memset(&a, 0, sizeof(a));
   a.dy = dy; a.dycs = channels; a.y = y; a.ycs = channels; a.z = z; a.zcs = channels;
   a.mean = ms; a.rstd = ms + channels; a.dz = dz; a.dzcs = channels; a.dbeta = dbeta;
+  a.beta = nullptr;  // op-level API: mask from y
   a.V = voxels; a.C = channels; a.relu = relu; a.scratch = scratch;
   return launch_bn_bwd(a, s);
 }

@@ -11,6 +11,9 @@
 #include "conv_tiled_kernel.h"
 #include "wgrad_tiled_kernel.h"
 
+int twgrad4_dispatch_3d(const TWPlan& p, const TWgradArgs& a, hipStream_t s);
+int twgrad4_dispatch_2d(const TWPlan& p, const TWgradArgs& a, hipStream_t s);
+
 static bool tiled_shape_ok(int cin, int cout, int mode) {
   if (cin % 4 || cout % 4 || cin < 4 || cout < 4) return false;
   // instantiated shapes (weights + accumulators must fit 256 VGPRs for two waves per SIMD)
@@ -140,6 +143,21 @@ int launch_tiled_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, c
 // ---------------------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------------------
+static bool wgrad4_enabled() {  // URSN_WGRAD4=0: keep the 16x16x4 kernel for Cout <= 8 too (A/B)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("URSN_WGRAD4"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+static bool use_wgrad4(const ursn_conv_desc& d, const TWPlan& p) {
+  // measured (profiles/r01): the 4x4x1 form needs one LDS operand per 8-cycle MFMA and loses to the 16x16x4 kernel
+  // at Cout = 8 (37 vs 42 TFLOP/s) but wins for the 3|4-channel logits layer (1.4 vs 2.0 ms); URSN_WGRAD4=8 forces it
+  static int force8 = -1;
+  if (force8 < 0) { const char* e = getenv("URSN_WGRAD4"); force8 = (e && e[0] == '8') ? 1 : 0; }
+  if (!wgrad4_enabled() || !(d.cin == 8 || d.cin == 16)) return false;
+  if (d.ndim == 3 && d.cin == 16 && p.cout == 4) return false;
+  return p.cout == 4 || (force8 && p.cout == 8);
+}
+
 static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
   if (tiled_disabled() && d.algo != 3) return false;
   if (d.transposed || d.k != 3 || d.stride != 1) return false;
@@ -151,7 +169,8 @@ static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
   b = Blocking();
   bool c816 = (d.cin == 8 || d.cin == 16) && (p.cout == 8 || p.cout == 16);
   bool extra = d.ndim == 3 ? ((d.cin == 8 && p.cout == 4) || (d.cin == 1 && p.cout == 8))
-                           : ((d.cin == 16 && p.cout == 32) || (d.cin == 16 && p.cout == 4) || (d.cin == 1 && p.cout == 16));
+                           : ((d.cin == 16 && p.cout == 32) || (d.cin == 16 && p.cout == 4) || (d.cin == 1 && p.cout == 16) ||
+                              (d.cin == 8 && p.cout == 4));
   if (!(c816 || extra)) {
     if ((d.cin % 16) || (d.cout % 16) || d.cin > 64 || d.cout > 64 || (p.grid < 96 && d.algo != 3)) return false;
     b.nbi = d.cin / 16;
@@ -176,7 +195,7 @@ size_t tiled_wgrad_scratch_bytes(const ursn_conv_desc& d) {
   if (!make_wplan(d, p, b)) return 0;
   int taps = d.ndim == 3 ? 27 : 9;
   int ci = (b.nbi > 1 || b.nbo > 1) ? 16 : d.cin, co = (b.nbi > 1 || b.nbo > 1) ? 16 : d.cout;
-  return (size_t)p.grid * 4 * taps * ci * co * sizeof(float);
+  return (size_t)p.grid * 4 * taps * ci * co * sizeof(float);   // the 4x4x1 form needs a quarter of it
 }
 
 int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
@@ -195,6 +214,12 @@ int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy,
   a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
   a.cout_w = blocked ? 16 : d.cout;
   const int taps = d.ndim == 3 ? 27 : 9;
+  if (!blocked && use_wgrad4(d, p)) {  // Cout <= 8: 4x4x1 blocks, one slab per workgroup
+    a.x = x;
+    a.dz = dy;
+    URSN_TRY(p.mode == 3 ? twgrad4_dispatch_3d(p, a, s) : twgrad4_dispatch_2d(p, a, s));
+    return launch_reduce_accum(dw, (const float*)scratch, (int64_t)taps * d.cin * d.cout, p.grid, s);
+  }
   for (int bi = 0; bi < b.nbi; ++bi)
     for (int bo = 0; bo < b.nbo; ++bo) {
       a.x = x + 16 * bi;

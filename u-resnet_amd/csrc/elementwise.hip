@@ -235,27 +235,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int shi
 #pragma unroll
   for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.0;
   if (c < a.C) {
-    float mu[VEC], rs[VEC], mu2[VEC], rs2[VEC];
+    float mu[VEC], rs[VEC], mu2[VEC], rs2[VEC], be[VEC];
+    const bool ymask = a.relu && a.y != nullptr, zmask = a.relu && a.y == nullptr;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       mu[j] = a.mean[c + j];
       rs[j] = a.rstd[c + j];
       mu2[j] = a.z2 ? a.mean2[c + j] : 0.f;
       rs2[j] = a.z2 ? a.rstd2[c + j] : 0.f;
+      be[j] = zmask ? a.beta[c + j] - mu[j] * rs[j] : 0.f;   // shift of the forward pass
     }
     for (int64_t v = (int64_t)blockIdx.x * VPB + vr; v < a.V; v += (int64_t)gridDim.x * VPB) {
       typename VT<VEC>::T g = ldv<VEC>(a.dy + v * a.dycs + c);
       typename VT<VEC>::T x = ldv<VEC>(a.z + v * a.zcs + c);
       typename VT<VEC>::T yv, x2;
-      if (a.relu) yv = ldv<VEC>(a.y + v * a.ycs + c);
+      if (ymask) yv = ldv<VEC>(a.y + v * a.ycs + c);
       if (a.z2) x2 = ldv<VEC>(a.z2 + v * a.z2cs + c);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         float gj = elem(g, j);
-        if (a.relu && !(elem(yv, j) > 0.f)) gj = 0.f;
+        const float xh0 = (elem(x, j) - mu[j]) * rs[j];
+        if (ymask && !(elem(yv, j) > 0.f)) gj = 0.f;
+        if (zmask && !(fmaf(elem(x, j), rs[j], be[j]) > 0.f)) gj = 0.f;   // same expression as bn_act
         double gd = (double)gj;
         acc[0][j] += gd;
-        acc[1][j] += gd * (double)((elem(x, j) - mu[j]) * rs[j]);
+        acc[1][j] += gd * (double)xh0;
         if (a.z2) acc[2][j] += gd * (double)((elem(x2, j) - mu2[j]) * rs2[j]);
       }
     }
@@ -285,11 +289,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int shif
   const int c = (threadIdx.x & (CP - 1)) * VEC;
   const int vr = threadIdx.x >> shift;
   if (c >= a.C) return;
-  float mu[VEC], rs[VEC], mu2[VEC], rs2[VEC], mg[VEC], mgx[VEC], mgx2[VEC];
+  float mu[VEC], rs[VEC], mu2[VEC], rs2[VEC], mg[VEC], mgx[VEC], mgx2[VEC], be[VEC];
+  const bool ymask = a.relu && a.y != nullptr, zmask = a.relu && a.y == nullptr;
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     mu[j] = a.mean[c + j];
     rs[j] = a.rstd[c + j];
+    be[j] = zmask ? a.beta[c + j] - mu[j] * rs[j] : 0.f;
     mu2[j] = a.z2 ? a.mean2[c + j] : 0.f;
     rs2[j] = a.z2 ? a.rstd2[c + j] : 0.f;
     mg[j] = (float)finals[c + j];
@@ -300,14 +306,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int shif
     typename VT<VEC>::T g = ldv<VEC>(a.dy + v * a.dycs + c);
     typename VT<VEC>::T x = ldv<VEC>(a.z + v * a.zcs + c);
     typename VT<VEC>::T yv, x2, dz, dz2, dr;
-    if (a.relu) yv = ldv<VEC>(a.y + v * a.ycs + c);
+    if (ymask) yv = ldv<VEC>(a.y + v * a.ycs + c);
     if (a.z2) x2 = ldv<VEC>(a.z2 + v * a.z2cs + c);
     if (a.dres && a.dres_accumulate) dr = ldv<VEC>(a.dres + v * a.drescs + c);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float gj = elem(g, j);
-      if (a.relu && !(elem(yv, j) > 0.f)) gj = 0.f;
       float xh = (elem(x, j) - mu[j]) * rs[j];
+      if (ymask && !(elem(yv, j) > 0.f)) gj = 0.f;
+      if (zmask && !(fmaf(elem(x, j), rs[j], be[j]) > 0.f)) gj = 0.f;
       setelem(dz, j, rs[j] * (gj - mg[j] - xh * mgx[j]));
       if (a.z2) {
         float xh2 = (elem(x2, j) - mu2[j]) * rs2[j];
@@ -322,7 +329,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int shif
 }
 
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
-  bool v4 = vec4_ok(a.C, {a.dycs, a.relu ? a.ycs : 0, a.zcs, a.dzcs, a.z2 ? a.z2cs : 0, a.z2 ? a.dz2cs : 0,
+  URSN_REQUIRE(!a.relu || a.y || a.beta, "bn_bwd: relu mask needs y or beta");
+  bool v4 = vec4_ok(a.C, {a.dycs, (a.relu && a.y) ? a.ycs : 0, a.zcs, a.dzcs, a.z2 ? a.z2cs : 0, a.z2 ? a.dz2cs : 0,
                           a.dres ? a.drescs : 0},
                     {a.dy, a.relu ? a.y : nullptr, a.z, a.dz, a.z2, a.dz2, a.dres});
   URSN_REQUIRE(v4 || a.C <= 256, "bn_bwd: unsupported channel count %d", a.C);

@@ -425,6 +425,7 @@ int bn_back(ursn_net* n, int li, const float* dy, int dycs, const float* y, int 
   a.dy = dy; a.dycs = dycs; a.y = y; a.ycs = ycs;
   a.z = L.z; a.zcs = L.zcs; a.mean = L.mean; a.rstd = L.rstd; a.dz = L.dz; a.dzcs = L.zcs;
   a.dbeta = n->grads + L.b_off;
+  a.beta = n->params + L.b_off;
   if (li2 >= 0) {
     Layer& L2 = n->layers[li2];
     a.z2 = L2.z; a.z2cs = L2.cout; a.mean2 = L2.mean; a.rstd2 = L2.rstd; a.dz2 = L2.dz; a.dz2cs = L2.cout;
@@ -459,14 +460,14 @@ int backward(ursn_net* n, const float* data, int N, hipStream_t s) {
   Layer& L2 = n->layers[n->conv2];
   URSN_TRY(bn_back(n, n->conv2, n->dlog, L2.cout, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
   URSN_TRY(conv_bwd(n, n->conv2, n->a_conv1, true, N, s));
-  URSN_TRY(bn_back(n, n->conv1, n->a_conv1.g, n->a_conv1.cs, n->a_conv1.p, n->a_conv1.cs, 1, -1, nullptr, 0, 0, N, s));
+  URSN_TRY(bn_back(n, n->conv1, n->a_conv1.g, n->a_conv1.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
   URSN_TRY(conv_bwd(n, n->conv1, n->a_pre1, true, N, s));
   size_t ui = n->units.size();
   for (int i = ns - 1; i >= 0; --i) {
     URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
     URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
     const Act& dout = n->deconv_out[i];
-    URSN_TRY(bn_back(n, n->deconv[i], dout.g, dout.cs, dout.p, dout.cs, 1, -1, nullptr, 0, 0, N, s));
+    URSN_TRY(bn_back(n, n->deconv[i], dout.g, dout.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
     URSN_TRY(conv_bwd(n, n->deconv[i], n->deconv_in[i], true, N, s));
   }
   for (int step = ns - 1; step >= 0; --step) {
@@ -474,7 +475,7 @@ int backward(ursn_net* n, const float* data, int N, hipStream_t s) {
     URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
   }
   const Act& a0 = n->a_conv0;
-  URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, a0.p, a0.cs, 1, -1, nullptr, 0, 0, N, s));
+  URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
   Act din = n->a_data;
   din.p = const_cast<float*>(data);
   URSN_TRY(conv_bwd(n, n->conv0, din, false, N, s));

@@ -125,6 +125,7 @@ int launch_bn_act(const BnActArgs& a, hipStream_t s);
 struct BnBwdArgs {
   const float* dy; int dycs; const float* y; int ycs;
   const float* z; int zcs; const float* mean; const float* rstd; float* dz; int dzcs; float* dbeta;
+  const float* beta;  // with relu and y == nullptr the mask is recomputed as bn(z) > 0 (saves reading y twice)
   const float* z2; int z2cs; const float* mean2; const float* rstd2; float* dz2; int dz2cs; float* dbeta2;
   float* dres; int drescs; int dres_accumulate;
   int64_t V; int C; int relu;
