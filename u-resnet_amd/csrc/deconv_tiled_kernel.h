@@ -1,0 +1,224 @@
+// LDS-tiled stride-2 "scatter-type" convolution for the full-resolution levels -- gfx950.
+//
+// Evaluates   out[2q + par][p] (+)= sum_{k : k == par (mod 2) per axis} X[q + (par - k)/2][c] * W[k][p][c]
+// i.e. the transposed convolution of lib/uresnet.py:68-88 (k3 s2 SAME, W = [k..,Cout,Cin]) AND the data gradient
+// of the stride-2 k3 convolutions of lib/resnet_module.py:43-51 (W = [k..,Cin,Cout]: same memory pattern
+// [k][produced][contracted]); SURVEY.md Appendix B-2 (the two are the same operator).
+//
+// lane = one LOW-resolution voxel q; it owns the 2^d high-resolution outputs 2q + par (one accumulator set per
+// parity class) and reads only its 2^d neighbours q + {0,-1}^d from a 2(+1)-plane LDS ring (halo of one on the
+// low side).  Each of the 27 (9) filter taps feeds exactly one class, so the MFMA count equals the dense count
+// (27*Cc*Cp/4 v_mfma_f32_4x4x1_16b per voxel), and weights stay in registers via the cbsz/abid A-broadcast
+// exactly as in conv_tiled_kernel.h.  Every lane stores 2 x-adjacent output voxels per (pz,py): 64 contiguous
+// bytes at Cp = 8, instead of the eight stride-2 scatter launches of the generic path.
+#pragma once
+#include "conv_tiled_kernel.h"
+
+struct TDeconvArgs {
+  const float* in;   // low-res [N][Z][Y][X][in_cs]
+  const float* w;    // [taps][cp_w][ck_w]
+  float* out;        // high-res [N][2Z][2Y][2X][out_cs]
+  double* stats_partial;
+  int N, Z, Y, X;    // LOW-res dims (2-D: Z = H, Y = 1, X = W)
+  int in_cs, out_cs;
+  int zseg, nzseg, nty, ntx;
+  int accumulate;
+  int cp_w, ck_w;    // stored weight dims
+};
+
+// CK = contracted channels, CP = produced channels
+template <int CK, int CP, int MODE, bool STATS>
+__global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
+  using TL = Tile<MODE>;
+  constexpr int TX = TL::TX, TY = TL::TY, NTY = TL::NTY, NT = TL::NT;
+  constexpr int HY = (NTY == 3) ? 1 : 0;                       // halo rows on the low side
+  constexpr int PX = TX + 1, PY = TY + HY, PS = PX * PY;
+  constexpr int NQ = CK / 4, CQ = CP / 4;
+  constexpr int KTOT = NT * CK, R = (KTOT + 15) / 16;
+  constexpr int NSTAGE = (NQ * PS + 255) / 256;
+  constexpr int NCLS = (NTY == 3) ? 8 : 4;
+  extern __shared__ __attribute__((aligned(16))) f32x4 dlds[];  // [3 ring slots][NQ][PS]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  int bid = blockIdx.x;
+  const int xt = bid % a.ntx; bid /= a.ntx;
+  const int yt = bid % a.nty; bid /= a.nty;
+  const int zs = bid % a.nzseg;
+  const int n = bid / a.nzseg;
+  const int x0 = xt * TX, y0 = yt * TY;
+  const int z0 = zs * a.zseg;
+  const int z1 = (z0 + a.zseg < a.Z) ? z0 + a.zseg : a.Z;
+  const int ty = tid / TX, tx = tid % TX;
+  const int gy = y0 + ty, gx = x0 + tx;
+  const bool vox_ok = gy < a.Y && gx < a.X;
+
+  // weights -> registers: lane l holds W[k = 16r + (l>>2) -> (tap, c)][p = 4cq + (l&3)]
+  float wreg[CQ][R];
+  {
+    const int kl = lane >> 2, cl = lane & 3;
+#pragma unroll
+    for (int cq = 0; cq < CQ; ++cq)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int k = 16 * r + kl;
+        int t = k / CK, c = k - t * CK;
+        int p = 4 * cq + cl;
+        float v = 0.f;
+        if (k < KTOT && p < a.cp_w && c < a.ck_w) v = a.w[((size_t)t * a.cp_w + p) * a.ck_w + c];
+        wreg[cq][r] = v;
+      }
+  }
+
+  f32x4 stage[NSTAGE];
+  auto stage_load = [&](int zin) {
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+      int idx = tid + i * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < NQ * PS) {
+        int q = idx / PS, s = idx - q * PS;
+        int yy = s / PX, xx = s - yy * PX;
+        int py = y0 + yy - HY, px = x0 + xx - 1;
+        if (zin >= 0 && zin < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
+          v = *(const f32x4*)(a.in + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.in_cs + 4 * q);
+      }
+      stage[i] = v;
+    }
+  };
+  auto stage_store = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+      int idx = tid + i * 256;
+      if (idx < NQ * PS) dlds[(size_t)slot * NQ * PS + idx] = stage[i];
+    }
+  };
+
+  float s1[STATS ? CP : 1], s2[STATS ? CP : 1];
+#pragma unroll
+  for (int c = 0; c < (STATS ? CP : 1); ++c) s1[c] = s2[c] = 0.f;
+
+  // prologue: planes z0-1, z0  (ring slot of plane z = (z + 3) % 3)
+  stage_load(z0 - 1);
+  stage_store((z0 + 2) % 3);
+  stage_load(z0);
+  stage_store(z0 % 3);
+  __syncthreads();
+
+  const int lane_slot = (ty + HY) * PX + tx + 1;   // the lane's own voxel inside a plane
+  for (int z = z0; z < z1; ++z) {
+    stage_load(z + 1);
+    f32x4 acc[NCLS][CQ];
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+      for (int cq = 0; cq < CQ; ++cq) acc[c][cq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4* p_cur = dlds + (size_t)(z % 3) * NQ * PS + lane_slot;
+    const f32x4* p_prev = dlds + (size_t)((z + 2) % 3) * NQ * PS + lane_slot;
+    // loop over the 2^d source offsets; every tap with that offset reuses the loaded voxel
+    static_for<NCLS>([&](auto OFF) {
+      constexpr int off = decltype(OFF)::value;                 // bit2: z-1, bit1: y-1, bit0: x-1 (3-D); 2-D: bit1: row-1
+      constexpr int oz = (NTY == 3) ? (off >> 2) & 1 : (off >> 1) & 1;
+      constexpr int oy = (NTY == 3) ? (off >> 1) & 1 : 0;
+      constexpr int ox = off & 1;
+      const f32x4* pl = oz ? p_prev : p_cur;
+      static_for<NQ>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        f32x4 xv = pl[q * PS - oy * PX - ox];
+        static_for<NT>([&](auto T) {
+          constexpr int t = decltype(T)::value;
+          constexpr int kz = t / (NTY * 3), ky = (t / 3) % NTY, kx = t % 3;   // 2-D: ky == 0 always, kz = row tap
+          // per axis: k = 0 -> (par 0, source q); k = 1 -> (par 1, source q); k = 2 -> (par 0, source q-1)
+          constexpr int toz = (kz == 2), tox = (kx == 2), toy = (NTY == 3) ? (ky == 2) : 0;
+          if constexpr (toz == oz && toy == oy && tox == ox) {
+            constexpr int pz = (kz == 1), px_ = (kx == 1), py_ = (NTY == 3) ? (ky == 1) : 0;
+            constexpr int cls = (NTY == 3) ? (pz * 4 + py_ * 2 + px_) : (pz * 2 + px_);
+            static_for<4>([&](auto J) {
+              constexpr int j = decltype(J)::value;
+              constexpr int k = t * CK + 4 * q + j;
+              static_for<CQ>([&](auto C) {
+                constexpr int cq = decltype(C)::value;
+                acc[cls][cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[cq][k / 16], xv[j], acc[cls][cq], 4, k % 16, 0);
+              });
+            });
+          }
+        });
+      });
+    });
+    if (vox_ok) {
+#pragma unroll
+      for (int c = 0; c < NCLS; ++c) {
+        const int pz = (NTY == 3) ? (c >> 2) & 1 : (c >> 1) & 1;
+        const int py = (NTY == 3) ? (c >> 1) & 1 : 0;
+        const int px = c & 1;
+        float* op = a.out + ((((size_t)n * (2 * a.Z) + (2 * z + pz)) * ((NTY == 3) ? 2 * a.Y : 1) + (2 * gy + py)) *
+                                 (2 * a.X) + (2 * gx + px)) * a.out_cs;
+#pragma unroll
+        for (int cq = 0; cq < CQ; ++cq) {
+          f32x4 v = acc[c][cq];
+          if (a.accumulate) v += *(f32x4*)(op + 4 * cq);
+          *(f32x4*)(op + 4 * cq) = v;
+          if constexpr (STATS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              s1[4 * cq + j] += v[j];
+              s2[4 * cq + j] += v[j] * v[j];
+            }
+          }
+        }
+      }
+    }
+    stage_store((z + 1) % 3);
+    __syncthreads();
+  }
+
+  if constexpr (STATS) if (a.stats_partial) {
+    __shared__ float red[4][2 * CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      float u = s1[c], v = s2[c];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        u += __shfl_xor(u, o);
+        v += __shfl_xor(v, o);
+      }
+      if (lane == 0) {
+        red[tid >> 6][c] = u;
+        red[tid >> 6][CP + c] = v;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * CP) {
+      double t = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
+      a.stats_partial[(size_t)blockIdx.x * 2 * CP + tid] = t;
+    }
+  }
+}
+
+struct TDPlan {
+  int mode, ck, cp;
+  int Z, Y, X, zseg, nzseg, nty, ntx;
+  size_t lds;
+  int grid;
+};
+
+template <int CK, int CP, int MODE, bool STATS>
+static int launch_td(const TDPlan& p, const TDeconvArgs& a, hipStream_t s) {
+  auto kern = tdeconv_kernel<CK, CP, MODE, STATS>;
+  static size_t attr_lds = 48 * 1024;
+  if (p.lds > attr_lds) {
+    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    attr_lds = p.lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds, s, a);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+#define URSN_TD(ck_, cp_)                                                                        \
+  if (p.ck == ck_ && p.cp == cp_) {                                                              \
+    ursn_note_kernel("tdeconv<" #ck_ "," #cp_ ">");                                              \
+    return a.stats_partial ? launch_td<ck_, cp_, MODE, true>(p, a, s) : launch_td<ck_, cp_, MODE, false>(p, a, s); \
+  }
+
+int tdeconv_dispatch_3d(const TDPlan& p, const TDeconvArgs& a, hipStream_t s);
+int tdeconv_dispatch_2d(const TDPlan& p, const TDeconvArgs& a, hipStream_t s);
