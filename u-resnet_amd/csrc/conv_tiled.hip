@@ -13,6 +13,7 @@
 
 int twgrad4_dispatch_3d(const TWPlan& p, const TWgradArgs& a, hipStream_t s);
 int twgrad4_dispatch_2d(const TWPlan& p, const TWgradArgs& a, hipStream_t s);
+int twgradz_dispatch(const TWPlan& p, const TWgradArgs& a, hipStream_t s);
 
 static bool tiled_shape_ok(int cin, int cout, int mode) {
   if (cin % 4 || cout % 4 || cin < 4 || cout < 4) return false;
@@ -158,6 +159,12 @@ static bool use_wgrad4(const ursn_conv_desc& d, const TWPlan& p) {
   return p.cout == 4 || (force8 && p.cout == 8);
 }
 
+static bool use_wgradz(const ursn_conv_desc& d) {  // Cout == 8: plane-pair kernel (URSN_WGRADZ=0 disables, A/B)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("URSN_WGRADZ"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1 && d.cout == 8 && (d.cin == 8 || d.cin == 16);
+}
+
 static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
   if (tiled_disabled() && d.algo != 3) return false;
   if (d.transposed || d.k != 3 || d.stride != 1) return false;
@@ -180,6 +187,7 @@ static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
   const int TX = p.mode == 3 ? 32 : 256, TY = p.mode == 3 ? 8 : 1;
   const int PX = TX + 2, PY = TY + (p.mode == 3 ? 2 : 0);
   p.lds = ((size_t)4 * PX * PY * p.cin + (size_t)2 * TX * TY * p.cout) * sizeof(float) + 256;
+  if (use_wgradz(d)) p.lds = ((size_t)6 * PX * PY * 8 + (size_t)4 * TX * TY * 8) * sizeof(float) + 256;
   return p.lds <= 160 * 1024;
 }
 
@@ -195,6 +203,7 @@ size_t tiled_wgrad_scratch_bytes(const ursn_conv_desc& d) {
   if (!make_wplan(d, p, b)) return 0;
   int taps = d.ndim == 3 ? 27 : 9;
   int ci = (b.nbi > 1 || b.nbo > 1) ? 16 : d.cin, co = (b.nbi > 1 || b.nbo > 1) ? 16 : d.cout;
+  if (use_wgradz(d)) return (size_t)p.grid * 8 * taps * 8 * 8 * sizeof(float);   // two slabs per wave
   return (size_t)p.grid * 4 * taps * ci * co * sizeof(float);   // the 4x4x1 form needs a quarter of it
 }
 
@@ -214,6 +223,18 @@ int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy,
   a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
   a.cout_w = blocked ? 16 : d.cout;
   const int taps = d.ndim == 3 ? 27 : 9;
+  if (!blocked && use_wgradz(d)) {  // Cout == 8: two output planes share each MFMA; Cin = 16 as two 8-channel slices
+    a.dz = dy;
+    a.cout_w = 8;
+    for (int bi = 0; bi < d.cin / 8; ++bi) {
+      a.x = x + 8 * bi;
+      URSN_TRY(twgradz_dispatch(p, a, s));
+      if (d.cin == 8) return launch_reduce_accum(dw, (const float*)scratch, (int64_t)taps * 64, p.grid * 8, s);
+      URSN_TRY(launch_reduce_accum_blocked(dw + (size_t)8 * bi * 8, (const float*)scratch, taps, 8, 8, (int64_t)d.cin * 8,
+                                           8, p.grid * 8, s));
+    }
+    return 0;
+  }
   if (!blocked && use_wgrad4(d, p)) {  // Cout <= 8: 4x4x1 blocks, one slab per workgroup
     a.x = x;
     a.dz = dy;

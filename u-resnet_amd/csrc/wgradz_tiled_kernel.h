@@ -1,0 +1,171 @@
+// Weight gradient for Cout = 8 (the full-resolution 8->8 / 16->8 layers) with both halves of the 16-wide MFMA
+// column tile doing useful work -- gfx950.
+//
+// twgrad<*,8> leaves columns 8..15 of every v_mfma_f32_16x16x4_f32 empty (Cout = 8).  Here two OUTPUT planes
+// are processed per step: columns 0..7 carry dz of plane z, columns 8..15 dz of plane z+1.  The A operand
+// (x at plane z-1+tz4, tz4 = 0..3) is shared, so
+//     D[(tz4,ty,tx,ci)][co]     accumulates tap (tz4,   ty, tx) for plane z      (valid tz4 <= 2)
+//     D[(tz4,ty,tx,ci)][8 + co] accumulates tap (tz4-1, ty, tx) for plane z + 1  (valid tz4 >= 1)
+// i.e. 36 tap rows serve 2 x 27 taps: 18 MFMAs per 4-voxel group and plane pair instead of 2 x 14 (Cin = 8).
+// Both column halves cover exactly the workgroup's voxels of their own plane, so image borders need no
+// special case.  Ring of 6 x planes (4 live + 2 in flight), 4 dz planes; two slabs per wave (one per column
+// half), summed into the gradient by the deterministic reduce.  Cin = 16 runs as two 8-channel slices.
+#pragma once
+#include "wgrad_tiled_kernel.h"
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void twgradz_kernel(TWgradArgs a) {
+  constexpr int CIN = 8, COUT = 8;
+  using TL = WTile<MODE>;
+  constexpr int TX = TL::TX, TY = TL::TY, NTY = TL::NTY, NT = TL::NT;
+  constexpr int NT4 = 4 * NTY * 3;                              // tap rows incl. the 4th z plane
+  constexpr int PX = TX + 2, PY = TY + (NTY == 3 ? 2 : 0), PS = PX * PY;
+  constexpr int NA = NT4 / 2;                                  // two taps (8 ci each) per 16-row tile
+  constexpr int XQ = CIN / 4, DQ = COUT / 4;
+  constexpr int NSX = (XQ * PS + 255) / 256, NSD = (DQ * TX * TY + 255) / 256;
+  constexpr int XPLANE = PS * CIN, DPLANE = TX * TY * COUT;
+  extern __shared__ __attribute__((aligned(16))) float wldz[];  // [6][XPLANE] then [4][DPLANE]
+  float* xr = wldz;
+  float* dr = wldz + 6 * XPLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 15, kl = lane >> 4;
+  int bid = blockIdx.x;
+  const int xt = bid % a.ntx; bid /= a.ntx;
+  const int yt = bid % a.nty; bid /= a.nty;
+  const int zs = bid % a.nzseg;
+  const int n = bid / a.nzseg;
+  const int x0 = xt * TX, y0 = yt * TY;
+  const int z0 = zs * a.zseg;
+  const int z1 = (z0 + a.zseg < a.Z) ? z0 + a.zseg : a.Z;
+
+  int a_off[NA], a_tz[NA];
+#pragma unroll
+  for (int m = 0; m < NA; ++m) {
+    int tap = 2 * m + (il >> 3), ci = il & 7;
+    a_tz[m] = tap / (NTY * 3);
+    a_off[m] = (((tap / 3) % NTY) * PX + (tap % 3)) * CIN + ci;
+  }
+  const int wrow = (MODE == 3) ? 2 * wave : 0;
+  const int wcol = (MODE == 3) ? 0 : 64 * wave;
+  const int a_lane = ((wrow * PX) + wcol + kl) * CIN;
+  const int b_lane = ((wrow * TX) + wcol + kl) * COUT + (il & 7);
+  const bool hi = il >= 8;
+
+  wg_f32x4 acc[NA];
+#pragma unroll
+  for (int m = 0; m < NA; ++m) acc[m] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto xslot = [](int p) { return (p + 6) % 6; };
+  auto load_x = [&](int zin, wg_f32x4 (&sx)[NSX]) {
+#pragma unroll
+    for (int i = 0; i < NSX; ++i) {
+      int idx = tid + i * 256;
+      wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < XQ * PS) {
+        int s = idx / XQ, q = idx - s * XQ;
+        int yy = s / PX, xx = s - yy * PX;
+        int py = y0 + yy - (NTY == 3 ? 1 : 0), px = x0 + xx - 1;
+        if (zin >= 0 && zin < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
+          v = *(const wg_f32x4*)(a.x + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.x_cs + 4 * q);
+      }
+      sx[i] = v;
+    }
+  };
+  auto store_x = [&](int zin, const wg_f32x4 (&sx)[NSX]) {
+#pragma unroll
+    for (int i = 0; i < NSX; ++i) {
+      int idx = tid + i * 256;
+      if (idx < XQ * PS) *(wg_f32x4*)(xr + (size_t)xslot(zin) * XPLANE + idx * 4) = sx[i];
+    }
+  };
+  auto load_d = [&](int zin, wg_f32x4 (&sd)[NSD]) {
+#pragma unroll
+    for (int i = 0; i < NSD; ++i) {
+      int idx = tid + i * 256;
+      wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < DQ * TX * TY) {
+        int s = idx / DQ, q = idx - s * DQ;
+        int yy = s / TX, xx = s - yy * TX;
+        int py = y0 + yy, px = x0 + xx;
+        if (zin < z1 && py < a.Y && px < a.X)
+          v = *(const wg_f32x4*)(a.dz + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.dz_cs + 4 * q);
+      }
+      sd[i] = v;
+    }
+  };
+  auto store_d = [&](int zin, const wg_f32x4 (&sd)[NSD]) {
+#pragma unroll
+    for (int i = 0; i < NSD; ++i) {
+      int idx = tid + i * 256;
+      if (idx < DQ * TX * TY) *(wg_f32x4*)(dr + (size_t)(zin & 3) * DPLANE + idx * 4) = sd[i];
+    }
+  };
+
+  wg_f32x4 sxa[NSX], sxb[NSX], sda[NSD], sdb[NSD];
+  for (int p = -1; p <= 2; ++p) {
+    load_x(z0 + p, sxa);
+    store_x(z0 + p, sxa);
+  }
+  for (int p = 0; p <= 1; ++p) {
+    load_d(z0 + p, sda);
+    store_d(z0 + p, sda);
+  }
+  __syncthreads();
+
+  for (int z = z0; z < z1; z += 2) {
+    load_x(z + 3, sxa);
+    load_x(z + 4, sxb);
+    load_d(z + 2, sda);
+    load_d(z + 3, sdb);
+    int abase[NA];
+#pragma unroll
+    for (int m = 0; m < NA; ++m) abase[m] = xslot(z - 1 + a_tz[m]) * XPLANE + a_lane + a_off[m];
+    const float* dcur = dr + (size_t)((hi ? z + 1 : z) & 3) * DPLANE + b_lane;
+    wg_static_for<16>([&](auto G) {
+      constexpr int g = decltype(G)::value;
+      constexpr int grow = (MODE == 3) ? g / 8 : 0;
+      constexpr int gcol = (MODE == 3) ? (g % 8) * 4 : g * 4;
+      const float b = dcur[(grow * TX + gcol) * COUT];
+#pragma unroll
+      for (int m = 0; m < NA; ++m) {
+        float av = xr[abase[m] + (grow * PX + gcol) * CIN];
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[m], 0, 0, 0);
+      }
+    });
+    store_x(z + 3, sxa);
+    store_x(z + 4, sxb);
+    store_d(z + 2, sda);
+    store_d(z + 3, sdb);
+    __syncthreads();
+  }
+
+  // two slabs per wave: [0] columns 0..7 (plane z, tap tz4), [1] columns 8..15 (plane z+1, tap tz4-1)
+  float* slab = a.slab + (((size_t)blockIdx.x * 4 + wave) * 2 + (hi ? 1 : 0)) * (size_t)(NT * CIN * COUT);
+#pragma unroll
+  for (int m = 0; m < NA; ++m) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = 4 * kl + r;
+      int tap4 = 2 * m + (row >> 3), ci = row & 7;
+      int tz4 = tap4 / (NTY * 3), rest = tap4 - tz4 * (NTY * 3);
+      int tz = hi ? tz4 - 1 : tz4;
+      if (tz >= 0 && tz <= 2) slab[((size_t)(tz * (NTY * 3) + rest) * CIN + ci) * COUT + (il & 7)] = acc[m][r];
+    }
+  }
+}
+
+template <int MODE>
+static int launch_twz(const TWPlan& p, const TWgradArgs& a, hipStream_t s) {
+  auto kern = twgradz_kernel<MODE>;
+  static size_t attr_lds = 48 * 1024;
+  if (p.lds > attr_lds) {
+    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    attr_lds = p.lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds, s, a);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+int twgradz_dispatch(const TWPlan& p, const TWgradArgs& a, hipStream_t s);
