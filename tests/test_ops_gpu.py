@@ -404,3 +404,39 @@ def test_tiled_stride2_conv_data_gradient(case):
     assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
     base = torch.ones(x.shape, dtype=torch.float32, device="cuda")
     assert rel_err(conv_backward_data(d, dyg, wg, x.shape, accumulate=1, dx_init=base).cpu().numpy(), dx + 1.0) < TOL
+
+
+IGEMM_CASES = [
+    (3, 2, (8, 8, 32), 32, 32), (3, 1, (9, 11, 21), 64, 32), (3, 2, (6, 6, 12), 128, 64), (3, 1, (4, 12, 16), 16, 48),
+    (2, 2, (32, 48), 32, 64), (2, 1, (19, 37), 64, 128), (2, 1, (16, 16), 256, 32),
+]
+
+
+@pytest.mark.parametrize("case", IGEMM_CASES)
+def test_igemm_conv_fwd_dgrad_stats(case):
+    """LDS-staged implicit-GEMM conv (algo=4): forward + fused BN statistics, data gradient, accumulate."""
+    ndim, N, S, ci, co = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (3,) * ndim + (ci, co)) * 0.1
+    y = O.conv_fwd(x, w, 1)
+    dy = _rand(rng, y.shape)
+    dx, _ = O.conv_bwd(x, w, 1, dy)
+    d = desc(ndim, N, S, ci, co, 3, 1, algo=4)
+    xg, wg, dyg = dev(x), dev(w), dev(dy)
+    lib = _lib.load()
+    yg = torch.full(y.shape, float("nan"), dtype=torch.float32, device="cuda")
+    mg, rg = torch.empty(co, device="cuda"), torch.empty(co, device="cuda")
+    nb = 1 << 24
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.ursn_conv_forward_stats(ctypes.byref(d), P(xg), P(wg), P(yg), P(mg), P(rg), 1e-3, P(scratch), nb,
+                                           stream()))
+    torch.cuda.synchronize()
+    assert rel_err(yg.cpu().numpy(), y) < TOL
+    ax = tuple(range(y.ndim - 1))
+    assert np.abs(mg.cpu().numpy() - y.mean(axis=ax)).max() < 1e-5 * np.sqrt(y.var(axis=ax).max())
+    assert rel_err(rg.cpu().numpy(), 1 / np.sqrt(y.var(axis=ax) + 1e-3)) < 1e-5
+    assert rel_err(conv_forward(d, xg, wg, y.shape).cpu().numpy(), y) < TOL
+    assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
+    base = torch.ones(x.shape, dtype=torch.float32, device="cuda")
+    assert rel_err(conv_backward_data(d, dyg, wg, x.shape, accumulate=1, dx_init=base).cpu().numpy(), dx + 1.0) < TOL

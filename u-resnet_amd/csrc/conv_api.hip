@@ -232,6 +232,12 @@ int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const
     URSN_REQUIRE(tiled_conv_supported(d, pass), "tiled conv kernel does not support this shape");
     return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
   }
+  if (d.algo == 4) {
+    URSN_REQUIRE(igemm_conv_supported(d, pass), "igemm conv kernel does not support this shape");
+    return launch_igemm_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
+  }
+  if (d.algo == 0 && igemm_conv_supported(d, pass))
+    return launch_igemm_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
   if (d.algo == 0 && tiled_conv_supported(d, pass)) return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
   if (d.algo == 0 && tiled_deconv_supported(d, pass))
     return launch_tiled_deconv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
@@ -255,6 +261,11 @@ extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, 
   for (int j = 0; j < 3; ++j) V *= g[0].out_d[j];
   if (d->transposed) { V = (int64_t)d->n; for (int j = 0; j < d->ndim; ++j) V *= 2 * d->in_sp[j]; }
   const int ocs = d->out_cstride > 0 ? d->out_cstride : d->cout;
+  if ((d->algo == 0 || d->algo == 4) && igemm_conv_supported(*d, PASS_FWD)) {
+    URSN_REQUIRE(igemm_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
+                 "conv_forward_stats: scratch too small");
+    return launch_igemm_conv(*d, PASS_FWD, x, w, y, 0, (double*)scratch, eps, mean, rstd, s);
+  }
   if ((d->algo == 0 || d->algo == 3) && tiled_deconv_supported(*d, PASS_FWD)) {
     URSN_REQUIRE(tiled_deconv_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
                  "conv_forward_stats: scratch too small");

@@ -1,0 +1,99 @@
+// Host side + instantiations of the LDS-staged implicit-GEMM convolution (conv_igemm_kernel.h).
+#include <stdlib.h>
+
+#include "conv_igemm_kernel.h"
+
+static int igemm_mode() {  // URSN_IGEMM: 0 = off, 1 = on (default)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("URSN_IGEMM"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
+static bool make_igplan(const ursn_conv_desc& d, ConvPass pass, IGPlan& p, int& kcin, int& kcout) {
+  {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("URSN_DISABLE_TILED"); off = (e && e[0] == '1') ? 1 : 0; }
+    if ((off || igemm_mode() == 0) && d.algo != 4) return false;
+  }
+  if (d.transposed || d.k != 3 || d.stride != 1) return false;
+  if (pass != PASS_FWD && pass != PASS_DGRAD) return false;
+  p.flip = (pass == PASS_DGRAD);
+  kcin = p.flip ? d.cout : d.cin;
+  kcout = p.flip ? d.cin : d.cout;
+  if ((kcin % 16) || (kcout % 16)) return false;
+  if (kcin <= 16 && kcout <= 16 && d.algo != 4) return false;   // register-resident weights win there
+  const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+  if ((ics & 3) || (ocs & 3)) return false;
+  p.mode = d.ndim;
+  if (d.ndim == 3) { p.Z = d.in_sp[0]; p.Y = d.in_sp[1]; p.X = d.in_sp[2]; }
+  else { p.Z = 1; p.Y = d.in_sp[0]; p.X = d.in_sp[1]; }
+  if (p.X < 12 && d.algo != 4) return false;  // 16-wide x tiles: below that the gather kernel wastes less
+  const int BZ = p.mode == 3 ? 4 : 1, BY = p.mode == 3 ? 4 : 16, BX = 16;
+  p.nbz = (p.Z + BZ - 1) / BZ;
+  p.nby = (p.Y + BY - 1) / BY;
+  p.nbx = (p.X + BX - 1) / BX;
+  p.gridx = d.n * p.nbz * p.nby * p.nbx;
+  // wide cout tiles reuse the staged input more, narrow ones give the small deep levels enough workgroups
+  if (kcout >= 64 && p.gridx >= 512) p.bm = 64;
+  else if (kcout >= 32 && (int64_t)p.gridx * (kcout / 32) >= 384) p.bm = 32;
+  else p.bm = 16;
+  p.gridy = (kcout + p.bm - 1) / p.bm;
+  const int HZ = p.mode == 3 ? 6 : 1, HY = BY + 2, HX = BX + 2;
+  p.lds = ((size_t)4 * HZ * HY * HX * 4 + (size_t)2 * 16 * (p.bm + 16)) * sizeof(float);
+  return true;
+}
+
+int igemm_conv_supported(const ursn_conv_desc& d, ConvPass pass) {
+  IGPlan p;
+  int a, b;
+  return make_igplan(d, pass, p, a, b) ? 1 : 0;
+}
+
+size_t igemm_stats_scratch_doubles(const ursn_conv_desc& d) {
+  IGPlan p;
+  int a, b;
+  if (!make_igplan(d, PASS_FWD, p, a, b)) return 0;
+  return (size_t)p.gridx * p.gridy * 2 * p.bm;
+}
+
+template <int MODE, int BM>
+static int dispatch_flags(const IGPlan& p, const IGemmArgs& a, hipStream_t s) {
+  if (p.flip) return launch_ig<MODE, BM, true, false>(p, a, s);
+  if (a.stats_partial) return launch_ig<MODE, BM, false, true>(p, a, s);
+  return launch_ig<MODE, BM, false, false>(p, a, s);
+}
+
+template <int MODE>
+static int dispatch_bm(const IGPlan& p, const IGemmArgs& a, hipStream_t s) {
+  if (p.bm == 64) { ursn_note_kernel(p.flip ? "igemm_dgrad<64>" : "igemm<64>"); return dispatch_flags<MODE, 64>(p, a, s); }
+  if (p.bm == 32) { ursn_note_kernel(p.flip ? "igemm_dgrad<32>" : "igemm<32>"); return dispatch_flags<MODE, 32>(p, a, s); }
+  ursn_note_kernel(p.flip ? "igemm_dgrad<16>" : "igemm<16>");
+  return dispatch_flags<MODE, 16>(p, a, s);
+}
+
+int launch_igemm_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
+                      int accumulate, double* stats_partial, float eps, float* mean, float* rstd, hipStream_t s) {
+  IGPlan p;
+  int kcin, kcout;
+  URSN_REQUIRE(make_igplan(d, pass, p, kcin, kcout), "igemm conv: unsupported shape");
+  const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+  IGemmArgs a;
+  a.in = in; a.w = w; a.out = out; a.stats_partial = stats_partial;
+  a.N = d.n; a.Z = p.Z; a.Y = p.Y; a.X = p.X;
+  a.cin = kcin; a.cout = kcout;
+  a.in_cs = p.flip ? ocs : ics;
+  a.out_cs = p.flip ? ics : ocs;
+  a.cin_w = d.cin; a.cout_w = d.cout;
+  a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx;
+  a.accumulate = accumulate;
+  URSN_TRY(p.mode == 3 ? dispatch_bm<3>(p, a, s) : dispatch_bm<2>(p, a, s));
+  if (stats_partial) {
+    const int64_t V = (int64_t)d.n * p.Z * p.Y * p.X;
+    for (int ct = 0; ct < p.gridy; ++ct) {
+      int cb = kcout - ct * p.bm < p.bm ? kcout - ct * p.bm : p.bm;
+      URSN_TRY(launch_bn_stats_final(stats_partial + (size_t)ct * p.gridx * 2 * p.bm, p.gridx, cb, p.bm, V, eps,
+                                     mean + ct * p.bm, rstd + ct * p.bm, s));
+    }
+  }
+  return 0;
+}

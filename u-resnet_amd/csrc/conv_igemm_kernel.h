@@ -1,0 +1,209 @@
+// LDS-staged implicit-GEMM convolution (k3, stride 1) for the mid/deep levels: Cin, Cout multiples of 16,
+// too many channels for the register-resident weights of conv_tiled_kernel.h -- gfx950.
+//
+// Workgroup = 4 waves, output box of 256 voxels (3-D: 4z x 4y x 16x, one z-slab per wave; 2-D: 16y x 16x,
+// four rows per wave) x BM output channels.  K loop: Cin in chunks of 16; per chunk the input box + halo is
+// staged ONCE into LDS as [ci/4][slot] float4 and reused by all 27 (9) taps (the gather kernel re-fetches it per
+// tap through L1); per tap the 16 x BM weight slab goes through a double-buffered LDS tile shared by the 4 waves.
+// v_mfma_f32_16x16x4_f32: A = W[ci][co] (row stride BM+16 floats -> conflict-free ds_read_b32), B = x[ci][voxel]
+// (16 x-adjacent voxels -> 64 consecutive floats), D[co][voxel]: each lane ends with 4 consecutive channels of
+// one voxel (16-byte stores).  Per tap and wave: 8 LDS operand reads feed 16*BM/64 MFMAs.
+// FLIP evaluates the data gradient (taps mirrored, weight matrix transposed while staging).
+#pragma once
+#include <utility>
+
+#include "ursn_common.h"
+
+typedef float ig_f32x4 __attribute__((ext_vector_type(4)));
+
+struct IGemmArgs {
+  const float* in;
+  const float* w;
+  float* out;
+  double* stats_partial;  // [grid.y][grid.x][2][BM], or null
+  int N, Z, Y, X;         // 2-D: Z = 1
+  int cin, cout;          // kernel view (contraction / produced)
+  int in_cs, out_cs;
+  int cin_w, cout_w;      // stored weight dims [t][cin_w][cout_w]
+  int nbz, nby, nbx;
+  int accumulate;
+};
+
+template <int MODE> struct IBox;
+template <> struct IBox<3> { static constexpr int BZ = 4, BY = 4, BX = 16, NT = 27, KZ = 3; };
+template <> struct IBox<2> { static constexpr int BZ = 1, BY = 16, BX = 16, NT = 9, KZ = 1; };
+
+template <int MODE, int BM, bool FLIP, bool STATS>
+__global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IGemmArgs a) {
+  using B = IBox<MODE>;
+  constexpr int BZ = B::BZ, BY = B::BY, BX = B::BX, NT = B::NT, KZ = B::KZ;
+  constexpr int HZ = BZ + (KZ - 1), HY = BY + 2, HX = BX + 2, PS = HZ * HY * HX;   // halo box slots
+  constexpr int KC = 16, WS = BM + 16;                                              // ci chunk, weight row stride
+  constexpr int MT = BM / 16;
+  constexpr int NH = (4 * PS + 255) / 256;                                          // halo float4 per thread
+  extern __shared__ __attribute__((aligned(16))) float ilds[];  // [4][PS][4] halo, then [2][KC][WS] weights
+  float* hal = ilds;
+  float* wl = ilds + 4 * PS * 4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 15, kl = lane >> 4;
+  int bid = blockIdx.x;
+  const int bx = bid % a.nbx; bid /= a.nbx;
+  const int by = bid % a.nby; bid /= a.nby;
+  const int bz = bid % a.nbz;
+  const int n = bid / a.nbz;
+  const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
+  const int co0 = blockIdx.y * BM;
+
+  // this wave's 4 voxel tiles (16 x each): 3-D: z = wave, y = 0..3; 2-D: y = 4*wave + 0..3
+  ig_f32x4 acc[4][MT];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[v][m] = (ig_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // weight staging: one float4 of the [KC][BM] slab per thread (threads beyond KC*BM/4 idle)
+  auto load_w = [&](int t, int ci0) -> ig_f32x4 {
+    ig_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (tid < KC * BM / 4) {
+      if (!FLIP) {
+        int k = tid / (BM / 4), c4 = (tid % (BM / 4)) * 4;
+        if (co0 + c4 < a.cout) v = *(const ig_f32x4*)(a.w + ((size_t)t * a.cin_w + ci0 + k) * a.cout_w + co0 + c4);
+      } else {
+        int nn = tid / (KC / 4), k4 = (tid % (KC / 4)) * 4;   // produced channel nn, contraction k4..k4+3
+        if (co0 + nn < a.cout) v = *(const ig_f32x4*)(a.w + ((size_t)(NT - 1 - t) * a.cin_w + co0 + nn) * a.cout_w + ci0 + k4);
+      }
+    }
+    return v;
+  };
+  auto store_w = [&](int buf, ig_f32x4 v) {
+    if (tid < KC * BM / 4) {
+      float* dst = wl + (size_t)buf * KC * WS;
+      if (!FLIP) {
+        int k = tid / (BM / 4), c4 = (tid % (BM / 4)) * 4;
+        *(ig_f32x4*)(dst + k * WS + c4) = v;
+      } else {
+        int nn = tid / (KC / 4), k4 = (tid % (KC / 4)) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[(k4 + j) * WS + nn] = v[j];
+      }
+    }
+  };
+
+  const int nchunks = a.cin / KC;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int ci0 = ch * KC;
+    __syncthreads();  // previous chunk's MFMAs are done with the halo / weight tiles
+    // ---- input box + halo for 16 channels -> LDS [q][slot] float4 ----
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      int idx = tid + i * 256;
+      if (idx < 4 * PS) {
+        int s = idx >> 2, q = idx & 3;   // consecutive threads: the 4 quads of one voxel (64 contiguous bytes)
+        int hx = s % HX, r = s / HX;
+        int hy = r % HY, hz = r / HY;
+        int pz = z0 + hz - (KZ == 3 ? 1 : 0), py = y0 + hy - 1, px = x0 + hx - 1;
+        ig_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pz >= 0 && pz < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
+          v = *(const ig_f32x4*)(a.in + ((((size_t)n * a.Z + pz) * a.Y + py) * a.X + px) * a.in_cs + ci0 + 4 * q);
+        *(ig_f32x4*)(hal + ((size_t)q * PS + s) * 4) = v;
+      }
+    }
+    ig_f32x4 wv = load_w(0, ci0);
+    store_w(0, wv);
+    __syncthreads();
+
+    for (int t = 0; t < NT; ++t) {
+      const int buf = t & 1;
+      if (t + 1 < NT) wv = load_w(t + 1, ci0);
+      const int tz = (KZ == 3) ? t / 9 : 0, ty = (t / 3) % 3, tx = t % 3;
+      const float* wb = wl + (size_t)buf * KC * WS;
+      // halo slot of this lane's voxel for tile v: 3-D (z = wave, y = v), 2-D (y = 4*wave + v)
+      const int zz = (MODE == 3) ? wave + tz : 0;
+      const int yb = (MODE == 3) ? ty : 4 * wave + ty;
+      const float* hb = hal + ((size_t)(zz * HY + yb) * HX + il + tx) * 4 + kl;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float bv[4], av[MT];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) bv[v] = hb[((size_t)s * PS + v * HX) * 4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = wb[(4 * s + kl) * WS + m * 16 + il];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[v][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[v], acc[v][m], 0, 0, 0);
+      }
+      if (t + 1 < NT) store_w(buf ^ 1, wv);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: lane (il = x, kl) holds channels co0 + 16m + 4kl + r of voxel (z, y, x0 + il) ----
+  float s1[MT][4], s2[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
+  const int gx = x0 + il;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int gz = (MODE == 3) ? z0 + wave : 0;
+    const int gy = (MODE == 3) ? y0 + v : y0 + 4 * wave + v;
+    const bool ok = gz < a.Z && gy < a.Y && gx < a.X;
+    if (!ok) continue;
+    float* op = a.out + ((((size_t)n * a.Z + gz) * a.Y + gy) * a.X + gx) * a.out_cs + co0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      int c = 16 * m + 4 * kl;
+      if (co0 + c >= a.cout) continue;
+      ig_f32x4 val = acc[v][m];
+      if (a.accumulate) val += *(ig_f32x4*)(op + c);
+      *(ig_f32x4*)(op + c) = val;
+      if constexpr (STATS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[m][r] += val[r]; s2[m][r] += val[r] * val[r]; }
+      }
+    }
+  }
+  if constexpr (STATS) if (a.stats_partial) {
+    __shared__ float red[4][2 * BM];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float u = s1[m][r], w2 = s2[m][r];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
+        if (il == 0) {
+          red[wave][16 * m + 4 * kl + r] = u;
+          red[wave][BM + 16 * m + 4 * kl + r] = w2;
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * BM)
+      a.stats_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * BM + tid] =
+          (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
+  }
+}
+
+struct IGPlan {
+  int mode, bm;
+  bool flip;
+  int Z, Y, X, nbz, nby, nbx;
+  size_t lds;
+  int gridx, gridy;
+};
+
+template <int MODE, int BM, bool FLIP, bool STATS>
+static int launch_ig(const IGPlan& p, const IGemmArgs& a, hipStream_t s) {
+  auto kern = igemm_conv_kernel<MODE, BM, FLIP, STATS>;
+  static size_t attr_lds = 48 * 1024;
+  if (p.lds > attr_lds) {
+    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    attr_lds = p.lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.gridx, p.gridy), dim3(256), p.lds, s, a);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}

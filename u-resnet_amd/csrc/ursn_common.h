@@ -106,6 +106,11 @@ int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass);
 size_t tiled_conv_stats_scratch_doubles(const ursn_conv_desc& d);
 int launch_tiled_conv_bn(const ursn_conv_desc& d, const float* in, const float* w, float* out, double* scratch,
                          float eps, float* mean, float* rstd, hipStream_t s);
+// LDS-staged implicit GEMM for k3 s1 layers with >= 32 channels (conv_igemm.hip)
+int igemm_conv_supported(const ursn_conv_desc& d, ConvPass pass);
+size_t igemm_stats_scratch_doubles(const ursn_conv_desc& d);
+int launch_igemm_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
+                      int accumulate, double* stats_partial, float eps, float* mean, float* rstd, hipStream_t s);
 // tiled stride-2 scatter-type conv (deconv_tiled.hip): transposed-conv forward / stride-2 conv data gradient
 int tiled_deconv_supported(const ursn_conv_desc& d, ConvPass pass);
 size_t tiled_deconv_stats_scratch_doubles(const ursn_conv_desc& d);
