@@ -421,7 +421,7 @@ def test_igemm_conv_fwd_dgrad_stats(case):
     w = _rand(rng, (3,) * ndim + (ci, co)) * 0.1
     y = O.conv_fwd(x, w, 1)
     dy = _rand(rng, y.shape)
-    dx, _ = O.conv_bwd(x, w, 1, dy)
+    dx, dw = O.conv_bwd(x, w, 1, dy)
     d = desc(ndim, N, S, ci, co, 3, 1, algo=4)
     xg, wg, dyg = dev(x), dev(w), dev(dy)
     lib = _lib.load()
@@ -440,3 +440,6 @@ def test_igemm_conv_fwd_dgrad_stats(case):
     assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
     base = torch.ones(x.shape, dtype=torch.float32, device="cuda")
     assert rel_err(conv_backward_data(d, dyg, wg, x.shape, accumulate=1, dx_init=base).cpu().numpy(), dx + 1.0) < TOL
+    dwg = conv_backward_weight(d, xg, dyg, w.shape)
+    assert rel_err(dwg.cpu().numpy(), dw) < 5e-5
+    assert rel_err(conv_backward_weight(d, xg, dyg, w.shape, dw_init=dwg).cpu().numpy(), 2 * dw) < 5e-5

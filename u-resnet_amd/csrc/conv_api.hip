@@ -298,11 +298,17 @@ extern "C" size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d) {
   if (build_geoms(*d, PASS_WGRAD, g) != 1) return 0;
   size_t a = wgrad_plan(g[0]).scratch_bytes;
   size_t b = tiled_wgrad_supported(*d) ? tiled_wgrad_scratch_bytes(*d) : 0;
-  return (a > b ? a : b) + 256;
+  size_t c = igemm_wgrad_scratch_bytes(*d);
+  if (b > a) a = b;
+  if (c > a) a = c;
+  return a + 256;
 }
 
 int wgrad_dispatch(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
                    size_t scratch_bytes, hipStream_t s) {
+  if ((d.algo == 0 || d.algo == 4) && igemm_wgrad_supported(d))
+    return launch_igemm_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
+  URSN_REQUIRE(d.algo != 4, "igemm wgrad kernel does not support this shape");
   if ((d.algo == 0 || d.algo == 3) && tiled_wgrad_supported(d))
     return launch_tiled_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
   URSN_REQUIRE(d.algo != 3, "tiled wgrad kernel does not support this shape");

@@ -1,0 +1,258 @@
+// LDS-staged weight gradient for k3 s1 layers with >= 32 channels (mid/deep levels, most of the 2-D net).
+//
+//   dW[t][ci][co] = sum_v x[v + t - 1][ci] * dz[v][co]       GEMM: M = ci, N = co, K = voxels
+//
+// A workgroup owns a (16 ci) x (16*MT co) block of dW and a group of 256-voxel boxes.  Per box the input box +
+// halo (16 channels) and the dz box (16*MT channels) are staged once into LDS as [channel quad][slot] float4
+// (plane stride padded to 2 mod 8 slots -> the 16-channel x 2-voxel operand reads of v_mfma_f32_16x16x4_f32
+// hit 32 distinct banks).  The 27 (9) taps are split over the 4 waves (7+7+7+6), every wave sweeps all 64
+// voxel quads of the box for its taps: per quad MT reads of dz feed 7*MT MFMAs, and no cross-wave reduction
+// is needed.  One slab per workgroup; a single reduce kernel sums the box groups and ADDS into the gradient.
+#include <stdlib.h>
+#include <utility>
+
+#include "ursn_common.h"
+
+typedef float iw_f32x4 __attribute__((ext_vector_type(4)));
+
+struct IGWArgs {
+  const float* x;
+  const float* dz;
+  float* slab;  // [grid.z][grid.y][grid.x][taps][16][BN]
+  int N, Z, Y, X;
+  int x_cs, dz_cs;
+  int nbz, nby, nbx, nboxes, boxes_per_group;
+};
+
+template <int MODE> struct WBox;
+template <> struct WBox<3> { static constexpr int BZ = 4, BY = 4, BX = 16, NT = 27, KZ = 3; };
+template <> struct WBox<2> { static constexpr int BZ = 1, BY = 16, BX = 16, NT = 9, KZ = 1; };
+
+template <int MODE, int MT>
+__global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(IGWArgs a) {
+  using B = WBox<MODE>;
+  constexpr int BZ = B::BZ, BY = B::BY, BX = B::BX, NT = B::NT, KZ = B::KZ;
+  constexpr int HZ = BZ + (KZ - 1), HY = BY + 2, HX = BX + 2, PS = HZ * HY * HX;
+  constexpr int PSP = PS + ((2 - PS % 8) + 8) % 8;          // plane stride == 2 (mod 8) slots
+  constexpr int DS = BZ * BY * BX, DSP = DS + 2;            // 256 voxels, padded likewise
+  constexpr int BN = 16 * MT;
+  constexpr int TPW = (NT + 3) / 4;
+  constexpr int NHX = (4 * PS + 255) / 256, NHD = (BN / 4 * DS + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float iwl[];  // [4][PSP][4] x, then [BN/4][DSP][4] dz
+  float* xl = iwl;
+  float* dl = iwl + 4 * PSP * 4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 15, kl = lane >> 4;
+  const int ci0 = blockIdx.y * 16, co0 = blockIdx.z * BN;
+
+  iw_f32x4 acc[TPW][MT];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[i][m] = (iw_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // this wave's taps: halo-slot offset of the tap shift
+  int t_off[TPW];
+  bool t_ok[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    int t = wave * TPW + i;
+    t_ok[i] = t < NT;
+    if (!t_ok[i]) t = 0;
+    int tz = (KZ == 3) ? t / 9 : 0, ty = (t / 3) % 3, tx = t % 3;
+    t_off[i] = (tz * HY + ty) * HX + tx;
+  }
+  const int a_lane = ((il >> 2) * PSP + kl) * 4 + (il & 3);   // + (halo slot of quad start + tap offset)*4
+  const int b_lane = ((il >> 2) * DSP + kl) * 4 + (il & 3);   // + (m*4*DSP + voxel slot of quad start)*4
+
+  const int box_begin = blockIdx.x * a.boxes_per_group;
+  int box_end = box_begin + a.boxes_per_group;
+  if (box_end > a.nboxes) box_end = a.nboxes;
+  for (int box = box_begin; box < box_end; ++box) {
+    int bid = box;
+    const int bx = bid % a.nbx; bid /= a.nbx;
+    const int by = bid % a.nby; bid /= a.nby;
+    const int bz = bid % a.nbz;
+    const int n = bid / a.nbz;
+    const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NHX; ++i) {
+      int idx = tid + i * 256;
+      if (idx < 4 * PS) {
+        int s = idx >> 2, q = idx & 3;
+        int hx = s % HX, r = s / HX;
+        int hy = r % HY, hz = r / HY;
+        int pz = z0 + hz - (KZ == 3 ? 1 : 0), py = y0 + hy - 1, px = x0 + hx - 1;
+        iw_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pz >= 0 && pz < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
+          v = *(const iw_f32x4*)(a.x + ((((size_t)n * a.Z + pz) * a.Y + py) * a.X + px) * a.x_cs + ci0 + 4 * q);
+        *(iw_f32x4*)(xl + ((size_t)q * PSP + s) * 4) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NHD; ++i) {
+      int idx = tid + i * 256;
+      if (idx < BN / 4 * DS) {
+        int s = idx / (BN / 4), q = idx % (BN / 4);
+        int vx = s % BX, r = s / BX;
+        int vy = r % BY, vz = r / BY;
+        int pz = z0 + vz, py = y0 + vy, px = x0 + vx;
+        iw_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (pz < a.Z && py < a.Y && px < a.X)
+          v = *(const iw_f32x4*)(a.dz + ((((size_t)n * a.Z + pz) * a.Y + py) * a.X + px) * a.dz_cs + co0 + 4 * q);
+        *(iw_f32x4*)(dl + ((size_t)q * DSP + s) * 4) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int ks = 0; ks < 64; ++ks) {          // voxel quads: row = ks >> 2 (z*BY + y), x = 4*(ks & 3)
+      const int row = ks >> 2, xq = (ks & 3) * 4;
+      const int vz = (MODE == 3) ? row / BY : 0, vy = (MODE == 3) ? row % BY : row;
+      const int hs = (vz * HY + vy) * HX + xq;             // halo slot of the quad's first voxel (tap 0,0,0)
+      const int vs = row * BX + xq;
+      float bv[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) bv[m] = dl[b_lane + ((size_t)m * 4 * DSP + vs) * 4];
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        float av = xl[a_lane + (hs + t_off[i]) * 4];
+        if (!t_ok[i]) av = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[m], acc[i][m], 0, 0, 0);
+      }
+    }
+  }
+
+  // D: row = ci (4*kl + r), col = co (il)
+  float* slab = a.slab + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (size_t)(NT * 16 * BN);
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = wave * TPW + i;
+    if (t >= NT) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[((size_t)t * 16 + 4 * kl + r) * BN + 16 * m + il] = acc[i][m][r];
+  }
+}
+
+// dw[t][ci][co] += sum_g slab[(cz*ncy + cy)*ng + g][t][ci%16][co%BN]
+__global__ __launch_bounds__(256) void igw_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slab, int taps,
+                                                         int cin, int cout, int BN, int ng) {
+  __shared__ float sm[4][64];
+  const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int64_t total = (int64_t)taps * cin * cout;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < total) {
+    int co = (int)(i % cout);
+    int64_t r = i / cout;
+    int ci = (int)(r % cin);
+    int t = (int)(r / cin);
+    int cy = ci / 16, cz = co / BN, ncy = cin / 16;
+    const int64_t per = (int64_t)taps * 16 * BN;
+    const float* base = slab + ((int64_t)(cz * ncy + cy) * ng) * per + ((int64_t)t * 16 + (ci & 15)) * BN + (co % BN);
+    int g = cg;
+    for (; g + 4 < ng; g += 8) {
+      s0 += base[(int64_t)g * per];
+      s1 += base[(int64_t)(g + 4) * per];
+    }
+    for (; g < ng; g += 4) s0 += base[(int64_t)g * per];
+  }
+  sm[cg][e] = s0 + s1;
+  __syncthreads();
+  if (cg == 0 && i < total) dw[i] += (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
+}
+
+struct IGWPlan {
+  int mode, mt, Z, Y, X, nbz, nby, nbx, nboxes, ngroups, bpg;
+  size_t lds, scratch;
+};
+
+static bool make_igwplan(const ursn_conv_desc& d, IGWPlan& p) {
+  {
+    static int off = -1;
+    if (off < 0) {
+      const char* e = getenv("URSN_DISABLE_TILED");
+      const char* f = getenv("URSN_IGEMM");
+      off = ((e && e[0] == '1') || (f && f[0] == '0')) ? 1 : 0;
+    }
+    if (off && d.algo != 4) return false;
+  }
+  if (d.transposed || d.k != 3 || d.stride != 1) return false;
+  if ((d.cin % 16) || (d.cout % 16)) return false;
+  if (d.cin <= 16 && d.cout <= 16 && d.algo != 4) return false;
+  const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+  if ((ics & 3) || (ocs & 3)) return false;
+  p.mode = d.ndim;
+  if (d.ndim == 3) { p.Z = d.in_sp[0]; p.Y = d.in_sp[1]; p.X = d.in_sp[2]; }
+  else { p.Z = 1; p.Y = d.in_sp[0]; p.X = d.in_sp[1]; }
+  if (p.X < 12 && d.algo != 4) return false;
+  const int BZ = p.mode == 3 ? 4 : 1, BY = p.mode == 3 ? 4 : 16, BX = 16;
+  p.nbz = (p.Z + BZ - 1) / BZ;
+  p.nby = (p.Y + BY - 1) / BY;
+  p.nbx = (p.X + BX - 1) / BX;
+  p.nboxes = d.n * p.nbz * p.nby * p.nbx;
+  p.mt = (d.cout % 32 == 0) ? 2 : 1;
+  const int blocks = (d.cin / 16) * (d.cout / (16 * p.mt));
+  int want = 1024 / blocks;
+  if (want < 1) want = 1;
+  if (want > p.nboxes) want = p.nboxes;
+  p.bpg = (p.nboxes + want - 1) / want;
+  p.ngroups = (p.nboxes + p.bpg - 1) / p.bpg;
+  const int taps = p.mode == 3 ? 27 : 9;
+  const int HZ = p.mode == 3 ? 6 : 1, PS = HZ * (BY + 2) * (BX + 2);
+  const int PSP = PS + ((2 - PS % 8) + 8) % 8;
+  p.lds = ((size_t)4 * PSP * 4 + (size_t)(4 * p.mt) * 258 * 4) * sizeof(float);
+  p.scratch = (size_t)blocks * p.ngroups * taps * 16 * (16 * p.mt) * sizeof(float);
+  return p.scratch <= ((size_t)1 << 30);
+}
+
+int igemm_wgrad_supported(const ursn_conv_desc& d) {
+  IGWPlan p;
+  return make_igwplan(d, p) ? 1 : 0;
+}
+size_t igemm_wgrad_scratch_bytes(const ursn_conv_desc& d) {
+  IGWPlan p;
+  return make_igwplan(d, p) ? p.scratch : 0;
+}
+
+template <int MODE, int MT>
+static int launch_igw(const IGWPlan& p, const IGWArgs& a, dim3 grid, hipStream_t s) {
+  auto kern = igemm_wgrad_kernel<MODE, MT>;
+  static size_t attr_lds = 48 * 1024;
+  if (p.lds > attr_lds) {
+    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    attr_lds = p.lds;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), p.lds, s, a);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_igemm_wgrad(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
+                       size_t scratch_bytes, hipStream_t s) {
+  IGWPlan p;
+  URSN_REQUIRE(make_igwplan(d, p), "igemm wgrad: unsupported shape");
+  URSN_REQUIRE(scratch && scratch_bytes >= p.scratch, "igemm wgrad: scratch too small (%zu < %zu)", scratch_bytes, p.scratch);
+  IGWArgs a;
+  a.x = x; a.dz = dy; a.slab = (float*)scratch;
+  a.N = d.n; a.Z = p.Z; a.Y = p.Y; a.X = p.X;
+  a.x_cs = d.in_cstride > 0 ? d.in_cstride : d.cin;
+  a.dz_cs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+  a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx; a.nboxes = p.nboxes; a.boxes_per_group = p.bpg;
+  dim3 grid(p.ngroups, d.cin / 16, d.cout / (16 * p.mt));
+  ursn_note_kernel(p.mt == 2 ? "igemm_wgrad<32>" : "igemm_wgrad<16>");
+  int rc;
+  if (p.mode == 3) rc = (p.mt == 2) ? launch_igw<3, 2>(p, a, grid, s) : launch_igw<3, 1>(p, a, grid, s);
+  else rc = (p.mt == 2) ? launch_igw<2, 2>(p, a, grid, s) : launch_igw<2, 1>(p, a, grid, s);
+  if (rc) return rc;
+  const int taps = p.mode == 3 ? 27 : 9;
+  const int64_t total = (int64_t)taps * d.cin * d.cout;
+  hipLaunchKernelGGL(igw_reduce_kernel, dim3((unsigned)cdiv64(total, 64)), dim3(256), 0, s, dw, (const float*)scratch, taps,
+                     d.cin, d.cout, 16 * p.mt, p.ngroups);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
