@@ -195,20 +195,36 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, int shift) {
       sc2[j] = sh2[j] = 0.f;
     }
   }
-  for (int64_t v = (int64_t)blockIdx.x * VPB + vr; v < a.V; v += (int64_t)gridDim.x * VPB) {
-    typename VT<VEC>::T x = ldv<VEC>(a.z + v * a.zcs + c), y;
-    typename VT<VEC>::T x2, r;
-    if (a.z2) x2 = ldv<VEC>(a.z2 + v * a.z2cs + c);
-    if (a.res) r = ldv<VEC>(a.res + v * a.rescs + c);
+  // 4 voxels per iteration, all loads issued before the first use (the struct pointers may alias, so the
+  // compiler will not hoist them itself): keeps 4x the bytes in flight per wave
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)gridDim.x * VPB;
+  for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += stride * U) {
+    typename VT<VEC>::T x[U], x2[U], r[U];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      float t = fmaf(elem(x, j), sc[j], sh[j]);
-      if (a.z2) t += fmaf(elem(x2, j), sc2[j], sh2[j]);
-      if (a.res) t += elem(r, j);
-      if (a.relu) t = fmaxf(t, 0.f);
-      setelem(y, j, t);
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * stride;
+      if (v < a.V) {
+        x[u] = ldv<VEC>(a.z + v * a.zcs + c);
+        if (a.z2) x2[u] = ldv<VEC>(a.z2 + v * a.z2cs + c);
+        if (a.res) r[u] = ldv<VEC>(a.res + v * a.rescs + c);
+      }
     }
-    stv<VEC>(a.y + v * a.ycs + c, y);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * stride;
+      if (v >= a.V) continue;
+      typename VT<VEC>::T y;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float t = fmaf(elem(x[u], j), sc[j], sh[j]);
+        if (a.z2) t += fmaf(elem(x2[u], j), sc2[j], sh2[j]);
+        if (a.res) t += elem(r[u], j);
+        if (a.relu) t = fmaxf(t, 0.f);
+        setelem(y, j, t);
+      }
+      stv<VEC>(a.y + v * a.ycs + c, y);
+    }
   }
 }
 
@@ -245,22 +261,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int shi
       rs2[j] = a.z2 ? a.rstd2[c + j] : 0.f;
       be[j] = zmask ? a.beta[c + j] - mu[j] * rs[j] : 0.f;   // shift of the forward pass
     }
-    for (int64_t v = (int64_t)blockIdx.x * VPB + vr; v < a.V; v += (int64_t)gridDim.x * VPB) {
-      typename VT<VEC>::T g = ldv<VEC>(a.dy + v * a.dycs + c);
-      typename VT<VEC>::T x = ldv<VEC>(a.z + v * a.zcs + c);
-      typename VT<VEC>::T yv, x2;
-      if (ymask) yv = ldv<VEC>(a.y + v * a.ycs + c);
-      if (a.z2) x2 = ldv<VEC>(a.z2 + v * a.z2cs + c);
+    constexpr int U = 4;
+    const int64_t stride = (int64_t)gridDim.x * VPB;
+    for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += stride * U) {
+      typename VT<VEC>::T gv[U], xv[U], yv[U], x2v[U];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        float gj = elem(g, j);
-        const float xh0 = (elem(x, j) - mu[j]) * rs[j];
-        if (ymask && !(elem(yv, j) > 0.f)) gj = 0.f;
-        if (zmask && !(fmaf(elem(x, j), rs[j], be[j]) > 0.f)) gj = 0.f;   // same expression as bn_act
-        double gd = (double)gj;
-        acc[0][j] += gd;
-        acc[1][j] += gd * (double)xh0;
-        if (a.z2) acc[2][j] += gd * (double)((elem(x2, j) - mu2[j]) * rs2[j]);
+      for (int u = 0; u < U; ++u) {
+        const int64_t v = v0 + u * stride;
+        if (v < a.V) {
+          gv[u] = ldv<VEC>(a.dy + v * a.dycs + c);
+          xv[u] = ldv<VEC>(a.z + v * a.zcs + c);
+          if (ymask) yv[u] = ldv<VEC>(a.y + v * a.ycs + c);
+          if (a.z2) x2v[u] = ldv<VEC>(a.z2 + v * a.z2cs + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (v0 + u * stride >= a.V) continue;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float gj = elem(gv[u], j);
+          const float xh0 = (elem(xv[u], j) - mu[j]) * rs[j];
+          if (ymask && !(elem(yv[u], j) > 0.f)) gj = 0.f;
+          if (zmask && !(fmaf(elem(xv[u], j), rs[j], be[j]) > 0.f)) gj = 0.f;   // same expression as bn_act
+          double gd = (double)gj;
+          acc[0][j] += gd;
+          acc[1][j] += gd * (double)xh0;
+          if (a.z2) acc[2][j] += gd * (double)((elem(x2v[u], j) - mu2[j]) * rs2[j]);
+        }
       }
     }
   }
@@ -302,29 +330,43 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int shif
     mgx[j] = (float)finals[a.C + c + j];
     mgx2[j] = (float)finals[2 * a.C + c + j];
   }
-  for (int64_t v = (int64_t)blockIdx.x * VPB + vr; v < a.V; v += (int64_t)gridDim.x * VPB) {
-    typename VT<VEC>::T g = ldv<VEC>(a.dy + v * a.dycs + c);
-    typename VT<VEC>::T x = ldv<VEC>(a.z + v * a.zcs + c);
-    typename VT<VEC>::T yv, x2, dz, dz2, dr;
-    if (ymask) yv = ldv<VEC>(a.y + v * a.ycs + c);
-    if (a.z2) x2 = ldv<VEC>(a.z2 + v * a.z2cs + c);
-    if (a.dres && a.dres_accumulate) dr = ldv<VEC>(a.dres + v * a.drescs + c);
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)gridDim.x * VPB;
+  for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += stride * U) {
+    typename VT<VEC>::T gv[U], xv[U], yv[U], x2v[U], drv[U];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      float gj = elem(g, j);
-      float xh = (elem(x, j) - mu[j]) * rs[j];
-      if (ymask && !(elem(yv, j) > 0.f)) gj = 0.f;
-      if (zmask && !(fmaf(elem(x, j), rs[j], be[j]) > 0.f)) gj = 0.f;
-      setelem(dz, j, rs[j] * (gj - mg[j] - xh * mgx[j]));
-      if (a.z2) {
-        float xh2 = (elem(x2, j) - mu2[j]) * rs2[j];
-        setelem(dz2, j, rs2[j] * (gj - mg[j] - xh2 * mgx2[j]));
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * stride;
+      if (v < a.V) {
+        gv[u] = ldv<VEC>(a.dy + v * a.dycs + c);
+        xv[u] = ldv<VEC>(a.z + v * a.zcs + c);
+        if (ymask) yv[u] = ldv<VEC>(a.y + v * a.ycs + c);
+        if (a.z2) x2v[u] = ldv<VEC>(a.z2 + v * a.z2cs + c);
+        if (a.dres && a.dres_accumulate) drv[u] = ldv<VEC>(a.dres + v * a.drescs + c);
       }
-      if (a.dres) setelem(dr, j, a.dres_accumulate ? elem(dr, j) + gj : gj);
     }
-    stv<VEC>(a.dz + v * a.dzcs + c, dz);
-    if (a.z2) stv<VEC>(a.dz2 + v * a.dz2cs + c, dz2);
-    if (a.dres) stv<VEC>(a.dres + v * a.drescs + c, dr);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * stride;
+      if (v >= a.V) continue;
+      typename VT<VEC>::T dz, dz2, dr = drv[u];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float gj = elem(gv[u], j);
+        float xh = (elem(xv[u], j) - mu[j]) * rs[j];
+        if (ymask && !(elem(yv[u], j) > 0.f)) gj = 0.f;
+        if (zmask && !(fmaf(elem(xv[u], j), rs[j], be[j]) > 0.f)) gj = 0.f;
+        setelem(dz, j, rs[j] * (gj - mg[j] - xh * mgx[j]));
+        if (a.z2) {
+          float xh2 = (elem(x2v[u], j) - mu2[j]) * rs2[j];
+          setelem(dz2, j, rs2[j] * (gj - mg[j] - xh2 * mgx2[j]));
+        }
+        if (a.dres) setelem(dr, j, a.dres_accumulate ? elem(dr, j) + gj : gj);
+      }
+      stv<VEC>(a.dz + v * a.dzcs + c, dz);
+      if (a.z2) stv<VEC>(a.dz2 + v * a.dz2cs + c, dz2);
+      if (a.dres) stv<VEC>(a.dres + v * a.drescs + c, dr);
+    }
   }
 }
 
