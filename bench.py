@@ -189,12 +189,22 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = batch * world * args.steps / elapsed
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the per-launch figure
+    # comes from the committed rocprofv3 --pmc passes of this same command (profiles/pmc_traffic.json), else null
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f) if args.workload.startswith("cfg3") else {}
+    except Exception:
+        pmc = {}
     roofline = None
     if by_kernel:
         dom_name, dom = max(((k, v) for k, v in by_kernel.items() if v["conv"]), key=lambda kv: kv[1]["ms"])
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+                    "traffic": (round(pmc[dom_name]["hbm_bytes_per_launch"]) if dom_name in pmc else None),
+                    "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                     "kernel_share_of_step": round(dom["ms"] / max(all_ms, 1e-9), 3),
                     # whole-step view: sum over the 58 layers of max(F/P, B/BW) vs measured
