@@ -34,6 +34,11 @@ struct Blocking {
   int nbi = 1, nbo = 1;  // channel blocks of the contraction / produced dims (kernel view); block = 16 when > 1
 };
 
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 static bool spatial_plan(const ursn_conv_desc& d, int& Z, int& Y, int& X, int& ntx, int& nty, int& zseg, int& nzseg,
                          int target_blocks) {
   if (d.ndim == 3) { Z = d.in_sp[0]; Y = d.in_sp[1]; X = d.in_sp[2]; }
@@ -63,7 +68,8 @@ static bool make_plan(const ursn_conv_desc& d, ConvPass pass, TPlan& p, Blocking
   const bool single_in = (d.cin == 1 && ics == 1 && !p.flip);   // conv0: scalar input fetch, kernel view Cin = 4
   if (((ics & 3) && !single_in) || (ocs & 3)) return false;
   if (d.cin == 1 && p.flip) return false;
-  if (!spatial_plan(d, p.Z, p.Y, p.X, p.ntx, p.nty, p.zseg, p.nzseg, 1024)) return false;
+  static const int tb_conv = env_int("URSN_TB_CONV", 2048);
+  if (!spatial_plan(d, p.Z, p.Y, p.X, p.ntx, p.nty, p.zseg, p.nzseg, tb_conv)) return false;
   p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
   b = Blocking();
   if (!tiled_shape_ok(p.cin, p.cout, p.mode)) {
@@ -171,7 +177,8 @@ static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
   p.mode = d.ndim; p.cin = d.cin; p.cout = (d.cout + 3) & ~3;
   const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
   if (((ics & 3) && !(d.cin == 1 && ics == 1)) || (ocs & 3)) return false;
-  if (!spatial_plan(d, p.Z, p.Y, p.X, p.ntx, p.nty, p.zseg, p.nzseg, 512)) return false;
+  static const int tb_wgrad = env_int("URSN_TB_WGRAD", 1024);
+  if (!spatial_plan(d, p.Z, p.Y, p.X, p.ntx, p.nty, p.zseg, p.nzseg, tb_wgrad)) return false;
   p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
   b = Blocking();
   bool c816 = (d.cin == 8 || d.cin == 16) && (p.cout == 8 || p.cout == 16);
@@ -203,8 +210,8 @@ size_t tiled_wgrad_scratch_bytes(const ursn_conv_desc& d) {
   if (!make_wplan(d, p, b)) return 0;
   int taps = d.ndim == 3 ? 27 : 9;
   int ci = (b.nbi > 1 || b.nbo > 1) ? 16 : d.cin, co = (b.nbi > 1 || b.nbo > 1) ? 16 : d.cout;
-  if (use_wgradz(d)) return (size_t)p.grid * 8 * taps * 8 * 8 * sizeof(float);   // two slabs per wave
-  return (size_t)p.grid * 4 * taps * ci * co * sizeof(float);   // the 4x4x1 form needs a quarter of it
+  if (use_wgradz(d)) return (size_t)p.grid * 2 * taps * 8 * 8 * sizeof(float);   // two slabs per workgroup
+  return (size_t)p.grid * taps * ci * co * sizeof(float);   // one slab per workgroup
 }
 
 int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
@@ -229,9 +236,9 @@ int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy,
     for (int bi = 0; bi < d.cin / 8; ++bi) {
       a.x = x + 8 * bi;
       URSN_TRY(twgradz_dispatch(p, a, s));
-      if (d.cin == 8) return launch_reduce_accum(dw, (const float*)scratch, (int64_t)taps * 64, p.grid * 8, s);
+      if (d.cin == 8) return launch_reduce_accum(dw, (const float*)scratch, (int64_t)taps * 64, p.grid * 2, s);
       URSN_TRY(launch_reduce_accum_blocked(dw + (size_t)8 * bi * 8, (const float*)scratch, taps, 8, 8, (int64_t)d.cin * 8,
-                                           8, p.grid * 8, s));
+                                           8, p.grid * 2, s));
     }
     return 0;
   }
@@ -246,10 +253,10 @@ int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy,
       a.x = x + 16 * bi;
       a.dz = dy + 16 * bo;
       URSN_TRY(p.mode == 3 ? twgrad_dispatch_3d(p, a, s) : twgrad_dispatch_2d(p, a, s));
-      if (!blocked) return launch_reduce_accum(dw, (const float*)scratch, (int64_t)taps * d.cin * d.cout, p.grid * 4, s);
+      if (!blocked) return launch_reduce_accum(dw, (const float*)scratch, (int64_t)taps * d.cin * d.cout, p.grid, s);
       // slab [tap][16][16] -> dw[tap][16*bi + r][16*bo + c]
       URSN_TRY(launch_reduce_accum_blocked(dw + (size_t)16 * bi * d.cout + 16 * bo, (const float*)scratch, taps, 16, 16,
-                                           (int64_t)d.cin * d.cout, d.cout, p.grid * 4, s));
+                                           (int64_t)d.cin * d.cout, d.cout, p.grid, s));
     }
   ursn_note_kernel("twgrad<16,16>xB");
   return 0;

@@ -10,8 +10,8 @@
 // every x plane and dz plane is read from HBM exactly once.  A workgroup owns a TYxTX tile and marches
 // along the slowest axis with a ring of 4 x planes (halo included) + a double-buffered dz plane in LDS,
 // voxel-major ([slot][channel], a straight copy of the NDHWC rows).  Each wave takes a quarter of the
-// tile's voxels; per-wave partial slabs go to scratch and are summed (and ADDED into the gradient buffer,
-// the assign_add of lib/ssnet.py:77) by a deterministic second kernel.
+// tile's voxels; the waves are summed in LDS in fixed order, one slab per workgroup goes to scratch and the slabs
+// are summed (and ADDED into the gradient buffer, the assign_add of lib/ssnet.py:77) by a deterministic second kernel.
 #pragma once
 #include <utility>
 
@@ -190,23 +190,33 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
     __syncthreads();
   }
 
-  // per-wave partial slab
-  float* slab = a.slab + ((size_t)blockIdx.x * 4 + wave) * (size_t)(NT * CIN * a.cout_w);
+  // Sum the 4 waves in LDS (plane ring is free now) in fixed wave order -> one slab per workgroup (reproducible).
+  float* red = wlds;  // [NT*CIN*cout_w]
+  const int nred = NT * CIN * a.cout_w;
+  for (int i = tid; i < nred; i += 256) red[i] = 0.f;
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int m = 0; m < NA; ++m)
+      for (int m = 0; m < NA; ++m)
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      int col = c * 16 + il;
+        for (int c = 0; c < CT; ++c) {
+          int col = c * 16 + il;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = 4 * kl + r;
-        int tap, ci;
-        if (CIN >= 16) { tap = m / MT; ci = (m % MT) * 16 + row; }
-        else if (CIN == 1) { tap = 16 * m + row; ci = 0; }
-        else { tap = 2 * m + (row >> 3); ci = row & 7; }
-        if (tap < NT && col < a.cout_w) slab[((size_t)tap * CIN + ci) * a.cout_w + col] = acc[m][c][r];
-      }
+          for (int r = 0; r < 4; ++r) {
+            int row = 4 * kl + r;
+            int tap, ci;
+            if (CIN >= 16) { tap = m / MT; ci = (m % MT) * 16 + row; }
+            else if (CIN == 1) { tap = 16 * m + row; ci = 0; }
+            else { tap = 2 * m + (row >> 3); ci = row & 7; }
+            if (tap < NT && col < a.cout_w) red[(tap * CIN + ci) * a.cout_w + col] += acc[m][c][r];
+          }
+        }
     }
+    __syncthreads();
+  }
+  float* slab = a.slab + (size_t)blockIdx.x * (size_t)nred;
+  for (int i = tid; i < nred; i += 256) slab[i] = red[i];
 }
 
 struct TWPlan {

@@ -8,21 +8,22 @@
 //     D[(tz4,ty,tx,ci)][8 + co] accumulates tap (tz4-1, ty, tx) for plane z + 1  (valid tz4 >= 1)
 // i.e. 36 tap rows serve 2 x 27 taps: 18 MFMAs per 4-voxel group and plane pair instead of 2 x 14 (Cin = 8).
 // Both column halves cover exactly the workgroup's voxels of their own plane, so image borders need no
-// special case.  Ring of 6 x planes (4 live + 2 in flight), 4 dz planes; two slabs per wave (one per column
-// half), summed into the gradient by the deterministic reduce.  Cin = 16 runs as two 8-channel slices.
+// special case.  Ring of 6 x planes (4 live + 2 in flight), 4 dz planes; the waves are summed in LDS in fixed order,
+// two slabs per workgroup (one per column half) go to the deterministic reduce.  Cin = 16 runs as two 8-channel slices.
 #pragma once
 #include "wgrad_tiled_kernel.h"
 
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void twgradz_kernel(TWgradArgs a) {
+__global__ __launch_bounds__(512, 2) void twgradz_kernel(TWgradArgs a) {
   constexpr int CIN = 8, COUT = 8;
+  constexpr int NW = 8, NTHR = 64 * NW, NG = 64 / NW;           // 8 waves (2 per SIMD), NG voxel groups per wave and plane
   using TL = WTile<MODE>;
   constexpr int TX = TL::TX, TY = TL::TY, NTY = TL::NTY, NT = TL::NT;
   constexpr int NT4 = 4 * NTY * 3;                              // tap rows incl. the 4th z plane
   constexpr int PX = TX + 2, PY = TY + (NTY == 3 ? 2 : 0), PS = PX * PY;
   constexpr int NA = NT4 / 2;                                  // two taps (8 ci each) per 16-row tile
   constexpr int XQ = CIN / 4, DQ = COUT / 4;
-  constexpr int NSX = (XQ * PS + 255) / 256, NSD = (DQ * TX * TY + 255) / 256;
+  constexpr int NSX = (XQ * PS + NTHR - 1) / NTHR, NSD = (DQ * TX * TY + NTHR - 1) / NTHR;
   constexpr int XPLANE = PS * CIN, DPLANE = TX * TY * COUT;
   extern __shared__ __attribute__((aligned(16))) float wldz[];  // [6][XPLANE] then [4][DPLANE]
   float* xr = wldz;
@@ -46,8 +47,8 @@ __global__ __launch_bounds__(256, 1) void twgradz_kernel(TWgradArgs a) {
     a_tz[m] = tap / (NTY * 3);
     a_off[m] = (((tap / 3) % NTY) * PX + (tap % 3)) * CIN + ci;
   }
-  const int wrow = (MODE == 3) ? 2 * wave : 0;
-  const int wcol = (MODE == 3) ? 0 : 64 * wave;
+  const int wrow = (MODE == 3) ? wave : 0;          // 3-D: one 32-wide tile row per wave; 2-D: 32 x per wave
+  const int wcol = (MODE == 3) ? 0 : 32 * wave;
   const int a_lane = ((wrow * PX) + wcol + kl) * CIN;
   const int b_lane = ((wrow * TX) + wcol + kl) * COUT + (il & 7);
   const bool hi = il >= 8;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256, 1) void twgradz_kernel(TWgradArgs a) {
   auto load_x = [&](int zin, wg_f32x4 (&sx)[NSX]) {
 #pragma unroll
     for (int i = 0; i < NSX; ++i) {
-      int idx = tid + i * 256;
+      int idx = tid + i * NTHR;
       wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (idx < XQ * PS) {
         int s = idx / XQ, q = idx - s * XQ;
@@ -75,14 +76,14 @@ __global__ __launch_bounds__(256, 1) void twgradz_kernel(TWgradArgs a) {
   auto store_x = [&](int zin, const wg_f32x4 (&sx)[NSX]) {
 #pragma unroll
     for (int i = 0; i < NSX; ++i) {
-      int idx = tid + i * 256;
+      int idx = tid + i * NTHR;
       if (idx < XQ * PS) *(wg_f32x4*)(xr + (size_t)xslot(zin) * XPLANE + idx * 4) = sx[i];
     }
   };
   auto load_d = [&](int zin, wg_f32x4 (&sd)[NSD]) {
 #pragma unroll
     for (int i = 0; i < NSD; ++i) {
-      int idx = tid + i * 256;
+      int idx = tid + i * NTHR;
       wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (idx < DQ * TX * TY) {
         int s = idx / DQ, q = idx - s * DQ;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256, 1) void twgradz_kernel(TWgradArgs a) {
   auto store_d = [&](int zin, const wg_f32x4 (&sd)[NSD]) {
 #pragma unroll
     for (int i = 0; i < NSD; ++i) {
-      int idx = tid + i * 256;
+      int idx = tid + i * NTHR;
       if (idx < DQ * TX * TY) *(wg_f32x4*)(dr + (size_t)(zin & 3) * DPLANE + idx * 4) = sd[i];
     }
   };
@@ -122,10 +123,10 @@ __global__ __launch_bounds__(256, 1) void twgradz_kernel(TWgradArgs a) {
 #pragma unroll
     for (int m = 0; m < NA; ++m) abase[m] = xslot(z - 1 + a_tz[m]) * XPLANE + a_lane + a_off[m];
     const float* dcur = dr + (size_t)((hi ? z + 1 : z) & 3) * DPLANE + b_lane;
-    wg_static_for<16>([&](auto G) {
+    wg_static_for<NG>([&](auto G) {
       constexpr int g = decltype(G)::value;
-      constexpr int grow = (MODE == 3) ? g / 8 : 0;
-      constexpr int gcol = (MODE == 3) ? (g % 8) * 4 : g * 4;
+      constexpr int grow = 0;
+      constexpr int gcol = g * 4;
       const float b = dcur[(grow * TX + gcol) * COUT];
 #pragma unroll
       for (int m = 0; m < NA; ++m) {
@@ -140,19 +141,30 @@ __global__ __launch_bounds__(256, 1) void twgradz_kernel(TWgradArgs a) {
     __syncthreads();
   }
 
-  // two slabs per wave: [0] columns 0..7 (plane z, tap tz4), [1] columns 8..15 (plane z+1, tap tz4-1)
-  float* slab = a.slab + (((size_t)blockIdx.x * 4 + wave) * 2 + (hi ? 1 : 0)) * (size_t)(NT * CIN * COUT);
+  // Sum the 8 waves in LDS (the plane ring is free now) in fixed wave order -> ONE pair of slabs per workgroup,
+  // bitwise reproducible.  Half 0: columns 0..7 (plane z, tap tz4); half 1: columns 8..15 (plane z+1, tap tz4-1).
+  float* red = wldz;  // [2][NT*CIN*COUT]
+  for (int i = tid; i < 2 * NT * CIN * COUT; i += NTHR) red[i] = 0.f;
+  __syncthreads();
+  for (int w = 0; w < NW; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int m = 0; m < NA; ++m) {
+      for (int m = 0; m < NA; ++m) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int row = 4 * kl + r;
-      int tap4 = 2 * m + (row >> 3), ci = row & 7;
-      int tz4 = tap4 / (NTY * 3), rest = tap4 - tz4 * (NTY * 3);
-      int tz = hi ? tz4 - 1 : tz4;
-      if (tz >= 0 && tz <= 2) slab[((size_t)(tz * (NTY * 3) + rest) * CIN + ci) * COUT + (il & 7)] = acc[m][r];
+        for (int r = 0; r < 4; ++r) {
+          int row = 4 * kl + r;
+          int tap4 = 2 * m + (row >> 3), ci = row & 7;
+          int tz4 = tap4 / (NTY * 3), rest = tap4 - tz4 * (NTY * 3);
+          int tz = hi ? tz4 - 1 : tz4;
+          if (tz >= 0 && tz <= 2)
+            red[(hi ? NT * CIN * COUT : 0) + ((tz * (NTY * 3) + rest) * CIN + ci) * COUT + (il & 7)] += acc[m][r];
+        }
+      }
     }
+    __syncthreads();
   }
+  float* slab = a.slab + (size_t)blockIdx.x * 2 * (size_t)(NT * CIN * COUT);
+  for (int i = tid; i < 2 * NT * CIN * COUT; i += NTHR) slab[i] = red[i];
 }
 
 template <int MODE>
@@ -163,7 +175,7 @@ static int launch_twz(const TWPlan& p, const TWgradArgs& a, hipStream_t s) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
     attr_lds = p.lds;
   }
-  hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), p.lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(p.grid), dim3(512), p.lds, s, a);
   URSN_HIP(hipGetLastError());
   return 0;
 }
