@@ -443,3 +443,37 @@ def test_igemm_conv_fwd_dgrad_stats(case):
     dwg = conv_backward_weight(d, xg, dyg, w.shape)
     assert rel_err(dwg.cpu().numpy(), dw) < 5e-5
     assert rel_err(conv_backward_weight(d, xg, dyg, w.shape, dw_init=dwg).cpu().numpy(), 2 * dw) < 5e-5
+
+
+@pytest.mark.parametrize("case", [(3, 2, (8, 12, 16), 16, 8, 1), (3, 2, (8, 12, 16), 8, 16, 2), (3, 1, (6, 10, 14), 32, 16, 1),
+                                  (3, 1, (8, 8, 12), 16, 32, 2), (2, 2, (16, 40), 32, 16, 1), (2, 2, (16, 40), 32, 64, 2),
+                                  (3, 1, (4, 6, 10), 64, 32, 1)])
+def test_pointwise_shortcut_conv(case):
+    """1x1 shortcut convs (lib/resnet_module.py:25-33), stride 1 and 2, on the dedicated kernels (algo=5)."""
+    ndim, N, S, ci, co, st = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (1,) * ndim + (ci, co)) * 0.3
+    y = O.conv_fwd(x, w, st)
+    dy = _rand(rng, y.shape)
+    dx, dw = O.conv_bwd(x, w, st, dy)
+    d = desc(ndim, N, S, ci, co, 1, st, algo=5)
+    xg, wg, dyg = dev(x), dev(w), dev(dy)
+    lib = _lib.load()
+    yg = torch.full(y.shape, float("nan"), dtype=torch.float32, device="cuda")
+    mg, rg = torch.empty(co, device="cuda"), torch.empty(co, device="cuda")
+    nb = 1 << 22
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.ursn_conv_forward_stats(ctypes.byref(d), P(xg), P(wg), P(yg), P(mg), P(rg), 1e-3, P(scratch), nb,
+                                           stream()))
+    torch.cuda.synchronize()
+    assert rel_err(yg.cpu().numpy(), y) < TOL
+    ax = tuple(range(y.ndim - 1))
+    assert np.abs(mg.cpu().numpy() - y.mean(axis=ax)).max() < 1e-5 * np.sqrt(y.var(axis=ax).max())
+    assert rel_err(rg.cpu().numpy(), 1 / np.sqrt(y.var(axis=ax) + 1e-3)) < 1e-5
+    base = torch.ones(x.shape, dtype=torch.float32, device="cuda")
+    assert rel_err(conv_backward_data(d, dyg, wg, x.shape, accumulate=1, dx_init=base).cpu().numpy(), dx + 1.0) < TOL
+    if st == 1:
+        assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
+    dwg = conv_backward_weight(d, xg, dyg, w.shape)
+    assert rel_err(dwg.cpu().numpy(), dw) < 5e-5

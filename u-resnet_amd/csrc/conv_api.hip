@@ -236,6 +236,9 @@ int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const
     URSN_REQUIRE(igemm_conv_supported(d, pass), "igemm conv kernel does not support this shape");
     return launch_igemm_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
   }
+  if ((d.algo == 0 || d.algo == 5) && pointwise_conv_supported(d, pass, accumulate))
+    return launch_pointwise_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
+  URSN_REQUIRE(d.algo != 5, "pointwise conv kernel does not support this shape");
   if (d.algo == 0 && igemm_conv_supported(d, pass))
     return launch_igemm_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
   if (d.algo == 0 && tiled_conv_supported(d, pass)) return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
@@ -261,6 +264,11 @@ extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, 
   for (int j = 0; j < 3; ++j) V *= g[0].out_d[j];
   if (d->transposed) { V = (int64_t)d->n; for (int j = 0; j < d->ndim; ++j) V *= 2 * d->in_sp[j]; }
   const int ocs = d->out_cstride > 0 ? d->out_cstride : d->cout;
+  if ((d->algo == 0 || d->algo == 5) && pointwise_conv_supported(*d, PASS_FWD, 0)) {
+    URSN_REQUIRE(pointwise_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
+                 "conv_forward_stats: scratch too small");
+    return launch_pointwise_conv(*d, PASS_FWD, x, w, y, 0, (double*)scratch, eps, mean, rstd, s);
+  }
   if ((d->algo == 0 || d->algo == 4) && igemm_conv_supported(*d, PASS_FWD)) {
     URSN_REQUIRE(igemm_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
                  "conv_forward_stats: scratch too small");
@@ -299,13 +307,18 @@ extern "C" size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d) {
   size_t a = wgrad_plan(g[0]).scratch_bytes;
   size_t b = tiled_wgrad_supported(*d) ? tiled_wgrad_scratch_bytes(*d) : 0;
   size_t c = igemm_wgrad_scratch_bytes(*d);
+  size_t e = pointwise_wgrad_scratch_bytes(*d);
   if (b > a) a = b;
   if (c > a) a = c;
+  if (e > a) a = e;
   return a + 256;
 }
 
 int wgrad_dispatch(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
                    size_t scratch_bytes, hipStream_t s) {
+  if ((d.algo == 0 || d.algo == 5) && pointwise_wgrad_supported(d))
+    return launch_pointwise_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
+  URSN_REQUIRE(d.algo != 5, "pointwise wgrad kernel does not support this shape");
   if ((d.algo == 0 || d.algo == 4) && igemm_wgrad_supported(d))
     return launch_igemm_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
   URSN_REQUIRE(d.algo != 4, "igemm wgrad kernel does not support this shape");

@@ -27,7 +27,8 @@ static bool make_igplan(const ursn_conv_desc& d, ConvPass pass, IGPlan& p, int& 
   p.mode = d.ndim;
   if (d.ndim == 3) { p.Z = d.in_sp[0]; p.Y = d.in_sp[1]; p.X = d.in_sp[2]; }
   else { p.Z = 1; p.Y = d.in_sp[0]; p.X = d.in_sp[1]; }
-  if (p.X < 12 && d.algo != 4) return false;  // 16-wide x tiles: below that the gather kernel wastes less
+  static const int min_x = getenv("URSN_IGEMM_MINX") ? atoi(getenv("URSN_IGEMM_MINX")) : 12;
+  if (p.X < min_x && d.algo != 4) return false;  // 16-wide x tiles: below that the gather kernel wastes less
   const int BZ = p.mode == 3 ? 4 : 1, BY = p.mode == 3 ? 4 : 16, BX = 16;
   p.nbz = (p.Z + BZ - 1) / BZ;
   p.nby = (p.Y + BY - 1) / BY;

@@ -249,6 +249,8 @@ int plan(ursn_net* n, Arena& A) {
     if (rt > red) red = rt;
     rt = igemm_stats_scratch_doubles(L.desc) * sizeof(double);
     if (rt > red) red = rt;
+    rt = pointwise_stats_scratch_doubles(L.desc) * sizeof(double);
+    if (rt > red) red = rt;
     if (tr) {
       size_t w = ursn_conv_wgrad_scratch_bytes(&L.desc);
       if (w > wg) wg = w;
@@ -308,6 +310,13 @@ int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s) {
   d.n = N;
   d.in_cstride = in.cs;
   d.out_cstride = L.zcs;
+  if (pointwise_conv_supported(d, PASS_FWD, 0)) {  // 1x1 shortcut + BN-statistics partials in one pass
+    ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
+    URSN_TRY(launch_pointwise_conv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)n->red_scratch,
+                                   n->cfg.bn_eps, L.mean, L.rstd, s));
+    ps.done(ursn_last_kernel_name());
+    return 0;
+  }
   if (igemm_conv_supported(d, PASS_FWD)) {  // LDS-staged implicit GEMM + BN-statistics partials in one pass
     ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
     URSN_TRY(launch_igemm_conv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)n->red_scratch,
