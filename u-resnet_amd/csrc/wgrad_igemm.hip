@@ -36,7 +36,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(IGWArgs a) {
   constexpr int PSP = PS + ((2 - PS % 8) + 8) % 8;          // plane stride == 2 (mod 8) slots
   constexpr int DS = BZ * BY * BX, DSP = DS + 2;            // 256 voxels, padded likewise
   constexpr int BN = 16 * MT;
-  constexpr int TPW = (NT + 3) / 4;
+  // 3-D: the 27 taps are split over the waves (7+7+7+6); 2-D: 9 taps do not split evenly (3+3+3+0), so every
+  // wave keeps all 9 taps and the waves split the 64 voxel quads instead (fixed-order LDS sum at the end)
+  constexpr bool SPLITK = (MODE == 2);
+  constexpr int TPW = SPLITK ? NT : (NT + 3) / 4;
   constexpr int NHX = (4 * PS + 255) / 256, NHD = (BN / 4 * DS + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float iwl[];  // [4][PSP][4] x, then [BN/4][DSP][4] dz
   float* xl = iwl;
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(IGWArgs a) {
   bool t_ok[TPW];
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
-    int t = wave * TPW + i;
+    int t = SPLITK ? i : wave * TPW + i;
     t_ok[i] = t < NT;
     if (!t_ok[i]) t = 0;
     int tz = (KZ == 3) ? t / 9 : 0, ty = (t / 3) % 3, tx = t % 3;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(IGWArgs a) {
     }
     __syncthreads();
 #pragma unroll 4
-    for (int ks = 0; ks < 64; ++ks) {          // voxel quads: row = ks >> 2 (z*BY + y), x = 4*(ks & 3)
+    for (int ks = SPLITK ? wave : 0; ks < 64; ks += SPLITK ? 4 : 1) {   // voxel quads: row = ks >> 2, x = 4*(ks & 3)
       const int row = ks >> 2, xq = (ks & 3) * 4;
       const int vz = (MODE == 3) ? row / BY : 0, vy = (MODE == 3) ? row % BY : row;
       const int hs = (vz * HY + vy) * HX + xq;             // halo slot of the quad's first voxel (tap 0,0,0)
@@ -127,14 +130,33 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(IGWArgs a) {
 
   // D: row = ci (4*kl + r), col = co (il)
   float* slab = a.slab + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (size_t)(NT * 16 * BN);
+  if constexpr (SPLITK) {
+    __syncthreads();
+    float* red = iwl;  // NT*16*BN floats fit in the halo region
+    for (int i = tid; i < NT * 16 * BN; i += 256) red[i] = 0.f;
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
 #pragma unroll
-  for (int i = 0; i < TPW; ++i) {
-    const int t = wave * TPW + i;
-    if (t >= NT) continue;
+        for (int i = 0; i < TPW; ++i)
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) slab[((size_t)t * 16 + 4 * kl + r) * BN + 16 * m + il] = acc[i][m][r];
+            for (int r = 0; r < 4; ++r) red[((size_t)i * 16 + 4 * kl + r) * BN + 16 * m + il] += acc[i][m][r];
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < NT * 16 * BN; i += 256) slab[i] = red[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int t = wave * TPW + i;
+      if (t >= NT) continue;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[((size_t)t * 16 + 4 * kl + r) * BN + 16 * m + il] = acc[i][m][r];
+    }
   }
 }
 
