@@ -102,6 +102,10 @@ int ursn_eval(ursn_net* net, const float* data, const float* label, const float*
 int ursn_infer(ursn_net* net, const float* data, const float* label, int32_t n, float* softmax_out,
                float* out2, void* stream);
 
+/* ana_step's label rule on the device (lib/ssnet_trainval.py:285-287): labels_out [N,*spatial] =
+ * ((p[1] > p[2]) * 1 + (p[2] >= p[1]) * 2) * (data > 1.0); avoids returning the full softmax. Synchronises. */
+int ursn_infer_labels(ursn_net* net, const float* data, int32_t n, float* labels_out, void* stream);
+
 /* Metrics of the last accum/eval call: synchronises, writes {loss, acc_all, acc_nonzero}. */
 int ursn_read_metrics(ursn_net* net, float* out3, void* stream);
 

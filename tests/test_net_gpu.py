@@ -218,3 +218,16 @@ def test_driver_call_sequence_checkpoint_and_resume(tmp_path, capsys):
     assert set(r) == {'entries', 'input', 'label', 'softmax', 'acc_all', 'acc_nonzero'}
     assert r['softmax'].shape == (2, 32, 32, 32, 3) and r['input'].shape == (2, 32, 32, 32, 1)
     a.reset()
+
+
+def test_ana_label_rule_on_device():
+    """ursn_infer_labels == the reference's numpy post-processing of the softmax (lib/ssnet_trainval.py:285-287)."""
+    from oracle import uresnet_np as O
+    dims, base, ncls, N = (32, 32, 32, 1), 4, 3, 2
+    net = build(dims, base, ncls, False, trainable=False)
+    data, _, _ = make_inputs(dims, ncls, N, seed=4)
+    sm = net.inference(None, data)[0]
+    got = net.inference_labels(None, data)
+    want = np.stack([O.ana_label_rule(sm[i], data[i].reshape(dims[:-1])) for i in range(N)])
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert set(np.unique(got)) <= {0.0, 1.0, 2.0} and (got > 0).any()

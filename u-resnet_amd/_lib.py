@@ -48,6 +48,7 @@ _SIGS = {
     "ursn_apply_adam": (C.c_int, [_P, C.c_float, _P]),
     "ursn_eval": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(C.c_float), _P]),
     "ursn_infer": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.POINTER(C.c_float), _P]),
+    "ursn_infer_labels": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "ursn_read_metrics": (C.c_int, [_P, C.POINTER(C.c_float), _P]),
     "ursn_get_adam_step": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "ursn_set_adam_step": (C.c_int, [_P, C.c_int64]),

@@ -396,7 +396,7 @@ extern "C" int ursn_softmax_ce(const float* logits, const float* data, const flo
   HeadArgs a;
   memset(&a, 0, sizeof(a));
   a.z = logits; a.z_cs = ncls; a.data = data; a.data_cs = 1; a.label = label; a.weight = weight;
-  a.n = n; a.pix = pix; a.ncls = ncls; a.softmax_out = softmax_out; a.dlogits = dlogits;
+  a.n = n; a.pix = pix; a.ncls = ncls; a.softmax_out = softmax_out; a.dlogits = dlogits; a.ana_out = nullptr;
   a.scratch = scratch;
   a.metrics = (float*)((char*)scratch + ((head_scratch_bytes(n, pix) + 15) & ~(size_t)15));
   URSN_TRY(launch_head(a, s));

@@ -432,6 +432,11 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a, double* __restric
       for (int k = 0; k < URSN_MAX_CLASS; ++k)
         if (k < a.ncls) a.softmax_out[p * a.ncls + k] = e[k] * inv;
     }
+    if (a.ana_out) {  // (shower > track)*1 + (track >= shower)*2, masked by data > 1.0 (lib/ssnet_trainval.py:285-287)
+      float shower = e[1] * inv, track = e[2] * inv;
+      float lab = (shower > track ? 1.f : 0.f) + (track >= shower ? 2.f : 0.f);
+      a.ana_out[p] = (a.data && a.data[p * a.data_cs] > 1.0f) ? lab : 0.f;
+    }
     if (a.label) {
       int lab = (int)a.label[p];  // tf.cast(float -> int64) truncates toward zero
       bool lab_ok = lab >= 0 && lab < a.ncls;

@@ -3,6 +3,7 @@
 // lib/ssnet.py:91-139.  Host-side orchestration only; all arithmetic is in the HIP kernels.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -85,6 +86,12 @@ struct ursn_net {
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
+  // weight gradients run on a second stream: they only feed the optimiser, so they overlap the HBM-bound
+  // BN-backward passes and the low-occupancy deep-level kernels of the main chain (URSN_WGRAD_STREAM=0 disables)
+  hipStream_t s2 = nullptr;
+  std::vector<hipEvent_t> sync_pool;
+  size_t sync_used = 0;
+  hipEvent_t s2_done = nullptr;
   std::map<std::string, Act> named;       // debug lookup: activations
   std::map<std::string, int> named_z;     // layer name -> layer index
 };
@@ -403,7 +410,7 @@ int forward(ursn_net* n, const float* data, int N, hipStream_t s) {
 }
 
 int head(ursn_net* n, const float* data, const float* label, const float* weight, int N, float* softmax_out,
-         bool want_grad, hipStream_t s) {
+         bool want_grad, hipStream_t s, float* ana_out = nullptr) {
   Layer& L = n->layers[n->conv2];
   HeadArgs a;
   memset(&a, 0, sizeof(a));
@@ -412,6 +419,7 @@ int head(ursn_net* n, const float* data, const float* label, const float* weight
   a.data_cs = n->cfg.cin;
   a.label = label; a.weight = weight; a.n = N; a.pix = n->lvox[0]; a.ncls = n->cfg.num_class;
   a.softmax_out = softmax_out; a.dlogits = want_grad ? n->dlog : nullptr;
+  a.ana_out = ana_out;
   a.scratch = n->head_scratch; a.metrics = n->metrics;
   ProfScope ps(n, s, n->conv2, 6, 0.0, 4.0 * N * n->lvox[0] * (2.0 * a.ncls + 3));
   URSN_TRY(launch_head(a, s));
@@ -432,15 +440,27 @@ int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStre
   d.n = N;
   d.in_cstride = in.cs;
   d.out_cstride = L.zcs;
+  hipStream_t ws = s;
+  if (n->s2) {  // dz is final once the kernels queued so far on the main stream are done
+    if (n->sync_used == n->sync_pool.size()) {
+      hipEvent_t e;
+      URSN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      n->sync_pool.push_back(e);
+    }
+    hipEvent_t e = n->sync_pool[n->sync_used++];
+    URSN_HIP(hipEventRecord(e, s));
+    URSN_HIP(hipStreamWaitEvent(n->s2, e, 0));
+    ws = n->s2;
+  }
+  ProfScope ps(n, ws, li, 2, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
+  URSN_TRY(wgrad_dispatch(d, in.p, L.dz, n->grads + L.w_off, n->wg_scratch, n->wg_scratch_bytes, ws));
+  ps.done(ursn_last_kernel_name());
   if (need_dgrad) {
     bool acc = take_flag(n, in);
-    ProfScope ps(n, s, li, 1, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
+    ProfScope pd(n, s, li, 1, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
     URSN_TRY(conv_dispatch(d, PASS_DGRAD, L.dz, n->params + L.w_off, in.g, acc ? 1 : 0, s));
-    ps.done(ursn_last_kernel_name());
+    pd.done(ursn_last_kernel_name());
   }
-  ProfScope ps(n, s, li, 2, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
-  URSN_TRY(wgrad_dispatch(d, in.p, L.dz, n->grads + L.w_off, n->wg_scratch, n->wg_scratch_bytes, s));
-  ps.done(ursn_last_kernel_name());
   return 0;
 }
 
@@ -484,6 +504,7 @@ int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
 int backward(ursn_net* n, const float* data, int N, hipStream_t s) {
   const int ns = n->cfg.num_strides;
   for (size_t i = 0; i < n->ginit.size(); ++i) n->ginit[i] = 0;
+  n->sync_used = 0;
   Layer& L2 = n->layers[n->conv2];
   URSN_TRY(bn_back(n, n->conv2, n->dlog, L2.cout, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
   URSN_TRY(conv_bwd(n, n->conv2, n->a_conv1, true, N, s));
@@ -506,6 +527,10 @@ int backward(ursn_net* n, const float* data, int N, hipStream_t s) {
   Act din = n->a_data;
   din.p = const_cast<float*>(data);
   URSN_TRY(conv_bwd(n, n->conv0, din, false, N, s));
+  if (n->s2) {  // everything after this call on the caller's stream (Adam, the next step) sees finished gradients
+    URSN_HIP(hipEventRecord(n->s2_done, n->s2));
+    URSN_HIP(hipStreamWaitEvent(s, n->s2_done, 0));
+  }
   return 0;
 }
 
@@ -557,6 +582,17 @@ extern "C" int ursn_create(const ursn_config* cfg, float* params, float* grads, 
   }
   if (rc) { delete n; return rc; }
   n->params = params; n->grads = grads; n->adam_m = adam_m; n->adam_v = adam_v;
+  {
+    const char* e = getenv("URSN_WGRAD_STREAM");
+    if (n->cfg.trainable && !(e && e[0] == '0')) {
+      if (hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&n->s2_done, hipEventDisableTiming) != hipSuccess) {
+        ursn_set_error("create: could not create the weight-gradient stream");
+        delete n;
+        return 1;
+      }
+    }
+  }
   for (const Layer& L : n->layers) {  // pad channels of z/dz are never written afterwards: keep them 0 (not NaN)
     if (L.zcs == L.cout) continue;
     size_t bytes = (size_t)n->cfg.max_batch * n->lvox[L.lout] * L.zcs * sizeof(float);
@@ -570,7 +606,15 @@ extern "C" int ursn_create(const ursn_config* cfg, float* params, float* grads, 
   return 0;
 }
 
-extern "C" int ursn_destroy(ursn_net* net) { delete net; return 0; }
+extern "C" int ursn_destroy(ursn_net* net) {
+  if (!net) return 0;
+  if (net->s2) { (void)hipStreamSynchronize(net->s2); (void)hipStreamDestroy(net->s2); }
+  if (net->s2_done) (void)hipEventDestroy(net->s2_done);
+  for (hipEvent_t e : net->sync_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : net->ev_pool) (void)hipEventDestroy(e);
+  delete net;
+  return 0;
+}
 
 extern "C" int ursn_get_sizes(const ursn_net* net, ursn_sizes* out) {
   URSN_REQUIRE(net && out, "get_sizes: null argument");
@@ -650,6 +694,18 @@ extern "C" int ursn_infer(ursn_net* net, const float* data, const float* label, 
   URSN_TRY(head(net, data, label, nullptr, n, softmax_out, false, s));
   if (label && out2) URSN_TRY(read_metrics(net, out2, 2, s));
   else URSN_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+extern "C" int ursn_infer_labels(ursn_net* net, const float* data, int32_t n, float* labels_out, void* stream) {
+  URSN_TRY(check_call(net, data, n));
+  URSN_REQUIRE(labels_out, "infer_labels: labels_out is null");
+  URSN_REQUIRE(net->cfg.num_class >= 3 && net->cfg.cin == 1, "infer_labels: needs >= 3 classes and one input channel");
+  hipStream_t s = (hipStream_t)stream;
+  net->last_n = n;
+  URSN_TRY(forward(net, data, n, s));
+  URSN_TRY(head(net, data, nullptr, nullptr, n, nullptr, false, s, labels_out));
+  URSN_HIP(hipStreamSynchronize(s));
   return 0;
 }
 

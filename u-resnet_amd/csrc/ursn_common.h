@@ -162,6 +162,7 @@ struct HeadArgs {
   const float* data; int data_cs; const float* label; const float* weight;
   int n; int64_t pix; int ncls;
   float* softmax_out; float* dlogits;  // nullable
+  float* ana_out;                      // nullable: ssnet label volume (lib/ssnet_trainval.py:285-287), [n*pix]
   double* partial;                     // [nblocks][4]
   float* metrics;                      // device [3 + 1]
   void* scratch;

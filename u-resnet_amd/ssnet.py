@@ -349,6 +349,18 @@ class ssnet_base(object):
             res += [float(out[0]), float(out[1])]
         return res
 
+    def inference_labels(self, sess, input_data, as_numpy=True):
+        """ana_step's shower/track label volume computed on the device (lib/ssnet_trainval.py:285-287);
+        returns [N, *spatial] float32 instead of the full softmax."""
+        import torch
+        d = self._feed(input_data, self._data_size, 'data')
+        n = int(d.shape[0])
+        self._ensure_handle(n)
+        out = torch.empty((n,) + tuple(int(x) for x in self._dims[:-1]), dtype=torch.float32, device=self._device)
+        _lib.check(_lib.load().ursn_infer_labels(self._handle, self._ptr(d), n, self._ptr(out), self._stream(sess)))
+        self._last_feed = {'input_data': d}
+        return out.cpu().numpy() if as_numpy else out
+
     # ------------------------------------------------------------------------------------------
     # variables (checkpoint / weight injection)
     # ------------------------------------------------------------------------------------------
