@@ -133,6 +133,11 @@ int ursn_profile_enable(ursn_net* net, int32_t on);
 /* out == NULL: only counts.  Otherwise fills up to max_recs records and clears the log. */
 int ursn_profile_read(ursn_net* net, ursn_prof_rec* out, int64_t max_recs, int64_t* n_out);
 
+/* Weight gradients normally run on a second internal stream, overlapped with the data-gradient / BN-backward chain.
+ * on = 0 serialises them on the caller's stream (per-kernel timing: concurrent kernels time-slice, so event intervals
+ * would include the partner's work). */
+int ursn_set_wgrad_overlap(ursn_net* net, int32_t on);
+
 /* ---- op-level entry points (unit parity tests; same kernels the net-level calls use) ----- */
 typedef struct ursn_conv_desc {
   int32_t ndim;        /* 2 or 3                                                                   */

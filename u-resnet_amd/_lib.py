@@ -54,6 +54,7 @@ _SIGS = {
     "ursn_set_adam_step": (C.c_int, [_P, C.c_int64]),
     "ursn_tensor": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                               C.POINTER(C.c_int32)]),
+    "ursn_set_wgrad_overlap": (C.c_int, [_P, C.c_int32]),
     "ursn_profile_enable": (C.c_int, [_P, C.c_int32]),
     "ursn_profile_read": (C.c_int, [_P, C.POINTER(ursn_prof_rec), C.c_int64, C.POINTER(C.c_int64)]),
     "ursn_conv_forward": (C.c_int, [C.POINTER(ursn_conv_desc), _P, _P, _P, _P]),

@@ -89,6 +89,7 @@ struct ursn_net {
   // weight gradients run on a second stream: they only feed the optimiser, so they overlap the HBM-bound
   // BN-backward passes and the low-occupancy deep-level kernels of the main chain (URSN_WGRAD_STREAM=0 disables)
   hipStream_t s2 = nullptr;
+  hipStream_t s2_owned = nullptr;   // s2 == s2_owned when the overlap is switched on
   std::vector<hipEvent_t> sync_pool;
   size_t sync_used = 0;
   hipEvent_t s2_done = nullptr;
@@ -585,12 +586,13 @@ extern "C" int ursn_create(const ursn_config* cfg, float* params, float* grads, 
   {
     const char* e = getenv("URSN_WGRAD_STREAM");
     if (n->cfg.trainable && !(e && e[0] == '0')) {
-      if (hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking) != hipSuccess ||
+      if (hipStreamCreateWithFlags(&n->s2_owned, hipStreamNonBlocking) != hipSuccess ||
           hipEventCreateWithFlags(&n->s2_done, hipEventDisableTiming) != hipSuccess) {
         ursn_set_error("create: could not create the weight-gradient stream");
         delete n;
         return 1;
       }
+      n->s2 = n->s2_owned;
     }
   }
   for (const Layer& L : n->layers) {  // pad channels of z/dz are never written afterwards: keep them 0 (not NaN)
@@ -608,7 +610,7 @@ extern "C" int ursn_create(const ursn_config* cfg, float* params, float* grads, 
 
 extern "C" int ursn_destroy(ursn_net* net) {
   if (!net) return 0;
-  if (net->s2) { (void)hipStreamSynchronize(net->s2); (void)hipStreamDestroy(net->s2); }
+  if (net->s2_owned) { (void)hipStreamSynchronize(net->s2_owned); (void)hipStreamDestroy(net->s2_owned); }
   if (net->s2_done) (void)hipEventDestroy(net->s2_done);
   for (hipEvent_t e : net->sync_pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : net->ev_pool) (void)hipEventDestroy(e);
@@ -783,5 +785,12 @@ extern "C" int ursn_profile_read(ursn_net* net, ursn_prof_rec* out, int64_t max_
   }
   *n_out = cnt;
   if (out) { net->prof.clear(); net->ev_used = 0; }
+  return 0;
+}
+
+extern "C" int ursn_set_wgrad_overlap(ursn_net* net, int32_t on) {
+  URSN_REQUIRE(net, "null handle");
+  if (net->s2_owned) (void)hipStreamSynchronize(net->s2_owned);
+  net->s2 = on ? net->s2_owned : nullptr;
   return 0;
 }
