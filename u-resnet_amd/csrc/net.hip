@@ -586,7 +586,11 @@ extern "C" int ursn_create(const ursn_config* cfg, float* params, float* grads, 
   {
     const char* e = getenv("URSN_WGRAD_STREAM");
     if (n->cfg.trainable && !(e && e[0] == '0')) {
-      if (hipStreamCreateWithFlags(&n->s2_owned, hipStreamNonBlocking) != hipSuccess ||
+      int prio_lo = 0, prio_hi = 0;   // lowest priority: the dgrad / BN chain on the caller's stream is the critical path
+      (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+      const char* pe = getenv("URSN_WGRAD_PRIO");
+      int prio = pe ? atoi(pe) : prio_lo;
+      if (hipStreamCreateWithPriority(&n->s2_owned, hipStreamNonBlocking, prio) != hipSuccess ||
           hipEventCreateWithFlags(&n->s2_done, hipEventDisableTiming) != hipSuccess) {
         ursn_set_error("create: could not create the weight-gradient stream");
         delete n;
