@@ -149,7 +149,7 @@ typedef struct ursn_conv_desc {
   int32_t transposed;  /* 0: slim.conv{2,3}d SAME; 1: slim.conv{2,3}d_transpose k3 s2 SAME          */
   int32_t in_cstride;  /* channel stride (floats per voxel) of x / dx; 0 = compact (= cin)         */
   int32_t out_cstride; /* channel stride of y / dy; 0 = compact (= cout)                           */
-  int32_t algo;        /* 0 auto, 1 naive reference, 2 gather MFMA, 3 tiled small-C, 4 LDS implicit GEMM, 5 pointwise */
+  int32_t algo;        /* 0 auto, 1 naive reference, 2 gather MFMA, 3 tiled small-C, 4 LDS implicit GEMM, 5 pointwise, 6 LDS stride-2 */
 } ursn_conv_desc;
 
 /* y = conv(x, w).  w layout [k..,Cin,Cout] (transposed: [k..,Cout,Cin]). */

@@ -477,3 +477,58 @@ def test_pointwise_shortcut_conv(case):
         assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
     dwg = conv_backward_weight(d, xg, dyg, w.shape)
     assert rel_err(dwg.cpu().numpy(), dw) < 5e-5
+
+
+S2_CASES = [(3, 2, (16, 32, 64), 8, 16), (3, 1, (17, 21, 45), 16, 32), (3, 1, (8, 16, 32), 32, 64), (2, 2, (48, 160), 16, 32),
+            (2, 1, (37, 75), 8, 16), (3, 1, (6, 6, 6), 64, 128)]
+
+
+@pytest.mark.parametrize("case", S2_CASES)
+def test_stride2_lds_conv_forward_and_weight_gradient(case):
+    """k3 stride-2 convs (lib/resnet_module.py:43-51) on the LDS-staged stride-2 kernels (algo=6): forward with fused
+    BN statistics, weight gradient (overwrite + accumulate); odd sizes exercise TF SAME pad-before = 1."""
+    ndim, N, S, ci, co = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (3,) * ndim + (ci, co)) * 0.2
+    y = O.conv_fwd(x, w, 2)
+    dy = _rand(rng, y.shape)
+    _, dw = O.conv_bwd(x, w, 2, dy)
+    d = desc(ndim, N, S, ci, co, 3, 2, algo=6)
+    xg, wg, dyg = dev(x), dev(w), dev(dy)
+    lib = _lib.load()
+    yg = torch.full(y.shape, float("nan"), dtype=torch.float32, device="cuda")
+    mg, rg = torch.empty(co, device="cuda"), torch.empty(co, device="cuda")
+    nb = 1 << 24
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.ursn_conv_forward_stats(ctypes.byref(d), P(xg), P(wg), P(yg), P(mg), P(rg), 1e-3, P(scratch), nb,
+                                           stream()))
+    torch.cuda.synchronize()
+    assert rel_err(yg.cpu().numpy(), y) < TOL
+    ax = tuple(range(y.ndim - 1))
+    assert np.abs(mg.cpu().numpy() - y.mean(axis=ax)).max() < 1e-5 * np.sqrt(y.var(axis=ax).max())
+    assert rel_err(rg.cpu().numpy(), 1 / np.sqrt(y.var(axis=ax) + 1e-3)) < 1e-5
+    assert rel_err(conv_forward(d, xg, wg, y.shape).cpu().numpy(), y) < TOL
+    dwg = conv_backward_weight(d, xg, dyg, w.shape)
+    assert rel_err(dwg.cpu().numpy(), dw) < 5e-5
+    assert rel_err(conv_backward_weight(d, xg, dyg, w.shape, dw_init=dwg).cpu().numpy(), 2 * dw) < 5e-5
+
+
+@pytest.mark.parametrize("case", [(3, 2, (8, 16, 32), 16, 8), (3, 1, (9, 11, 37), 32, 16), (2, 2, (24, 80), 32, 16),
+                                  (2, 1, (19, 41), 16, 8)])
+def test_stride2_lds_transposed_conv_gradients(case):
+    """dx and dW of slim.conv{2,3}d_transpose k3 s2 (lib/uresnet.py:72-79) on the LDS-staged stride-2 kernels (algo=6)."""
+    ndim, N, S, ci, co = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (3,) * ndim + (co, ci)) * 0.2
+    y = O.deconv_fwd(x, w)
+    dy = _rand(rng, y.shape)
+    dx, dw = O.deconv_bwd(x, w, dy)
+    d = desc(ndim, N, S, ci, co, 3, 2, transposed=1, algo=6)
+    xg, wg, dyg = dev(x), dev(w), dev(dy)
+    assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
+    base = torch.ones(x.shape, dtype=torch.float32, device="cuda")
+    assert rel_err(conv_backward_data(d, dyg, wg, x.shape, accumulate=1, dx_init=base).cpu().numpy(), dx + 1.0) < TOL
+    dwg = conv_backward_weight(d, xg, dyg, w.shape)
+    assert rel_err(dwg.cpu().numpy(), dw) < 5e-5

@@ -236,6 +236,10 @@ int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const
     URSN_REQUIRE(igemm_conv_supported(d, pass), "igemm conv kernel does not support this shape");
     return launch_igemm_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
   }
+  if (d.algo == 6) {
+    URSN_REQUIRE(stride2_conv_supported(d, pass), "stride-2 conv kernel does not support this shape");
+    return launch_stride2_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
+  }
   if ((d.algo == 0 || d.algo == 5) && pointwise_conv_supported(d, pass, accumulate))
     return launch_pointwise_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
   URSN_REQUIRE(d.algo != 5, "pointwise conv kernel does not support this shape");
@@ -244,6 +248,8 @@ int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const
   if (d.algo == 0 && tiled_conv_supported(d, pass)) return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
   if (d.algo == 0 && tiled_deconv_supported(d, pass))
     return launch_tiled_deconv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
+  if (d.algo == 0 && stride2_conv_supported(d, pass))
+    return launch_stride2_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
   return run_gather(d, pass, in, w, out, accumulate, s);
 }
 
@@ -273,6 +279,11 @@ extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, 
     URSN_REQUIRE(igemm_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
                  "conv_forward_stats: scratch too small");
     return launch_igemm_conv(*d, PASS_FWD, x, w, y, 0, (double*)scratch, eps, mean, rstd, s);
+  }
+  if ((d->algo == 0 || d->algo == 6) && stride2_conv_supported(*d, PASS_FWD)) {
+    URSN_REQUIRE(stride2_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
+                 "conv_forward_stats: scratch too small");
+    return launch_stride2_conv(*d, PASS_FWD, x, w, y, 0, (double*)scratch, eps, mean, rstd, s);
   }
   if ((d->algo == 0 || d->algo == 3) && tiled_deconv_supported(*d, PASS_FWD)) {
     URSN_REQUIRE(tiled_deconv_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
@@ -308,6 +319,8 @@ extern "C" size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d) {
   size_t b = tiled_wgrad_supported(*d) ? tiled_wgrad_scratch_bytes(*d) : 0;
   size_t c = igemm_wgrad_scratch_bytes(*d);
   size_t e = pointwise_wgrad_scratch_bytes(*d);
+  size_t f = stride2_wgrad_scratch_bytes(*d);
+  if (f > a) a = f;
   if (b > a) a = b;
   if (c > a) a = c;
   if (e > a) a = e;
@@ -325,6 +338,9 @@ int wgrad_dispatch(const ursn_conv_desc& d, const float* x, const float* dy, flo
   if ((d.algo == 0 || d.algo == 3) && tiled_wgrad_supported(d))
     return launch_tiled_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
   URSN_REQUIRE(d.algo != 3, "tiled wgrad kernel does not support this shape");
+  if ((d.algo == 0 || d.algo == 6) && stride2_wgrad_supported(d))
+    return launch_stride2_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
+  URSN_REQUIRE(d.algo != 6, "stride-2 wgrad kernel does not support this shape");
   GatherGeom g[8];
   if (build_geoms(d, PASS_WGRAD, g) != 1) return 2;
   const float* S = d.transposed ? dy : x;

@@ -124,6 +124,15 @@ int pointwise_wgrad_supported(const ursn_conv_desc& d);
 size_t pointwise_wgrad_scratch_bytes(const ursn_conv_desc& d);
 int launch_pointwise_wgrad(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
                            size_t scratch_bytes, hipStream_t s);
+// LDS-staged stride-2 gather-type conv (conv_stride2.hip): conv k3 s2 forward / transposed-conv data gradient + wgrads
+int stride2_conv_supported(const ursn_conv_desc& d, ConvPass pass);
+size_t stride2_stats_scratch_doubles(const ursn_conv_desc& d);
+int launch_stride2_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
+                        int accumulate, double* stats_partial, float eps, float* mean, float* rstd, hipStream_t s);
+int stride2_wgrad_supported(const ursn_conv_desc& d);
+size_t stride2_wgrad_scratch_bytes(const ursn_conv_desc& d);
+int launch_stride2_wgrad(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
+                         size_t scratch_bytes, hipStream_t s);
 // tiled stride-2 scatter-type conv (deconv_tiled.hip): transposed-conv forward / stride-2 conv data gradient
 int tiled_deconv_supported(const ursn_conv_desc& d, ConvPass pass);
 size_t tiled_deconv_stats_scratch_doubles(const ursn_conv_desc& d);
