@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define URSN_ABI_VERSION 1
+#define URSN_ABI_VERSION 2
 
 typedef struct ursn_net ursn_net; /* opaque */
 
@@ -150,6 +150,13 @@ typedef struct ursn_conv_desc {
   int32_t in_cstride;  /* channel stride (floats per voxel) of x / dx; 0 = compact (= cin)         */
   int32_t out_cstride; /* channel stride of y / dy; 0 = compact (= cout)                           */
   int32_t algo;        /* 0 auto, 1 naive reference, 2 gather MFMA, 3 tiled small-C, 4 LDS implicit GEMM, 5 pointwise, 6 LDS stride-2 */
+  /* Split input (a tf.concat that is never materialised, lib/uresnet.py:81): channels [0,in_split) of the layer input
+   * live in x / dx, channels [in_split,cin) in x2 / dx2.  in_split = 0: single tensor.  Only k3 s1 and k1 s1 layers with
+   * in_split = cin/2 on the tiled / pointwise kernels; other shapes return an error.                                   */
+  int32_t in_split;
+  int32_t in2_cstride; /* channel stride of x2 / dx2; 0 = compact (= cin - in_split)                                   */
+  const float* x2;     /* forward and weight gradient: second input tensor                                            */
+  float* dx2;          /* data gradient: second output tensor                                                         */
 } ursn_conv_desc;
 
 /* y = conv(x, w).  w layout [k..,Cin,Cout] (transposed: [k..,Cout,Cin]). */

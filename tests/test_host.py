@@ -122,7 +122,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert set(_lib.EXPORTS) <= declared
-    assert lib.ursn_abi_version() == 1
+    assert lib.ursn_abi_version() == 2
 
 
 def test_query_sizes_and_errors():

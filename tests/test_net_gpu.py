@@ -231,3 +231,24 @@ def test_ana_label_rule_on_device():
     want = np.stack([O.ana_label_rule(sm[i], data[i].reshape(dims[:-1])) for i in range(N)])
     assert got.shape == want.shape and np.array_equal(got, want)
     assert set(np.unique(got)) <= {0.0, 1.0, 2.0} and (got > 0).any()
+
+
+def test_split_concat_matches_materialised_concat(monkeypatch):
+    """The never-materialised level-0 concat (two-tensor inputs) against the concat-buffer plan on the
+    same weights and batch: same loss, same gradients up to fp32 summation order."""
+    dims, base, ncls, N, ns = (32, 32, 64, 1), 8, 3, 2, 2
+    P = as_f32_exact(oracle_params(dims, base, ncls, num_strides=ns))
+    data, label, weight = make_inputs(dims, ncls, N, seed=11)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("URSN_SPLIT_CAT", mode)
+        net = build(dims, base, ncls, True, num_strides=ns)
+        net.set_variables(P)
+        net.zero_gradients(None)
+        res, _ = net.accum_gradients(None, data, label, weight)
+        out[mode] = (res[1], net.get_gradients(), net.debug_tensor("UResNet/deconv%d" % (ns - 1)),
+                     net._sizes.workspace_bytes if hasattr(net, "_sizes") else 0)
+    assert abs(out["0"][0] - out["1"][0]) <= 1e-5 * abs(out["0"][0])
+    assert max_rel(out["1"][2], out["0"][2]) < 1e-5
+    for k, g0 in out["0"][1].items():
+        assert l2_rel(out["1"][1][k], g0) < 2e-4, k

@@ -532,3 +532,51 @@ def test_stride2_lds_transposed_conv_gradients(case):
     assert rel_err(conv_backward_data(d, dyg, wg, x.shape, accumulate=1, dx_init=base).cpu().numpy(), dx + 1.0) < TOL
     dwg = conv_backward_weight(d, xg, dyg, w.shape)
     assert rel_err(dwg.cpu().numpy(), dw) < 5e-5
+
+
+@pytest.mark.parametrize("ndim,S,k", [(3, (8, 16, 32), 3), (3, (9, 11, 37), 3), (3, (8, 16, 32), 1), (3, (5, 7, 19), 1),
+                                      (2, (16, 256), 3), (2, (12, 40), 1)])
+def test_split_input_concat_never_materialised(ndim, S, k):
+    """tf.concat([deconv, skip], axis=-1) feeding resnet_module (lib/uresnet.py:81-84) with the two halves kept as
+    separate tensors (in_split / x2 / dx2): forward + fused statistics, data gradient into both halves (overwrite and
+    accumulate), weight gradient -- against the oracle on the concatenated input."""
+    N, h, co = 2, 8, 8
+    rng = np.random.default_rng(7 * ndim + k)
+    xa, xb = _rand(rng, (N,) + S + (h,)), _rand(rng, (N,) + S + (h,))
+    x = np.concatenate([xa, xb], axis=-1)
+    w = _rand(rng, (k,) * ndim + (2 * h, co)) * 0.2
+    y = O.conv_fwd(x, w, 1)
+    dy = _rand(rng, y.shape)
+    dx, dw = O.conv_bwd(x, w, 1, dy)
+    xag, xbg, wg, dyg = dev(xa), dev(xb), dev(w), dev(dy)
+    d = desc(ndim, N, S, 2 * h, co, k, 1)
+    d.in_split, d.in_cstride, d.in2_cstride = h, h, h
+    d.x2 = xbg.data_ptr()
+    lib = _lib.load()
+    assert rel_err(conv_forward(d, xag, wg, y.shape).cpu().numpy(), y) < TOL
+    yg = torch.full(y.shape, float("nan"), dtype=torch.float32, device="cuda")
+    mg, rg = torch.empty(co, device="cuda"), torch.empty(co, device="cuda")
+    nb = 1 << 24
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.ursn_conv_forward_stats(ctypes.byref(d), P(xag), P(wg), P(yg), P(mg), P(rg), 1e-3, P(scratch), nb,
+                                           stream()))
+    torch.cuda.synchronize()
+    assert rel_err(yg.cpu().numpy(), y) < TOL
+    ax = tuple(range(y.ndim - 1))
+    assert np.abs(mg.cpu().numpy() - y.mean(axis=ax)).max() < 1e-5 * np.sqrt(y.var(axis=ax).max())
+    assert rel_err(rg.cpu().numpy(), 1 / np.sqrt(y.var(axis=ax) + 1e-3)) < 1e-5
+    for acc in (0, 1):
+        dxa = torch.full(xa.shape, 1.0 if acc else float("nan"), dtype=torch.float32, device="cuda")
+        dxb = torch.full(xb.shape, 1.0 if acc else float("nan"), dtype=torch.float32, device="cuda")
+        d.dx2 = dxb.data_ptr()
+        _lib.check(lib.ursn_conv_backward_data(ctypes.byref(d), P(dyg), P(wg), P(dxa), acc, stream()))
+        torch.cuda.synchronize()
+        assert rel_err(dxa.cpu().numpy(), dx[..., :h] + acc) < TOL
+        assert rel_err(dxb.cpu().numpy(), dx[..., h:] + acc) < TOL
+    dwg = conv_backward_weight(d, xag, dyg, w.shape)
+    assert rel_err(dwg.cpu().numpy(), dw) < 5e-5
+    if k == 3:  # a split no two-tensor kernel covers must fail loudly, not fall back
+        d2 = desc(ndim, N, S, 2 * h, co, k, 1)
+        d2.in_split, d2.x2 = 4, xbg.data_ptr()
+        yy = torch.empty(y.shape, dtype=torch.float32, device="cuda")
+        assert lib.ursn_conv_forward(ctypes.byref(d2), P(xag), P(wg), P(yy), stream()) != 0

@@ -26,7 +26,8 @@ class ursn_param_info(C.Structure):
 class ursn_conv_desc(C.Structure):
     _fields_ = [("ndim", C.c_int32), ("n", C.c_int32), ("in_sp", C.c_int32 * 3), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("transposed", C.c_int32),
-                ("in_cstride", C.c_int32), ("out_cstride", C.c_int32), ("algo", C.c_int32)]
+                ("in_cstride", C.c_int32), ("out_cstride", C.c_int32), ("algo", C.c_int32),
+                ("in_split", C.c_int32), ("in2_cstride", C.c_int32), ("x2", C.c_void_p), ("dx2", C.c_void_p)]
 
 
 class ursn_prof_rec(C.Structure):
@@ -93,7 +94,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.ursn_abi_version() != 1:
+    if lib.ursn_abi_version() != 2:
         raise ImportError("liburesnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

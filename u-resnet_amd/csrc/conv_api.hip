@@ -226,6 +226,12 @@ int launch_tiled_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, c
 
 int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out, int accumulate,
                   hipStream_t s) {
+  if (d.in_split) {   // never-materialised concat: only the kernels that take two input tensors
+    if (pointwise_conv_supported(d, pass, accumulate))
+      return launch_pointwise_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
+    URSN_REQUIRE(tiled_conv_supported(d, pass), "conv: split input (in_split=%d) not supported for this shape", d.in_split);
+    return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
+  }
   if (d.algo == 3) {
     if (tiled_deconv_supported(d, pass))
       return launch_tiled_deconv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
@@ -270,7 +276,10 @@ extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, 
   for (int j = 0; j < 3; ++j) V *= g[0].out_d[j];
   if (d->transposed) { V = (int64_t)d->n; for (int j = 0; j < d->ndim; ++j) V *= 2 * d->in_sp[j]; }
   const int ocs = d->out_cstride > 0 ? d->out_cstride : d->cout;
-  if ((d->algo == 0 || d->algo == 5) && pointwise_conv_supported(*d, PASS_FWD, 0)) {
+  if (d->in_split)
+    URSN_REQUIRE(pointwise_conv_supported(*d, PASS_FWD, 0) || tiled_conv_supported(*d, PASS_FWD),
+                 "conv_forward_stats: split input (in_split=%d) not supported for this shape", d->in_split);
+  if ((d->algo == 0 || d->algo == 5 || d->in_split) && pointwise_conv_supported(*d, PASS_FWD, 0)) {
     URSN_REQUIRE(pointwise_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
                  "conv_forward_stats: scratch too small");
     return launch_pointwise_conv(*d, PASS_FWD, x, w, y, 0, (double*)scratch, eps, mean, rstd, s);
@@ -290,7 +299,7 @@ extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, 
                  "conv_forward_stats: scratch too small");
     return launch_tiled_deconv(*d, PASS_FWD, x, w, y, 0, (double*)scratch, eps, mean, rstd, s);
   }
-  if ((d->algo == 0 || d->algo == 3) && tiled_conv_supported(*d, PASS_FWD)) {
+  if ((d->algo == 0 || d->algo == 3 || d->in_split) && tiled_conv_supported(*d, PASS_FWD)) {
     URSN_REQUIRE(tiled_conv_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
                  "conv_forward_stats: scratch too small");
     return launch_tiled_conv_bn(*d, x, w, y, (double*)scratch, eps, mean, rstd, s);
@@ -329,6 +338,11 @@ extern "C" size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d) {
 
 int wgrad_dispatch(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
                    size_t scratch_bytes, hipStream_t s) {
+  if (d.in_split) {
+    if (pointwise_wgrad_supported(d)) return launch_pointwise_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
+    URSN_REQUIRE(tiled_wgrad_supported(d), "conv wgrad: split input (in_split=%d) not supported for this shape", d.in_split);
+    return launch_tiled_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
+  }
   if ((d.algo == 0 || d.algo == 5) && pointwise_wgrad_supported(d))
     return launch_pointwise_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
   URSN_REQUIRE(d.algo != 5, "pointwise wgrad kernel does not support this shape");

@@ -38,6 +38,11 @@ struct PConvArgs {
   int in_cs, out_cs;
   int cin_w, cout_w;
   int accumulate;
+  // split tensor on the contracted (forward: in) or produced (data gradient: out) side: channels >= split live in *2
+  int split;             // 0 = none
+  const float* in2;
+  float* out2;
+  int in2_cs, out2_cs;
 };
 
 // CK contracted, CP produced.  FLIP=false: in = x (hi grid when stride 2, sampled at even voxels), out = y (lo grid).
@@ -82,9 +87,12 @@ __global__ __launch_bounds__(256) void pconv_kernel(PConvArgs a) {
     }
     const float* ip = a.in + (FLIP ? v : hv) * a.in_cs;
     float* op = a.out + (FLIP ? hv : v) * a.out_cs;
+    const int sq = a.split >> 2;   // first channel quad held by the second tensor (split on in: forward, on out: dgrad)
+    const float* ip2 = (!FLIP && a.split) ? a.in2 + hv * a.in2_cs - a.split : ip;
+    float* op2 = (FLIP && a.split) ? a.out2 + hv * a.out2_cs - a.split : op;
     pw_f32x4 xv[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) xv[q] = *(const pw_f32x4*)(ip + 4 * q);
+    for (int q = 0; q < NQ; ++q) xv[q] = *(const pw_f32x4*)(((!FLIP && a.split && q >= sq) ? ip2 : ip) + 4 * q);
     pw_f32x4 acc[CQ];
 #pragma unroll
     for (int cq = 0; cq < CQ; ++cq) acc[cq] = (pw_f32x4){0.f, 0.f, 0.f, 0.f};
@@ -99,8 +107,9 @@ __global__ __launch_bounds__(256) void pconv_kernel(PConvArgs a) {
 #pragma unroll
     for (int cq = 0; cq < CQ; ++cq) {
       pw_f32x4 val = acc[cq];
-      if (a.accumulate) val += *(pw_f32x4*)(op + 4 * cq);
-      *(pw_f32x4*)(op + 4 * cq) = val;
+      float* o = ((FLIP && a.split && cq >= sq) ? op2 : op) + 4 * cq;
+      if (a.accumulate) val += *(pw_f32x4*)o;
+      *(pw_f32x4*)o = val;
       if constexpr (STATS) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s1[4 * cq + j] += val[j]; s2[4 * cq + j] += val[j] * val[j]; }
@@ -134,6 +143,9 @@ struct PWgradArgs {
   int stride;
   int x_cs, dz_cs;
   int64_t vox_per_block;
+  int split;        // channels >= split of x live in x2 (0 = none)
+  const float* x2;
+  int x2_cs;
 };
 
 template <int CIN, int COUT>
@@ -174,7 +186,8 @@ __global__ __launch_bounds__(256) void pwgrad_kernel(PWgradArgs a) {
           int64_t n = r / a.lo[0];
           hv = ((n * hi_z + a.sm[0] * z) * hi_y + a.sm[1] * y) * hi_x + a.sm[2] * x;
         }
-        val = *(const pw_f32x4*)(a.x + hv * a.x_cs + 4 * q);
+        val = (a.split && 4 * q >= a.split) ? *(const pw_f32x4*)(a.x2 + hv * a.x2_cs + 4 * q - a.split)
+                                            : *(const pw_f32x4*)(a.x + hv * a.x_cs + 4 * q);
       }
       *(pw_f32x4*)(xl + ((size_t)q * SP + s) * 4) = val;
     }
@@ -245,6 +258,10 @@ static bool pw_geometry(const ursn_conv_desc& d, int lo[3], int sm[3], int64_t& 
     nvox *= sz / d.stride;
   }
   const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+  if (d.in_split) {
+    const int i2 = d.in2_cstride > 0 ? d.in2_cstride : d.cin - d.in_split;
+    if (d.stride != 1 || (d.in_split & 3) || d.in_split >= d.cin || (i2 & 3)) return false;
+  }
   return !((ics & 3) || (ocs & 3));
 }
 
@@ -292,6 +309,12 @@ int launch_pointwise_conv(const ursn_conv_desc& d, ConvPass pass, const float* i
   a.out_cs = flip ? ics : ocs;
   a.cin_w = d.cin; a.cout_w = d.cout;
   a.accumulate = accumulate;
+  a.split = d.in_split; a.in2 = nullptr; a.out2 = nullptr; a.in2_cs = a.out2_cs = 0;
+  if (d.in_split) {
+    const int i2 = d.in2_cstride > 0 ? d.in2_cstride : d.cin - d.in_split;
+    if (flip) { URSN_REQUIRE(d.dx2, "pointwise conv: split input without dx2"); a.out2 = d.dx2; a.out2_cs = i2; }
+    else { URSN_REQUIRE(d.x2, "pointwise conv: split input without x2"); a.in2 = d.x2; a.in2_cs = i2; }
+  }
   const int ck = flip ? d.cout : d.cin, cp = flip ? d.cin : d.cout;
   int64_t blocks = cdiv64(a.nvox, 256 * 4);
   if (blocks > 2048) blocks = 2048;
@@ -351,6 +374,8 @@ int launch_pointwise_wgrad(const ursn_conv_desc& d, const float* x, const float*
   a.x_cs = d.in_cstride > 0 ? d.in_cstride : d.cin;
   a.dz_cs = d.out_cstride > 0 ? d.out_cstride : d.cout;
   a.vox_per_block = cdiv64(cdiv64(a.nvox, grid), 256) * 256;
+  a.split = d.in_split; a.x2 = d.x2; a.x2_cs = d.in2_cstride > 0 ? d.in2_cstride : d.cin - d.in_split;
+  URSN_REQUIRE(!d.in_split || d.x2, "pointwise wgrad: split input without x2");
   ursn_note_kernel("pwgrad");
   int rc = 3;
   if (d.cin == 16 && d.cout == 8) rc = pwgrad_launch<16, 8>(a, grid, s);

@@ -31,7 +31,9 @@ static bool tiled_disabled() {  // URSN_DISABLE_TILED=1: route everything throug
 }
 
 struct Blocking {
-  int nbi = 1, nbo = 1;  // channel blocks of the contraction / produced dims (kernel view); block = 16 when > 1
+  int nbi = 1, nbo = 1;  // channel blocks of the contraction / produced dims (kernel view)
+  int bsz = 16;          // block size when > 1 block (16; in_split for a split input)
+  bool split = false;    // the blocked side is a split input: block 1 lives in x2 / dx2
 };
 
 static int env_int(const char* name, int dflt) {
@@ -72,7 +74,16 @@ static bool make_plan(const ursn_conv_desc& d, ConvPass pass, TPlan& p, Blocking
   if (!spatial_plan(d, p.Z, p.Y, p.X, p.ntx, p.nty, p.zseg, p.nzseg, tb_conv)) return false;
   p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
   b = Blocking();
-  if (!tiled_shape_ok(p.cin, p.cout, p.mode)) {
+  if (d.in_split) {
+    // never-materialised concat: the two halves of the layer input are separate tensors -> two channel blocks on
+    // the input side (forward: contraction blocks accumulate into y; data gradient: one produced block per tensor)
+    const int half = d.in_split, i2 = d.in2_cstride > 0 ? d.in2_cstride : d.cin - d.in_split;
+    if (2 * half != d.cin || (half & 3) || (i2 & 3)) return false;
+    const int kc = p.flip ? p.cin : half, kp = p.flip ? half : p.cout;
+    if (!tiled_shape_ok(kc, kp, p.mode)) return false;
+    b.split = true; b.bsz = half;
+    if (p.flip) { b.nbo = 2; p.cout = half; } else { b.nbi = 2; p.cin = half; }
+  } else if (!tiled_shape_ok(p.cin, p.cout, p.mode)) {
     if ((p.cin % 16) || (p.cout % 16) || p.cin > 64 || p.cout > 64 || (p.grid < 192 && d.algo != 3)) return false;
     b.nbi = p.cin / 16;
     b.nbo = p.cout / 16;
@@ -102,6 +113,8 @@ static int launch_blocks(const ursn_conv_desc& d, const TPlan& p, const Blocking
                          float* out, int accumulate, double* stats_partial, float eps, float* mean, float* rstd,
                          hipStream_t s) {
   const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+  const int i2cs = d.in2_cstride > 0 ? d.in2_cstride : d.cin - d.in_split;
+  if (b.split) URSN_REQUIRE(p.flip ? d.dx2 != nullptr : d.x2 != nullptr, "tiled conv: split input without x2 / dx2");
   TConvArgs a;
   a.N = d.n; a.Z = p.Z; a.Y = p.Y; a.X = p.X;
   a.in_cs = p.flip ? ocs : ics;
@@ -113,20 +126,25 @@ static int launch_blocks(const ursn_conv_desc& d, const TPlan& p, const Blocking
   for (int bo = 0; bo < b.nbo; ++bo)
     for (int bi = 0; bi < b.nbi; ++bi) {
       const bool last = (bi == b.nbi - 1);
-      a.in = in + 16 * bi;
-      a.out = out + 16 * bo;
+      a.in = in + b.bsz * bi;
+      a.out = out + b.bsz * bo;
+      if (b.split) {   // block 1 of the split side is the second tensor
+        if (!p.flip) { a.in = bi ? d.x2 : in; a.in_cs = bi ? i2cs : ics; }
+        else { a.out = bo ? d.dx2 : out; a.out_cs = bo ? i2cs : ics; }
+      }
       // W[t][ci][co]: forward contracts ci (block bi) and produces co (block bo); the data gradient contracts co
       // (block bi) and produces ci (block bo)
-      a.w = p.flip ? w + (size_t)16 * bo * d.cout + 16 * bi : w + (size_t)16 * bi * d.cout + 16 * bo;
+      a.w = p.flip ? w + (size_t)b.bsz * bo * d.cout + b.bsz * bi : w + (size_t)b.bsz * bi * d.cout + b.bsz * bo;
       a.accumulate = (accumulate || bi > 0) ? 1 : 0;
       a.stats_partial = (stats_partial && last) ? stats_partial : nullptr;
       URSN_TRY(p.mode == 3 ? tconv_dispatch_3d(p, a, s) : tconv_dispatch_2d(p, a, s));
       if (stats_partial && last) {
-        int cb = (b.nbo > 1) ? 16 : real_out;  // real channels produced by this block
-        URSN_TRY(launch_bn_stats_final(stats_partial, p.grid, cb, p.cout, V, eps, mean + 16 * bo, rstd + 16 * bo, s));
+        int cb = (b.nbo > 1) ? b.bsz : real_out;  // real channels produced by this block
+        URSN_TRY(launch_bn_stats_final(stats_partial, p.grid, cb, p.cout, V, eps, mean + b.bsz * bo, rstd + b.bsz * bo, s));
       }
     }
-  if (b.nbi > 1 || b.nbo > 1) ursn_note_kernel(p.flip ? "tconv_dgrad<16,16>xB" : "tconv<16,16>xB");
+  if (b.split) ursn_note_kernel(p.flip ? "tconv_dgrad x2(split)" : "tconv x2(split)");
+  else if (b.nbi > 1 || b.nbo > 1) ursn_note_kernel(p.flip ? "tconv_dgrad<16,16>xB" : "tconv<16,16>xB");
   return 0;
 }
 
@@ -181,6 +199,7 @@ static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
   if (!spatial_plan(d, p.Z, p.Y, p.X, p.ntx, p.nty, p.zseg, p.nzseg, tb_wgrad)) return false;
   p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
   b = Blocking();
+  if (d.in_split && !(use_wgradz(d) && d.in_split == 8 && d.cin == 16)) return false;   // split input: plane-pair kernel only
   bool c816 = (d.cin == 8 || d.cin == 16) && (p.cout == 8 || p.cout == 16);
   bool extra = d.ndim == 3 ? ((d.cin == 8 && p.cout == 4) || (d.cin == 1 && p.cout == 8))
                            : ((d.cin == 16 && p.cout == 32) || (d.cin == 16 && p.cout == 4) || (d.cin == 1 && p.cout == 16) ||
@@ -235,6 +254,11 @@ int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy,
     a.cout_w = 8;
     for (int bi = 0; bi < d.cin / 8; ++bi) {
       a.x = x + 8 * bi;
+      if (d.in_split && bi) {   // second half of a split input
+        URSN_REQUIRE(d.x2, "tiled wgrad: split input without x2");
+        a.x = d.x2;
+        a.x_cs = d.in2_cstride > 0 ? d.in2_cstride : d.cin - d.in_split;
+      }
       URSN_TRY(twgradz_dispatch(p, a, s));
       if (d.cin == 8) return launch_reduce_accum(dw, (const float*)scratch, (int64_t)taps * 64, p.grid * 2, s);
       URSN_TRY(launch_reduce_accum_blocked(dw + (size_t)8 * bi * 8, (const float*)scratch, taps, 8, 8, (int64_t)d.cin * 8,

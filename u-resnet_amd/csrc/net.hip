@@ -54,6 +54,7 @@ struct Unit {
   std::string scope;
   int sc = -1, c1 = -1, c2 = -1;  // layer indices
   Act in, a1, out;
+  Act in2;   // C > 0: the unit input is the never-materialised concat [in | in2] (decoder, narrow levels)
 };
 
 }  // namespace
@@ -177,10 +178,32 @@ int plan(ursn_net* n, Arena& A) {
   n->layers.clear(); n->units.clear(); n->deconv.clear(); n->cat.clear(); n->deconv_in.clear(); n->deconv_out.clear();
   n->ginit.clear(); n->named.clear(); n->named_z.clear();
 
-  // concat buffers first (decoder step i lives at level ns-1-i with F*2^(ns-i) channels)
+  // concat buffers first (decoder step i lives at level ns-1-i with F*2^(ns-i) channels).  Where a half is narrower
+  // than a 64-byte line (<= 8 channels) and the tiled / pointwise kernels take the two halves as separate tensors,
+  // the concat is never materialised: half-line strided accesses cost the BN kernels ~2.5x (profiles/r01).
   n->cat.resize(ns);
-  for (int i = 0; i < ns; ++i) n->cat[i] = make_act(n, A, ns - 1 - i, F << (ns - i), tr);
+  std::vector<char> split(ns, 0);
+  std::vector<Act> lone_fmap(ns);
+  for (int i = 0; i < ns; ++i) {
+    const int lvl = ns - 1 - i, co = F << (ns - 1 - i);
+    {
+      const char* e = getenv("URSN_SPLIT_CAT");
+      ursn_conv_desc d3;
+      memset(&d3, 0, sizeof(d3));
+      d3.ndim = c.ndim; d3.n = c.max_batch;
+      for (int j = 0; j < c.ndim; ++j) d3.in_sp[j] = n->ldim[lvl][3 - c.ndim + j];
+      d3.cin = 2 * co; d3.cout = co; d3.k = 3; d3.stride = 1; d3.in_split = co;
+      ursn_conv_desc d1 = d3;
+      d1.k = 1;
+      split[i] = !(e && e[0] == '0') && co <= 8 && tiled_conv_supported(d3, PASS_FWD) && tiled_conv_supported(d3, PASS_DGRAD) &&
+                 pointwise_conv_supported(d1, PASS_FWD, 0) && pointwise_conv_supported(d1, PASS_DGRAD, 1) &&
+                 (!tr || (tiled_wgrad_supported(d3) && pointwise_wgrad_supported(d1)));
+    }
+    if (split[i]) lone_fmap[i] = make_act(n, A, lvl, co, tr);
+    else n->cat[i] = make_act(n, A, lvl, 2 * co, tr);
+  }
   auto fmap_view = [&](int lvl) {  // encoder feature map at level lvl (< ns) = second half of its concat buffer
+    if (split[ns - 1 - lvl]) return lone_fmap[ns - 1 - lvl];
     const Act& full = n->cat[ns - 1 - lvl];
     return sub_act(full, full.C / 2, full.C / 2);
   };
@@ -192,12 +215,15 @@ int plan(ursn_net* n, Arena& A) {
   n->a_conv0 = fmap_view(0);
   n->named["UResNet/conv0"] = n->a_conv0;
 
-  auto add_unit = [&](const std::string& scope, const Act& in, int co, int s, int lout, const Act* out_view) {
+  auto add_unit = [&](const std::string& scope, const Act& in, int co, int s, int lout, const Act* out_view,
+                      const Act* in2 = nullptr) {
     Unit u;
     u.scope = "UResNet/" + scope;
     u.in = in;
-    if (!(in.C == co && s == 1)) u.sc = add_layer(n, A, scope + "/shortcut", 0, 1, s, in.C, co, in.lvl, lout, poff);
-    u.c1 = add_layer(n, A, scope + "/resnet_conv1", 0, 3, s, in.C, co, in.lvl, lout, poff);
+    if (in2) u.in2 = *in2;
+    const int cin = in.C + (in2 ? in2->C : 0);
+    if (!(cin == co && s == 1)) u.sc = add_layer(n, A, scope + "/shortcut", 0, 1, s, cin, co, in.lvl, lout, poff);
+    u.c1 = add_layer(n, A, scope + "/resnet_conv1", 0, 3, s, cin, co, in.lvl, lout, poff);
     u.a1 = make_act(n, A, lout, co, tr);
     u.c2 = add_layer(n, A, scope + "/resnet_conv2", 0, 3, 1, co, co, lout, lout, poff);
     u.out = out_view ? *out_view : make_act(n, A, lout, co, tr);
@@ -229,11 +255,11 @@ int plan(ursn_net* n, Arena& A) {
     int li = add_layer(n, A, sc, 1, 3, 2, net.C, co, net.lvl, lvl, poff);
     n->deconv.push_back(li);
     n->deconv_in.push_back(net);
-    Act dout = sub_act(n->cat[i], 0, co);
+    Act dout = split[i] ? make_act(n, A, lvl, co, tr) : sub_act(n->cat[i], 0, co);
     n->deconv_out.push_back(dout);
     n->named[n->layers[li].name] = dout;
     snprintf(sc, sizeof(sc), "resnet_module%d/module1", i + 5);
-    Act u1 = add_unit(sc, n->cat[i], co, 1, lvl, nullptr);
+    Act u1 = split[i] ? add_unit(sc, dout, co, 1, lvl, nullptr, &lone_fmap[i]) : add_unit(sc, n->cat[i], co, 1, lvl, nullptr);
     snprintf(sc, sizeof(sc), "resnet_module%d/module2", i + 5);
     net = add_unit(sc, u1, co, 1, lvl, nullptr);
   }
@@ -314,12 +340,13 @@ double layer_bytes(const ursn_net* n, const Layer& L, int N) {  // x + y + w  (=
 }
 
 // ---- forward pieces -----------------------------------------------------------------------
-int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s) {
+int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s, const Act* in2 = nullptr) {
   Layer& L = n->layers[li];
   ursn_conv_desc d = L.desc;
   d.n = N;
   d.in_cstride = in.cs;
   d.out_cstride = L.zcs;
+  if (in2) { d.in_split = in.C; d.in2_cstride = in2->cs; d.x2 = in2->p; }
   if (pointwise_conv_supported(d, PASS_FWD, 0)) {  // 1x1 shortcut + BN-statistics partials in one pass
     ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
     URSN_TRY(launch_pointwise_conv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)n->red_scratch,
@@ -387,8 +414,9 @@ int bn_out(ursn_net* n, int li, const Act& out, int relu, int N, int li2, const 
 }
 
 int unit_fwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
-  if (u.sc >= 0) URSN_TRY(conv_stats(n, u.sc, u.in, N, s));
-  URSN_TRY(conv_stats(n, u.c1, u.in, N, s));
+  const Act* in2 = u.in2.C ? &u.in2 : nullptr;
+  if (u.sc >= 0) URSN_TRY(conv_stats(n, u.sc, u.in, N, s, in2));
+  URSN_TRY(conv_stats(n, u.c1, u.in, N, s, in2));
   URSN_TRY(bn_out(n, u.c1, u.a1, 0, N, -1, nullptr, 0, s));
   URSN_TRY(conv_stats(n, u.c2, u.a1, N, s));
   if (u.sc >= 0) URSN_TRY(bn_out(n, u.c2, u.out, 1, N, u.sc, nullptr, 0, s));
@@ -444,12 +472,13 @@ bool take_flag(ursn_net* n, const Act& a) {  // returns "accumulate?" and marks 
   return acc;
 }
 
-int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStream_t s) {
+int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStream_t s, const Act* in2 = nullptr) {
   Layer& L = n->layers[li];
   ursn_conv_desc d = L.desc;
   d.n = N;
   d.in_cstride = in.cs;
   d.out_cstride = L.zcs;
+  if (in2) { d.in_split = in.C; d.in2_cstride = in2->cs; d.x2 = in2->p; d.dx2 = in2->g; }
   hipStream_t ws = s;
   if (n->s2) {  // dz is final once the kernels queued so far on the main stream are done
     if (n->sync_used == n->sync_pool.size()) {
@@ -467,6 +496,7 @@ int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStre
   ps.done(ursn_last_kernel_name());
   if (need_dgrad) {
     bool acc = take_flag(n, in);
+    if (in2) URSN_REQUIRE(take_flag(n, *in2) == acc, "split input: the two halves disagree on gradient initialisation");
     ProfScope pd(n, s, li, 1, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
     URSN_TRY(conv_dispatch(d, PASS_DGRAD, L.dz, n->params + L.w_off, in.g, acc ? 1 : 0, s));
     pd.done(ursn_last_kernel_name());
@@ -506,8 +536,9 @@ int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
   }
   URSN_TRY(conv_bwd(n, u.c2, u.a1, true, N, s));
   URSN_TRY(bn_back(n, u.c1, u.a1.g, u.a1.cs, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
-  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s));
-  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, true, N, s));
+  const Act* in2 = u.in2.C ? &u.in2 : nullptr;
+  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, in2));
+  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, true, N, s, in2));
   return 0;
 }
 

@@ -106,6 +106,7 @@ int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass);
 size_t tiled_conv_stats_scratch_doubles(const ursn_conv_desc& d);
 int launch_tiled_conv_bn(const ursn_conv_desc& d, const float* in, const float* w, float* out, double* scratch,
                          float eps, float* mean, float* rstd, hipStream_t s);
+int tiled_wgrad_supported(const ursn_conv_desc& d);
 // LDS-staged implicit GEMM for k3 s1 layers with >= 32 channels (conv_igemm.hip)
 int igemm_conv_supported(const ursn_conv_desc& d, ConvPass pass);
 size_t igemm_stats_scratch_doubles(const ursn_conv_desc& d);
