@@ -157,6 +157,12 @@ typedef struct ursn_conv_desc {
   int32_t in2_cstride; /* channel stride of x2 / dx2; 0 = compact (= cin - in_split)                                   */
   const float* x2;     /* forward and weight gradient: second input tensor                                            */
   float* dx2;          /* data gradient: second output tensor                                                         */
+  /* Data gradient only: fused term of a parallel 1x1 stride-1 conv with the same cin/cout (the residual unit's shortcut,
+   * lib/resnet_module.py:25-33): dx (+)= conv^T(dy, w) + pw_dy . pw_w^T.  pw_dy = NULL: none.  k3 s1 tiled kernels only. */
+  const float* pw_dy;  /* [voxels][cout] gradient at the shortcut conv's output                                       */
+  const float* pw_w;   /* [cin][cout] shortcut weights                                                                 */
+  int32_t pw_dy_cstride; /* 0 = compact (= cout)                                                                       */
+  int32_t reserved_;
 } ursn_conv_desc;
 
 /* y = conv(x, w).  w layout [k..,Cin,Cout] (transposed: [k..,Cout,Cin]). */

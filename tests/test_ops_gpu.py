@@ -580,3 +580,37 @@ def test_split_input_concat_never_materialised(ndim, S, k):
         d2.in_split, d2.x2 = 4, xbg.data_ptr()
         yy = torch.empty(y.shape, dtype=torch.float32, device="cuda")
         assert lib.ursn_conv_forward(ctypes.byref(d2), P(xag), P(wg), P(yy), stream()) != 0
+
+
+@pytest.mark.parametrize("ndim,S,ci,co,split", [(3, (8, 16, 32), 16, 8, True), (3, (9, 11, 37), 16, 8, False),
+                                                (3, (8, 16, 32), 8, 8, False), (2, (16, 256), 16, 16, False)])
+def test_tiled_dgrad_with_fused_shortcut_term(ndim, S, ci, co, split):
+    """dx of resnet_conv1 and of the parallel 1x1 shortcut (lib/resnet_module.py:25-43) in ONE kernel (pw_dy / pw_w)."""
+    N = 2
+    rng = np.random.default_rng(5 * ndim + ci + co)
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (3,) * ndim + (ci, co)) * 0.2
+    ws = _rand(rng, (1,) * ndim + (ci, co)) * 0.3
+    dy, dys = _rand(rng, (N,) + S + (co,)), _rand(rng, (N,) + S + (co,))
+    dx = O.conv_bwd(x, w, 1, dy)[0] + O.conv_bwd(x, ws, 1, dys)[0]
+    wg, wsg, dyg, dysg = dev(w), dev(ws), dev(dy), dev(dys)
+    d = desc(ndim, N, S, ci, co, 3, 1)
+    d.pw_dy, d.pw_w = dysg.data_ptr(), wsg.data_ptr()
+    lib = _lib.load()
+    h = ci // 2
+    for acc in (0, 1):
+        if split:
+            d.in_split, d.in_cstride, d.in2_cstride = h, h, h
+            dxa = torch.full((N,) + S + (h,), 1.0 if acc else float("nan"), dtype=torch.float32, device="cuda")
+            dxb = torch.full((N,) + S + (h,), 1.0 if acc else float("nan"), dtype=torch.float32, device="cuda")
+            d.dx2 = dxb.data_ptr()
+            _lib.check(lib.ursn_conv_backward_data(ctypes.byref(d), P(dyg), P(wg), P(dxa), acc, stream()))
+            torch.cuda.synchronize()
+            got = np.concatenate([dxa.cpu().numpy(), dxb.cpu().numpy()], axis=-1)
+        else:
+            base = torch.full(x.shape, 1.0 if acc else float("nan"), dtype=torch.float32, device="cuda")
+            got = conv_backward_data(d, dyg, wg, x.shape, accumulate=acc, dx_init=base).cpu().numpy()
+        assert rel_err(got, dx + acc) < TOL
+    # the forward pass has no such term: must be refused
+    yy = torch.empty(dy.shape, dtype=torch.float32, device="cuda")
+    assert lib.ursn_conv_forward(ctypes.byref(d), P(dev(x)), P(wg), P(yy), stream()) != 0

@@ -226,6 +226,10 @@ int launch_tiled_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, c
 
 int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out, int accumulate,
                   hipStream_t s) {
+  if (d.pw_dy) {      // fused shortcut data gradient: tiled kernels only
+    URSN_REQUIRE(pass == PASS_DGRAD && tiled_conv_supported(d, pass), "conv: fused pointwise term (pw_dy) not supported for this shape / pass");
+    return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
+  }
   if (d.in_split) {   // never-materialised concat: only the kernels that take two input tensors
     if (pointwise_conv_supported(d, pass, accumulate))
       return launch_pointwise_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);

@@ -98,7 +98,9 @@ static bool make_plan(const ursn_conv_desc& d, ConvPass pass, TPlan& p, Blocking
 int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass) {
   TPlan p;
   Blocking b;
-  return make_plan(d, pass, p, b) ? 1 : 0;
+  if (!make_plan(d, pass, p, b)) return 0;
+  if (d.pw_dy && !(pass == PASS_DGRAD && p.cin <= 16)) return 0;
+  return 1;
 }
 
 // doubles of scratch the fused-statistics forward needs
@@ -121,6 +123,8 @@ static int launch_blocks(const ursn_conv_desc& d, const TPlan& p, const Blocking
   a.out_cs = p.flip ? ics : ocs;
   a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
   a.cin_w = d.cin; a.cout_w = d.cout;
+  a.pw_in = nullptr; a.pw_w = nullptr; a.pw_in_cs = d.pw_dy_cstride > 0 ? d.pw_dy_cstride : d.cout; a.pw_ws = d.cout;
+  if (d.pw_dy) URSN_REQUIRE(p.flip && d.pw_w && p.cin <= 16 && (a.pw_in_cs & 3) == 0, "tiled conv: fused pointwise term needs the data-gradient pass with <= 16 contraction channels");
   const int64_t V = (int64_t)d.n * p.Z * p.Y * p.X;
   const int real_out = p.flip ? d.cin : d.cout;
   for (int bo = 0; bo < b.nbo; ++bo)
@@ -136,6 +140,8 @@ static int launch_blocks(const ursn_conv_desc& d, const TPlan& p, const Blocking
       // (block bi) and produces ci (block bo)
       a.w = p.flip ? w + (size_t)b.bsz * bo * d.cout + b.bsz * bi : w + (size_t)b.bsz * bi * d.cout + b.bsz * bo;
       a.accumulate = (accumulate || bi > 0) ? 1 : 0;
+      if (d.pw_dy && bi == 0) { a.pw_in = d.pw_dy; a.pw_w = d.pw_w + (size_t)b.bsz * bo * d.cout; }   // once per produced block
+      else a.pw_in = nullptr;
       a.stats_partial = (stats_partial && last) ? stats_partial : nullptr;
       URSN_TRY(p.mode == 3 ? tconv_dispatch_3d(p, a, s) : tconv_dispatch_2d(p, a, s));
       if (stats_partial && last) {

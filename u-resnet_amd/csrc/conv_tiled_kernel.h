@@ -47,6 +47,11 @@ struct TConvArgs {
   int nzseg, nty, ntx;
   int accumulate;
   int cin_w, cout_w;      // dims of the weight tensor as stored: [t][cin_w][cout_w]
+  // data gradient only: fused pointwise term of the parallel 1x1 shortcut (lib/resnet_module.py:25-33),
+  //   out[v][ci] += sum_co pw_in[v][co] * pw_w[ci][co]     (pw_in = shortcut dz, CIN channels; null = none)
+  const float* pw_in;
+  const float* pw_w;      // rows = produced channels of this launch, row stride pw_ws
+  int pw_in_cs, pw_ws;
 };
 
 template <int MODE> struct Tile;
@@ -98,6 +103,17 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
       }
   }
 
+  float wpw[CQ];  // fused pointwise term (FLIP): lane l holds Ws[ci = 4cq + (l&3)][co = l>>2]
+#pragma unroll
+  for (int cq = 0; cq < CQ; ++cq) wpw[cq] = 0.f;
+  if constexpr (FLIP && CIN <= 16) {
+    if (a.pw_in) {
+      const int kl = lane >> 2, cl = lane & 3;
+#pragma unroll
+      for (int cq = 0; cq < CQ; ++cq) wpw[cq] = (kl < CIN) ? a.pw_w[(size_t)(4 * cq + cl) * a.pw_ws + kl] : 0.f;
+    }
+  }
+
   // ---- plane staging --------------------------------------------------------------------------------------
   f32x4 stage[NSTAGE];
   auto stage_load = [&](int zin) {
@@ -143,6 +159,15 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
     f32x4 acc[CQ];
 #pragma unroll
     for (int cq = 0; cq < CQ; ++cq) acc[cq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 pv[(FLIP && CIN <= 16) ? NQ : 1];
+    if constexpr (FLIP && CIN <= 16) {
+      if (a.pw_in) {  // this lane's voxel of the shortcut gradient (clamped for out-of-range lanes: MFMA needs all lanes)
+        const int cy = gy < a.Y ? gy : a.Y - 1, cx = gx < a.X ? gx : a.X - 1;
+        const float* pp = a.pw_in + ((((size_t)n * a.Z + z) * a.Y + cy) * a.X + cx) * a.pw_in_cs;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) pv[q] = *(const f32x4*)(pp + 4 * q);
+      }
+    }
     static_for<3>([&](auto TZ) {
       constexpr int tz = decltype(TZ)::value;
       const f32x4* plane = lds + (size_t)((z - 1 + tz) & 3) * NQ * PS + lane_slot;
@@ -163,6 +188,17 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
         });
       });
     });
+    if constexpr (FLIP && CIN <= 16) {
+      if (a.pw_in) {
+        static_for<CIN>([&](auto K) {
+          constexpr int k = decltype(K)::value;
+          static_for<CQ>([&](auto C) {
+            constexpr int cq = decltype(C)::value;
+            acc[cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wpw[cq], pv[k / 4][k % 4], acc[cq], 4, k, 0);
+          });
+        });
+      }
+    }
     if (vox_ok) {
       float* op = a.out + ((((size_t)n * a.Z + z) * a.Y + gy) * a.X + gx) * a.out_cs;
 #pragma unroll

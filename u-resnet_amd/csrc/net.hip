@@ -472,13 +472,25 @@ bool take_flag(ursn_net* n, const Act& a) {  // returns "accumulate?" and marks 
   return acc;
 }
 
-int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStream_t s, const Act* in2 = nullptr) {
+// desc of layer li for the backward passes; sc >= 0: with the fused data gradient of the unit's 1x1 shortcut
+ursn_conv_desc bwd_desc(ursn_net* n, int li, const Act& in, int N, const Act* in2, int sc) {
   Layer& L = n->layers[li];
   ursn_conv_desc d = L.desc;
   d.n = N;
   d.in_cstride = in.cs;
   d.out_cstride = L.zcs;
   if (in2) { d.in_split = in.C; d.in2_cstride = in2->cs; d.x2 = in2->p; d.dx2 = in2->g; }
+  if (sc >= 0) {
+    Layer& S = n->layers[sc];
+    d.pw_dy = S.dz; d.pw_w = n->params + S.w_off; d.pw_dy_cstride = S.zcs;
+  }
+  return d;
+}
+
+int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStream_t s, const Act* in2 = nullptr,
+             int fused_sc = -1) {
+  Layer& L = n->layers[li];
+  ursn_conv_desc d = bwd_desc(n, li, in, N, in2, -1);
   hipStream_t ws = s;
   if (n->s2) {  // dz is final once the kernels queued so far on the main stream are done
     if (n->sync_used == n->sync_pool.size()) {
@@ -497,6 +509,7 @@ int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStre
   if (need_dgrad) {
     bool acc = take_flag(n, in);
     if (in2) URSN_REQUIRE(take_flag(n, *in2) == acc, "split input: the two halves disagree on gradient initialisation");
+    if (fused_sc >= 0) d = bwd_desc(n, li, in, N, in2, fused_sc);
     ProfScope pd(n, s, li, 1, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
     URSN_TRY(conv_dispatch(d, PASS_DGRAD, L.dz, n->params + L.w_off, in.g, acc ? 1 : 0, s));
     pd.done(ursn_last_kernel_name());
@@ -537,8 +550,15 @@ int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
   URSN_TRY(conv_bwd(n, u.c2, u.a1, true, N, s));
   URSN_TRY(bn_back(n, u.c1, u.a1.g, u.a1.cs, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
   const Act* in2 = u.in2.C ? &u.in2 : nullptr;
-  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, in2));
-  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, true, N, s, in2));
+  // stride-1 shortcut next to a tiled conv1: its data gradient rides in conv1's data-gradient kernel
+  bool fuse = false;
+  if (u.sc >= 0 && n->layers[u.sc].stride == 1) {
+    static const bool off = getenv("URSN_FUSE_SHORTCUT_DGRAD") && getenv("URSN_FUSE_SHORTCUT_DGRAD")[0] == '0';
+    ursn_conv_desc d = bwd_desc(n, u.c1, u.in, N, in2, u.sc), d0 = bwd_desc(n, u.c1, u.in, N, in2, -1);
+    fuse = !off && tiled_conv_supported(d, PASS_DGRAD) && !igemm_conv_supported(d0, PASS_DGRAD);   // only where conv1's dgrad is tiled anyway
+  }
+  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, in2, fuse ? u.sc : -1));
+  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, !fuse, N, s, in2));
   return 0;
 }
 
