@@ -41,6 +41,9 @@ static bool make_igplan(const ursn_conv_desc& d, ConvPass pass, IGPlan& p, int& 
   p.gridy = (kcout + p.bm - 1) / p.bm;
   const int HZ = p.mode == 3 ? 6 : 1, HY = BY + 2, HX = BX + 2;
   p.lds = ((size_t)4 * HZ * HY * HX * 4 + (size_t)2 * 16 * (p.bm + 16)) * sizeof(float);
+  static const int at = getenv("URSN_IGEMM_ALLTAPS") ? atoi(getenv("URSN_IGEMM_ALLTAPS")) : 1;
+  p.alltaps = at && p.bm == 16;
+  if (p.alltaps) p.lds = ((size_t)4 * HZ * HY * HX * 4 + (size_t)(p.mode == 3 ? 27 : 9) * 16 * 16) * sizeof(float);
   return true;
 }
 
@@ -68,6 +71,12 @@ template <int MODE>
 static int dispatch_bm(const IGPlan& p, const IGemmArgs& a, hipStream_t s) {
   if (p.bm == 64) { ursn_note_kernel(p.flip ? "igemm_dgrad<64>" : "igemm<64>"); return dispatch_flags<MODE, 64>(p, a, s); }
   if (p.bm == 32) { ursn_note_kernel(p.flip ? "igemm_dgrad<32>" : "igemm<32>"); return dispatch_flags<MODE, 32>(p, a, s); }
+  if (p.alltaps) {
+    ursn_note_kernel(p.flip ? "igemm_at_dgrad<16>" : "igemm_at<16>");
+    if (p.flip) return launch_ig_at<MODE, true, false>(p, a, s);
+    if (a.stats_partial) return launch_ig_at<MODE, false, true>(p, a, s);
+    return launch_ig_at<MODE, false, false>(p, a, s);
+  }
   ursn_note_kernel(p.flip ? "igemm_dgrad<16>" : "igemm<16>");
   return dispatch_flags<MODE, 16>(p, a, s);
 }

@@ -187,13 +187,190 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IGemmArgs a) {
   }
 }
 
+// BM = 16 variant for the deep levels (few boxes, many channels), where the per-tap barrier + dependent weight-tile
+// load of igemm_conv_kernel is pure latency: ALL taps of the 16 x 16 weight slab of a chunk are staged at once
+// (27.6 KB), the next chunk's halo and weights are prefetched into registers during the MFMAs, and the inner loop
+// runs 27 x 16 MFMAs per wave between barriers.
+template <int MODE, bool FLIP, bool STATS>
+__global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
+  using B = IBox<MODE>;
+  constexpr int BZ = B::BZ, BY = B::BY, BX = B::BX, NT = B::NT, KZ = B::KZ;
+  constexpr int HZ = BZ + (KZ - 1), HY = BY + 2, HX = BX + 2, PS = HZ * HY * HX;
+  constexpr int KC = 16, BM = 16;
+  constexpr int NH = (4 * PS + 255) / 256;
+  constexpr int NW = (NT * KC * BM / 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float ilds[];  // [4][PS][4] halo, then [NT][KC][BM] weights
+  float* hal = ilds;
+  float* wl = ilds + 4 * PS * 4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 15, kl = lane >> 4;
+  int bid = blockIdx.x;
+  const int bx = bid % a.nbx; bid /= a.nbx;
+  const int by = bid % a.nby; bid /= a.nby;
+  const int bz = bid % a.nbz;
+  const int n = bid / a.nbz;
+  const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
+  const int co0 = blockIdx.y * BM;
+
+  ig_f32x4 acc[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) acc[v] = (ig_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto load_h = [&](int ci0, ig_f32x4 (&hv)[NH]) {
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int idx = tid + i * 256;
+      const int s = idx >> 2, q = idx & 3;
+      const int hx = s % HX, r = s / HX;
+      const int hy = r % HY, hz = r / HY;
+      const int pz = z0 + hz - (KZ == 3 ? 1 : 0), py = y0 + hy - 1, px = x0 + hx - 1;
+      ig_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < 4 * PS && pz >= 0 && pz < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
+        v = *(const ig_f32x4*)(a.in + ((((size_t)n * a.Z + pz) * a.Y + py) * a.X + px) * a.in_cs + ci0 + 4 * q);
+      hv[i] = v;
+    }
+  };
+  auto store_h = [&](const ig_f32x4 (&hv)[NH]) {
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < 4 * PS) *(ig_f32x4*)(hal + ((size_t)(idx & 3) * PS + (idx >> 2)) * 4) = hv[i];
+    }
+  };
+  // weights: float4 index j of the [NT][16][16] slab; FLIP loads along the contraction (contiguous in memory)
+  auto load_w = [&](int ci0, ig_f32x4 (&wv)[NW]) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int idx = tid + i * 256;
+      ig_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < NT * KC * BM / 4) {
+        const int t = idx / (KC * BM / 4), rem = idx % (KC * BM / 4);
+        if (!FLIP) {
+          const int k = rem / (BM / 4), c4 = (rem % (BM / 4)) * 4;
+          if (co0 + c4 < a.cout) v = *(const ig_f32x4*)(a.w + ((size_t)t * a.cin_w + ci0 + k) * a.cout_w + co0 + c4);
+        } else {
+          const int nn = rem / (KC / 4), k4 = (rem % (KC / 4)) * 4;
+          if (co0 + nn < a.cout) v = *(const ig_f32x4*)(a.w + ((size_t)(NT - 1 - t) * a.cin_w + co0 + nn) * a.cout_w + ci0 + k4);
+        }
+      }
+      wv[i] = v;
+    }
+  };
+  auto store_w = [&](const ig_f32x4 (&wv)[NW]) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < NT * KC * BM / 4) {
+        const int t = idx / (KC * BM / 4), rem = idx % (KC * BM / 4);
+        if (!FLIP) {
+          *(ig_f32x4*)(wl + (size_t)idx * 4) = wv[i];
+        } else {
+          const int nn = rem / (KC / 4), k4 = (rem % (KC / 4)) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) wl[((size_t)t * KC + k4 + j) * BM + nn] = wv[i][j];
+        }
+      }
+    }
+  };
+
+  // halo slot of this lane's voxel for tile v (tap 0,0,0): 3-D (z = wave, y = v), 2-D (y = 4*wave + v)
+  int hb[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int zz = (MODE == 3) ? wave : 0, yb = (MODE == 3) ? v : 4 * wave + v;
+    hb[v] = ((zz * HY + yb) * HX + il) * 4 + kl;
+  }
+  const int wb = kl * BM + il;
+
+  ig_f32x4 hv[NH], wv[NW];
+  const int nchunks = a.cin / KC;
+  load_h(0, hv);
+  load_w(0, wv);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (ch) __syncthreads();
+    store_h(hv);
+    store_w(wv);
+    __syncthreads();
+    if (ch + 1 < nchunks) {
+      load_h((ch + 1) * KC, hv);
+      load_w((ch + 1) * KC, wv);
+    }
+#pragma unroll 3
+    for (int t = 0; t < NT; ++t) {
+      const int tz = (KZ == 3) ? t / 9 : 0, ty = (t / 3) % 3, tx = t % 3;
+      const int toff = ((tz * HY + ty) * HX + tx) * 4;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float av = wl[wb + ((size_t)t * KC + 4 * s) * BM];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float bv = hal[hb[v] + toff + s * PS * 4];
+          acc[v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[v], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // epilogue (as igemm_conv_kernel, MT = 1)
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int gx = x0 + il;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int gz = (MODE == 3) ? z0 + wave : 0;
+    const int gy = (MODE == 3) ? y0 + v : y0 + 4 * wave + v;
+    if (!(gz < a.Z && gy < a.Y && gx < a.X)) continue;
+    const int c = 4 * kl;
+    if (co0 + c >= a.cout) continue;
+    float* op = a.out + ((((size_t)n * a.Z + gz) * a.Y + gy) * a.X + gx) * a.out_cs + co0 + c;
+    ig_f32x4 val = acc[v];
+    if (a.accumulate) val += *(ig_f32x4*)op;
+    *(ig_f32x4*)op = val;
+    if constexpr (STATS) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[r] += val[r]; s2[r] += val[r] * val[r]; }
+    }
+  }
+  if constexpr (STATS) if (a.stats_partial) {
+    __shared__ float red[4][2 * BM];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float u = s1[r], w2 = s2[r];
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
+      if (il == 0) {
+        red[wave][4 * kl + r] = u;
+        red[wave][BM + 4 * kl + r] = w2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BM)
+      a.stats_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * BM + tid] =
+          (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
+  }
+}
+
 struct IGPlan {
+  bool alltaps;   // BM = 16: igemm_at_kernel
   int mode, bm;
   bool flip;
   int Z, Y, X, nbz, nby, nbx;
   size_t lds;
   int gridx, gridy;
 };
+
+template <int MODE, bool FLIP, bool STATS>
+static int launch_ig_at(const IGPlan& p, const IGemmArgs& a, hipStream_t s) {
+  auto kern = igemm_at_kernel<MODE, FLIP, STATS>;
+  static size_t attr_lds = 48 * 1024;
+  if (p.lds > attr_lds) {
+    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    attr_lds = p.lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.gridx, p.gridy), dim3(256), p.lds, s, a);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
 
 template <int MODE, int BM, bool FLIP, bool STATS>
 static int launch_ig(const IGPlan& p, const IGemmArgs& a, hipStream_t s) {
