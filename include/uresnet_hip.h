@@ -149,7 +149,7 @@ typedef struct ursn_conv_desc {
   int32_t transposed;  /* 0: slim.conv{2,3}d SAME; 1: slim.conv{2,3}d_transpose k3 s2 SAME          */
   int32_t in_cstride;  /* channel stride (floats per voxel) of x / dx; 0 = compact (= cin)         */
   int32_t out_cstride; /* channel stride of y / dy; 0 = compact (= cout)                           */
-  int32_t algo;        /* 0 auto, 1 naive reference, 2 gather MFMA, 3 tiled small-C, 4 LDS implicit GEMM, 5 pointwise, 6 LDS stride-2 */
+  int32_t algo;        /* 0 auto, 1 naive reference, 2 gather MFMA, 3 tiled small-C, 4 LDS implicit GEMM, 5 pointwise, 6 LDS stride-2 gather, 7 LDS stride-2 scatter */
   /* Split input (a tf.concat that is never materialised, lib/uresnet.py:81): channels [0,in_split) of the layer input
    * live in x / dx, channels [in_split,cin) in x2 / dx2.  in_split = 0: single tensor.  Only k3 s1 and k1 s1 layers with
    * in_split = cin/2 on the tiled / pointwise kernels; other shapes return an error.                                   */

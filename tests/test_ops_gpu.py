@@ -614,3 +614,47 @@ def test_tiled_dgrad_with_fused_shortcut_term(ndim, S, ci, co, split):
     # the forward pass has no such term: must be refused
     yy = torch.empty(dy.shape, dtype=torch.float32, device="cuda")
     assert lib.ursn_conv_forward(ctypes.byref(d), P(dev(x)), P(wg), P(yy), stream()) != 0
+
+
+@pytest.mark.parametrize("case", [(3, 2, (8, 16, 32), 32, 16), (3, 1, (5, 7, 19), 16, 16), (3, 1, (6, 6, 6), 64, 32),
+                                  (2, 2, (24, 40), 32, 16), (2, 1, (17, 35), 16, 32)])
+def test_lds_scatter_transposed_conv_forward(case):
+    """slim.conv{2,3}d_transpose k3 s2 (lib/uresnet.py:72-79) on the LDS-staged scatter kernel (algo=7) + fused BN stats."""
+    ndim, N, S, ci, co = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (3,) * ndim + (co, ci)) * 0.2
+    y = O.deconv_fwd(x, w)
+    d = desc(ndim, N, S, ci, co, 3, 2, transposed=1, algo=7)
+    xg, wg = dev(x), dev(w)
+    lib = _lib.load()
+    yg = torch.full(y.shape, float("nan"), dtype=torch.float32, device="cuda")
+    mg, rg = torch.empty(co, device="cuda"), torch.empty(co, device="cuda")
+    nb = 1 << 24
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.ursn_conv_forward_stats(ctypes.byref(d), P(xg), P(wg), P(yg), P(mg), P(rg), 1e-3, P(scratch), nb,
+                                           stream()))
+    torch.cuda.synchronize()
+    assert rel_err(yg.cpu().numpy(), y) < TOL
+    ax = tuple(range(y.ndim - 1))
+    assert np.abs(mg.cpu().numpy() - y.mean(axis=ax)).max() < 1e-5 * np.sqrt(y.var(axis=ax).max())
+    assert rel_err(rg.cpu().numpy(), 1 / np.sqrt(y.var(axis=ax) + 1e-3)) < 1e-5
+    assert rel_err(conv_forward(d, xg, wg, y.shape).cpu().numpy(), y) < TOL
+
+
+@pytest.mark.parametrize("case", [(3, 2, (16, 32, 64), 16, 32), (3, 1, (10, 14, 38), 16, 16), (2, 2, (24, 96), 16, 32),
+                                  (3, 1, (12, 12, 12), 32, 64)])
+def test_lds_scatter_stride2_conv_data_gradient(case):
+    """dx of the k3 stride-2 convs (lib/resnet_module.py:43-51) on the LDS-staged scatter kernel, overwrite + accumulate."""
+    ndim, N, S, ci, co = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (3,) * ndim + (ci, co)) * 0.2
+    y = O.conv_fwd(x, w, 2)
+    dy = _rand(rng, y.shape)
+    dx, _ = O.conv_bwd(x, w, 2, dy)
+    d = desc(ndim, N, S, ci, co, 3, 2, algo=7)
+    wg, dyg = dev(w), dev(dy)
+    assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
+    base = torch.ones(x.shape, dtype=torch.float32, device="cuda")
+    assert rel_err(conv_backward_data(d, dyg, wg, x.shape, accumulate=1, dx_init=base).cpu().numpy(), dx + 1.0) < TOL

@@ -246,6 +246,10 @@ int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const
     URSN_REQUIRE(igemm_conv_supported(d, pass), "igemm conv kernel does not support this shape");
     return launch_igemm_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
   }
+  if (d.algo == 7) {
+    URSN_REQUIRE(lds_scatter_supported(d, pass), "LDS scatter conv kernel does not support this shape");
+    return launch_lds_scatter(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
+  }
   if (d.algo == 6) {
     URSN_REQUIRE(stride2_conv_supported(d, pass), "stride-2 conv kernel does not support this shape");
     return launch_stride2_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
@@ -256,6 +260,8 @@ int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const
   if (d.algo == 0 && igemm_conv_supported(d, pass))
     return launch_igemm_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
   if (d.algo == 0 && tiled_conv_supported(d, pass)) return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
+  if (d.algo == 0 && prefer_lds_scatter(d, pass))
+    return launch_lds_scatter(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
   if (d.algo == 0 && tiled_deconv_supported(d, pass))
     return launch_tiled_deconv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
   if (d.algo == 0 && stride2_conv_supported(d, pass))
@@ -297,6 +303,11 @@ extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, 
     URSN_REQUIRE(stride2_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
                  "conv_forward_stats: scratch too small");
     return launch_stride2_conv(*d, PASS_FWD, x, w, y, 0, (double*)scratch, eps, mean, rstd, s);
+  }
+  if ((d->algo == 0 && prefer_lds_scatter(*d, PASS_FWD)) || (d->algo == 7 && lds_scatter_supported(*d, PASS_FWD))) {
+    URSN_REQUIRE(lds_scatter_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
+                 "conv_forward_stats: scratch too small");
+    return launch_lds_scatter(*d, PASS_FWD, x, w, y, 0, (double*)scratch, eps, mean, rstd, s);
   }
   if ((d->algo == 0 || d->algo == 3) && tiled_deconv_supported(*d, PASS_FWD)) {
     URSN_REQUIRE(tiled_deconv_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,

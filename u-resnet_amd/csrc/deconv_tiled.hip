@@ -70,6 +70,12 @@ static bool make_dplan(const ursn_conv_desc& d, ConvPass pass, TDPlan& p, DBlock
   return p.lds <= 160 * 1024;
 }
 
+int tiled_deconv_blocks(const ursn_conv_desc& d, ConvPass pass) {  // launches the tiled kernel needs (0 = unsupported)
+  TDPlan p;
+  DBlocking b;
+  return make_dplan(d, pass, p, b) ? b.nbk * b.nbp : 0;
+}
+
 int tiled_deconv_supported(const ursn_conv_desc& d, ConvPass pass) {
   TDPlan p;
   DBlocking b;

@@ -287,6 +287,8 @@ int plan(ursn_net* n, Arena& A) {
     if (rt > red) red = rt;
     rt = stride2_stats_scratch_doubles(L.desc) * sizeof(double);
     if (rt > red) red = rt;
+    rt = lds_scatter_stats_scratch_doubles(L.desc) * sizeof(double);
+    if (rt > red) red = rt;
     if (tr) {
       size_t w = ursn_conv_wgrad_scratch_bytes(&L.desc);
       if (w > wg) wg = w;
@@ -365,6 +367,13 @@ int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s, const A
     ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
     URSN_TRY(launch_stride2_conv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)n->red_scratch,
                                  n->cfg.bn_eps, L.mean, L.rstd, s));
+    ps.done(ursn_last_kernel_name());
+    return 0;
+  }
+  if (prefer_lds_scatter(d, PASS_FWD)) {  // LDS-staged transposed conv + BN-statistics partials in one pass
+    ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
+    URSN_TRY(launch_lds_scatter(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)n->red_scratch,
+                                n->cfg.bn_eps, L.mean, L.rstd, s));
     ps.done(ursn_last_kernel_name());
     return 0;
   }

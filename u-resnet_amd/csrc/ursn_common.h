@@ -139,6 +139,16 @@ int tiled_deconv_supported(const ursn_conv_desc& d, ConvPass pass);
 size_t tiled_deconv_stats_scratch_doubles(const ursn_conv_desc& d);
 int launch_tiled_deconv(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
                         int accumulate, double* stats_partial, float eps, float* mean, float* rstd, hipStream_t s);
+int tiled_deconv_blocks(const ursn_conv_desc& d, ConvPass pass);
+// LDS-staged stride-2 scatter-type conv for channel counts that are multiples of 16 (deconv_lds.hip)
+int lds_scatter_supported(const ursn_conv_desc& d, ConvPass pass);
+size_t lds_scatter_stats_scratch_doubles(const ursn_conv_desc& d);
+int launch_lds_scatter(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
+                       int accumulate, double* stats_partial, float eps, float* mean, float* rstd, hipStream_t s);
+// the LDS kernel takes over where the lane-per-voxel kernel would need several channel-block launches or does not apply
+static inline bool prefer_lds_scatter(const ursn_conv_desc& d, ConvPass pass) {
+  return lds_scatter_supported(d, pass) && tiled_deconv_blocks(d, pass) != 1;
+}
 int launch_reduce_accum_blocked(float* dst, const float* src, int taps, int rows, int cols, int64_t dst_tap_stride,
                                 int dst_row_stride, int nchunks, hipStream_t s);
 // y = act(bn(z) [+ bn(z2) | + res]); any of z2/res may be null.
