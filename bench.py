@@ -193,7 +193,7 @@ def main():
         le = by_layer.setdefault((r.layer.decode(), r.pass_, k), [0.0, r.flops, r.bytes])
         le[0] += r.ms
         e = by_kernel.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, conv=r.pass_ <= 2))
-        e["ms"] += r.ms; e["flops"] += r.flops; e["bytes"] += r.bytes; e["launches"] += 1
+        e["ms"] += r.ms; e["flops"] += r.flops; e["bytes"] += r.bytes; e["launches"] += max(int(r.launches), 1)
         all_ms += r.ms
         if r.pass_ <= 2:
             t_roof_ms += max(r.flops / (PEAK_FP32_TFLOPS * 1e9), r.bytes / (PEAK_HBM_GBS * 1e6))

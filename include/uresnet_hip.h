@@ -128,6 +128,8 @@ typedef struct ursn_prof_rec {
   float ms;
   double flops; /* algorithmic: 2*MACs of the layer */
   double bytes; /* algorithmic: x + y + w (fwd), dy + w + dx (dgrad), x + dy + dw (wgrad) */
+  int32_t launches; /* launches of the named kernel inside this record (channel-block / split-input passes) */
+  int32_t reserved_;
 } ursn_prof_rec;
 int ursn_profile_enable(ursn_net* net, int32_t on);
 /* out == NULL: only counts.  Otherwise fills up to max_recs records and clears the log. */

@@ -33,7 +33,7 @@ class ursn_conv_desc(C.Structure):
 
 class ursn_prof_rec(C.Structure):
     _fields_ = [("kernel", C.c_char * 48), ("layer", C.c_char * 96), ("pass_", C.c_int32), ("ms", C.c_float),
-                ("flops", C.c_double), ("bytes", C.c_double)]
+                ("flops", C.c_double), ("bytes", C.c_double), ("launches", C.c_int32), ("reserved_", C.c_int32)]
 
 
 _P = C.c_void_p

@@ -14,7 +14,10 @@ void ursn_set_error(const char* fmt, ...) {
 }
 extern "C" const char* ursn_last_error(void) { return g_err; }
 static thread_local const char* g_kernel = "";
-void ursn_note_kernel(const char* name) { g_kernel = name; }
+static long g_kernel_launches = 0;
+void ursn_note_kernel(const char* name) { g_kernel = name; ++g_kernel_launches; }   // one call per main-kernel launch
+void ursn_relabel_kernel(const char* name) { g_kernel = name; }
+long ursn_kernel_launch_count() { return g_kernel_launches; }
 extern "C" const char* ursn_last_kernel_name() { return g_kernel; }
 extern "C" int ursn_abi_version(void) { return URSN_ABI_VERSION; }
 

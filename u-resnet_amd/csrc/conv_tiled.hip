@@ -149,8 +149,8 @@ static int launch_blocks(const ursn_conv_desc& d, const TPlan& p, const Blocking
         URSN_TRY(launch_bn_stats_final(stats_partial, p.grid, cb, p.cout, V, eps, mean + b.bsz * bo, rstd + b.bsz * bo, s));
       }
     }
-  if (b.split) ursn_note_kernel(p.flip ? "tconv_dgrad x2(split)" : "tconv x2(split)");
-  else if (b.nbi > 1 || b.nbo > 1) ursn_note_kernel(p.flip ? "tconv_dgrad<16,16>xB" : "tconv<16,16>xB");
+  if (b.split) ursn_relabel_kernel(p.flip ? "tconv_dgrad x2(split)" : "tconv x2(split)");
+  else if (b.nbi > 1 || b.nbo > 1) ursn_relabel_kernel(p.flip ? "tconv_dgrad<16,16>xB" : "tconv<16,16>xB");
   return 0;
 }
 
@@ -288,6 +288,6 @@ int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy,
       URSN_TRY(launch_reduce_accum_blocked(dw + (size_t)16 * bi * d.cout + 16 * bo, (const float*)scratch, taps, 16, 16,
                                            (int64_t)d.cin * d.cout, d.cout, p.grid, s));
     }
-  ursn_note_kernel("twgrad<16,16>xB");
+  ursn_relabel_kernel("twgrad<16,16>xB");
   return 0;
 }

@@ -118,6 +118,6 @@ int launch_tiled_deconv(const ursn_conv_desc& d, ConvPass pass, const float* in,
       if (stats_partial && last)
         URSN_TRY(launch_bn_stats_final(stats_partial, p.grid, b.pb, b.pb, V, eps, mean + b.pb * bp, rstd + b.pb * bp, s));
     }
-  if (b.nbk > 1 || b.nbp > 1) ursn_note_kernel("tdeconv xB");
+  if (b.nbk > 1 || b.nbp > 1) ursn_relabel_kernel("tdeconv xB");
   return 0;
 }

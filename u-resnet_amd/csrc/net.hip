@@ -83,7 +83,7 @@ struct ursn_net {
   int last_n = 0;
   // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
   bool profile = false;
-  struct ProfRec { int layer; int pass; const char* kernel; double flops; double bytes; hipEvent_t e0, e1; };
+  struct ProfRec { int layer; int pass; const char* kernel; double flops; double bytes; hipEvent_t e0, e1; long l0; int launches; };
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -319,7 +319,7 @@ struct ProfScope {
   ursn_net* n; hipStream_t s; int idx = -1;
   ProfScope(ursn_net* n_, hipStream_t s_, int layer, int pass, double flops, double bytes) : n(n_), s(s_) {
     if (!n->profile || n->prof.size() > 200000) return;
-    ursn_net::ProfRec r{layer, pass, "", flops, bytes, prof_event(n), prof_event(n)};
+    ursn_net::ProfRec r{layer, pass, "", flops, bytes, prof_event(n), prof_event(n), ursn_kernel_launch_count(), 1};
     if (!r.e0 || !r.e1) return;
     hipEventRecord(r.e0, s);
     n->prof.push_back(r);
@@ -328,6 +328,8 @@ struct ProfScope {
   void done(const char* kernel) {
     if (idx < 0) return;
     n->prof[idx].kernel = kernel;
+    long nl = ursn_kernel_launch_count() - n->prof[idx].l0;
+    n->prof[idx].launches = nl > 0 ? (int)nl : 1;   // elementwise scopes do not note their kernels: one launch
     hipEventRecord(n->prof[idx].e1, s);
   }
 };
@@ -497,7 +499,7 @@ ursn_conv_desc bwd_desc(ursn_net* n, int li, const Act& in, int N, const Act* in
 }
 
 int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStream_t s, const Act* in2 = nullptr,
-             int fused_sc = -1) {
+             int fused_sc = -1, bool dgrad_done_elsewhere = false) {
   Layer& L = n->layers[li];
   ursn_conv_desc d = bwd_desc(n, li, in, N, in2, -1);
   hipStream_t ws = s;
@@ -515,6 +517,10 @@ int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStre
   ProfScope ps(n, ws, li, 2, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
   URSN_TRY(wgrad_dispatch(d, in.p, L.dz, n->grads + L.w_off, n->wg_scratch, n->wg_scratch_bytes, ws));
   ps.done(ursn_last_kernel_name());
+  if (dgrad_done_elsewhere) {  // keeps the per-layer roofline accounting (bench.py) complete: the work ran inside conv1's kernel
+    ProfScope pd(n, s, li, 1, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
+    pd.done("(fused into conv1 dgrad)");
+  }
   if (need_dgrad) {
     bool acc = take_flag(n, in);
     if (in2) URSN_REQUIRE(take_flag(n, *in2) == acc, "split input: the two halves disagree on gradient initialisation");
@@ -567,7 +573,7 @@ int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
     fuse = !off && tiled_conv_supported(d, PASS_DGRAD) && !igemm_conv_supported(d0, PASS_DGRAD);   // only where conv1's dgrad is tiled anyway
   }
   URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, in2, fuse ? u.sc : -1));
-  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, !fuse, N, s, in2));
+  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, !fuse, N, s, in2, -1, fuse));
   return 0;
 }
 
@@ -852,7 +858,7 @@ extern "C" int ursn_profile_read(ursn_net* net, ursn_prof_rec* out, int64_t max_
       memset(&o, 0, sizeof(o));
       snprintf(o.kernel, sizeof(o.kernel), "%s", r.kernel);
       snprintf(o.layer, sizeof(o.layer), "%s", net->layers[r.layer].name.c_str());
-      o.pass = r.pass; o.ms = ms; o.flops = r.flops; o.bytes = r.bytes;
+      o.pass = r.pass; o.ms = ms; o.flops = r.flops; o.bytes = r.bytes; o.launches = r.launches;
     }
     ++cnt;
   }

@@ -8,6 +8,8 @@
 
 void ursn_set_error(const char* fmt, ...);
 void ursn_note_kernel(const char* name);  // remembered per thread for the profiling log
+void ursn_relabel_kernel(const char* name);   // rename the last dispatch without counting a launch
+long ursn_kernel_launch_count();
 
 #define URSN_HIP(expr)                                                                   \
   do {                                                                                   \
