@@ -42,8 +42,11 @@ static bool make_igplan(const ursn_conv_desc& d, ConvPass pass, IGPlan& p, int& 
   const int HZ = p.mode == 3 ? 6 : 1, HY = BY + 2, HX = BX + 2;
   p.lds = ((size_t)4 * HZ * HY * HX * 4 + (size_t)2 * 16 * (p.bm + 16)) * sizeof(float);
   static const int at = getenv("URSN_IGEMM_ALLTAPS") ? atoi(getenv("URSN_IGEMM_ALLTAPS")) : 1;
-  p.alltaps = at && p.bm == 16;
-  if (p.alltaps) p.lds = ((size_t)4 * HZ * HY * HX * 4 + (size_t)(p.mode == 3 ? 27 : 9) * 16 * 16) * sizeof(float);
+  p.alltaps = (at && p.bm == 16) || (at >= 1 && at != 16 && p.bm == 32);   // URSN_IGEMM_ALLTAPS: 0 off, 16 only BM=16, 1 both
+  if (p.alltaps) {
+    const int kc = p.bm == 16 ? 16 : 8;
+    p.lds = ((size_t)(kc / 4) * HZ * HY * HX * 4 + (size_t)(p.mode == 3 ? 27 : 9) * kc * p.bm) * sizeof(float);
+  }
   return true;
 }
 
@@ -70,12 +73,18 @@ static int dispatch_flags(const IGPlan& p, const IGemmArgs& a, hipStream_t s) {
 template <int MODE>
 static int dispatch_bm(const IGPlan& p, const IGemmArgs& a, hipStream_t s) {
   if (p.bm == 64) { ursn_note_kernel(p.flip ? "igemm_dgrad<64>" : "igemm<64>"); return dispatch_flags<MODE, 64>(p, a, s); }
+  if (p.bm == 32 && p.alltaps) {
+    ursn_note_kernel(p.flip ? "igemm_at_dgrad<32>" : "igemm_at<32>");
+    if (p.flip) return launch_ig_at<MODE, 32, 8, true, false>(p, a, s);
+    if (a.stats_partial) return launch_ig_at<MODE, 32, 8, false, true>(p, a, s);
+    return launch_ig_at<MODE, 32, 8, false, false>(p, a, s);
+  }
   if (p.bm == 32) { ursn_note_kernel(p.flip ? "igemm_dgrad<32>" : "igemm<32>"); return dispatch_flags<MODE, 32>(p, a, s); }
   if (p.alltaps) {
     ursn_note_kernel(p.flip ? "igemm_at_dgrad<16>" : "igemm_at<16>");
-    if (p.flip) return launch_ig_at<MODE, true, false>(p, a, s);
-    if (a.stats_partial) return launch_ig_at<MODE, false, true>(p, a, s);
-    return launch_ig_at<MODE, false, false>(p, a, s);
+    if (p.flip) return launch_ig_at<MODE, 16, 16, true, false>(p, a, s);
+    if (a.stats_partial) return launch_ig_at<MODE, 16, 16, false, true>(p, a, s);
+    return launch_ig_at<MODE, 16, 16, false, false>(p, a, s);
   }
   ursn_note_kernel(p.flip ? "igemm_dgrad<16>" : "igemm<16>");
   return dispatch_flags<MODE, 16>(p, a, s);

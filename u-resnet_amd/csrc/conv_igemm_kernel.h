@@ -187,21 +187,23 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IGemmArgs a) {
   }
 }
 
-// BM = 16 variant for the deep levels (few boxes, many channels), where the per-tap barrier + dependent weight-tile
-// load of igemm_conv_kernel is pure latency: ALL taps of the 16 x 16 weight slab of a chunk are staged at once
-// (27.6 KB), the next chunk's halo and weights are prefetched into registers during the MFMAs, and the inner loop
-// runs 27 x 16 MFMAs per wave between barriers.
-template <int MODE, bool FLIP, bool STATS>
+// All-taps variant (BM = 16 with 16-channel chunks, BM = 32 with 8-channel chunks): the per-tap barrier + dependent
+// weight-tile load of igemm_conv_kernel is latency the MFMAs cannot hide when there are few boxes or narrow co tiles.
+// Here ALL taps of the KC x BM weight slab of a chunk are staged at once (27.6 KB, one 16-column plane per co tile ->
+// conflict-free operand reads), the next chunk's halo and weights are prefetched into registers during the MFMAs, and
+// the inner loop runs 27 x 16 MFMAs per wave between barriers.
+template <int MODE, int BM, int KC, bool FLIP, bool STATS>
 __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
   using B = IBox<MODE>;
   constexpr int BZ = B::BZ, BY = B::BY, BX = B::BX, NT = B::NT, KZ = B::KZ;
   constexpr int HZ = BZ + (KZ - 1), HY = BY + 2, HX = BX + 2, PS = HZ * HY * HX;
-  constexpr int KC = 16, BM = 16;
-  constexpr int NH = (4 * PS + 255) / 256;
-  constexpr int NW = (NT * KC * BM / 4 + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) float ilds[];  // [4][PS][4] halo, then [NT][KC][BM] weights
+  constexpr int MT = BM / 16, NQ = KC / 4;
+  constexpr int NH = (NQ * PS + 255) / 256;
+  constexpr int NWF = NT * KC * BM / 4;          // float4 of the weight slab
+  constexpr int NW = (NWF + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float ilds[];  // [NQ][PS][4] halo, then [MT][NT][KC][16] weights
   float* hal = ilds;
-  float* wl = ilds + 4 * PS * 4;
+  float* wl = ilds + NQ * PS * 4;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int il = lane & 15, kl = lane >> 4;
@@ -213,20 +215,22 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
   const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
   const int co0 = blockIdx.y * BM;
 
-  ig_f32x4 acc[4];
+  ig_f32x4 acc[4][MT];
 #pragma unroll
-  for (int v = 0; v < 4; ++v) acc[v] = (ig_f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[v][m] = (ig_f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto load_h = [&](int ci0, ig_f32x4 (&hv)[NH]) {
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
       const int idx = tid + i * 256;
-      const int s = idx >> 2, q = idx & 3;
+      const int s = idx / NQ, q = idx % NQ;
       const int hx = s % HX, r = s / HX;
       const int hy = r % HY, hz = r / HY;
       const int pz = z0 + hz - (KZ == 3 ? 1 : 0), py = y0 + hy - 1, px = x0 + hx - 1;
       ig_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < 4 * PS && pz >= 0 && pz < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
+      if (idx < NQ * PS && pz >= 0 && pz < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
         v = *(const ig_f32x4*)(a.in + ((((size_t)n * a.Z + pz) * a.Y + py) * a.X + px) * a.in_cs + ci0 + 4 * q);
       hv[i] = v;
     }
@@ -235,16 +239,16 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
       const int idx = tid + i * 256;
-      if (idx < 4 * PS) *(ig_f32x4*)(hal + ((size_t)(idx & 3) * PS + (idx >> 2)) * 4) = hv[i];
+      if (idx < NQ * PS) *(ig_f32x4*)(hal + ((size_t)(idx % NQ) * PS + idx / NQ) * 4) = hv[i];
     }
   };
-  // weights: float4 index j of the [NT][16][16] slab; FLIP loads along the contraction (contiguous in memory)
+  // weights: float4 index of the [NT][KC][BM] slab; FLIP loads along the contraction (contiguous in memory)
   auto load_w = [&](int ci0, ig_f32x4 (&wv)[NW]) {
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       const int idx = tid + i * 256;
       ig_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < NT * KC * BM / 4) {
+      if (idx < NWF) {
         const int t = idx / (KC * BM / 4), rem = idx % (KC * BM / 4);
         if (!FLIP) {
           const int k = rem / (BM / 4), c4 = (rem % (BM / 4)) * 4;
@@ -261,14 +265,15 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       const int idx = tid + i * 256;
-      if (idx < NT * KC * BM / 4) {
+      if (idx < NWF) {
         const int t = idx / (KC * BM / 4), rem = idx % (KC * BM / 4);
         if (!FLIP) {
-          *(ig_f32x4*)(wl + (size_t)idx * 4) = wv[i];
+          const int k = rem / (BM / 4), c4 = (rem % (BM / 4)) * 4;
+          *(ig_f32x4*)(wl + ((((size_t)(c4 >> 4) * NT + t) * KC + k) * 16 + (c4 & 15))) = wv[i];
         } else {
           const int nn = rem / (KC / 4), k4 = (rem % (KC / 4)) * 4;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) wl[((size_t)t * KC + k4 + j) * BM + nn] = wv[i][j];
+          for (int j = 0; j < 4; ++j) wl[(((size_t)(nn >> 4) * NT + t) * KC + k4 + j) * 16 + (nn & 15)] = wv[i][j];
         }
       }
     }
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
     const int zz = (MODE == 3) ? wave : 0, yb = (MODE == 3) ? v : 4 * wave + v;
     hb[v] = ((zz * HY + yb) * HX + il) * 4 + kl;
   }
-  const int wb = kl * BM + il;
+  const int wb = kl * 16 + il;
 
   ig_f32x4 hv[NH], wv[NW];
   const int nchunks = a.cin / KC;
@@ -301,48 +306,60 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
       const int tz = (KZ == 3) ? t / 9 : 0, ty = (t / 3) % 3, tx = t % 3;
       const int toff = ((tz * HY + ty) * HX + tx) * 4;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float av = wl[wb + ((size_t)t * KC + 4 * s) * BM];
+      for (int s = 0; s < NQ; ++s) {
+        float av[MT], bv[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const float bv = hal[hb[v] + toff + s * PS * 4];
-          acc[v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[v], 0, 0, 0);
-        }
+        for (int m = 0; m < MT; ++m) av[m] = wl[wb + (((size_t)m * NT + t) * KC + 4 * s) * 16];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) bv[v] = hal[hb[v] + toff + s * PS * 4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[v][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[v], acc[v][m], 0, 0, 0);
       }
     }
   }
 
-  // epilogue (as igemm_conv_kernel, MT = 1)
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  // epilogue (as igemm_conv_kernel)
+  float s1[MT][4], s2[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
   const int gx = x0 + il;
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int gz = (MODE == 3) ? z0 + wave : 0;
     const int gy = (MODE == 3) ? y0 + v : y0 + 4 * wave + v;
     if (!(gz < a.Z && gy < a.Y && gx < a.X)) continue;
-    const int c = 4 * kl;
-    if (co0 + c >= a.cout) continue;
-    float* op = a.out + ((((size_t)n * a.Z + gz) * a.Y + gy) * a.X + gx) * a.out_cs + co0 + c;
-    ig_f32x4 val = acc[v];
-    if (a.accumulate) val += *(ig_f32x4*)op;
-    *(ig_f32x4*)op = val;
-    if constexpr (STATS) {
+    float* op = a.out + ((((size_t)n * a.Z + gz) * a.Y + gy) * a.X + gx) * a.out_cs + co0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[r] += val[r]; s2[r] += val[r] * val[r]; }
+    for (int m = 0; m < MT; ++m) {
+      const int c = 16 * m + 4 * kl;
+      if (co0 + c >= a.cout) continue;
+      ig_f32x4 val = acc[v][m];
+      if (a.accumulate) val += *(ig_f32x4*)(op + c);
+      *(ig_f32x4*)(op + c) = val;
+      if constexpr (STATS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[m][r] += val[r]; s2[m][r] += val[r] * val[r]; }
+      }
     }
   }
   if constexpr (STATS) if (a.stats_partial) {
     __shared__ float red[4][2 * BM];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float u = s1[r], w2 = s2[r];
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int o = 8; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
-      if (il == 0) {
-        red[wave][4 * kl + r] = u;
-        red[wave][BM + 4 * kl + r] = w2;
+      for (int r = 0; r < 4; ++r) {
+        float u = s1[m][r], w2 = s2[m][r];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
+        if (il == 0) {
+          red[wave][16 * m + 4 * kl + r] = u;
+          red[wave][BM + 16 * m + 4 * kl + r] = w2;
+        }
       }
-    }
     __syncthreads();
     if (tid < 2 * BM)
       a.stats_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * BM + tid] =
@@ -351,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
 }
 
 struct IGPlan {
-  bool alltaps;   // BM = 16: igemm_at_kernel
+  bool alltaps;   // BM = 16 | 32: igemm_at_kernel
   int mode, bm;
   bool flip;
   int Z, Y, X, nbz, nby, nbx;
@@ -359,9 +376,9 @@ struct IGPlan {
   int gridx, gridy;
 };
 
-template <int MODE, bool FLIP, bool STATS>
+template <int MODE, int BM, int KC, bool FLIP, bool STATS>
 static int launch_ig_at(const IGPlan& p, const IGemmArgs& a, hipStream_t s) {
-  auto kern = igemm_at_kernel<MODE, FLIP, STATS>;
+  auto kern = igemm_at_kernel<MODE, BM, KC, FLIP, STATS>;
   static size_t attr_lds = 48 * 1024;
   if (p.lds > attr_lds) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
