@@ -55,75 +55,91 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(IGWArgs a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[i][m] = (iw_f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // this wave's taps: halo-slot offset of the tap shift
-  int t_off[TPW];
-  bool t_ok[TPW];
+  // this wave's taps: halo-slot offset of the tap shift.  A tap index past the last one (wave 3 holds 6 of its 7
+  // slots) reads tap 0's (finite) data; its accumulator is never written out.
+  int abase[TPW];
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
     int t = SPLITK ? i : wave * TPW + i;
-    t_ok[i] = t < NT;
-    if (!t_ok[i]) t = 0;
+    if (t >= NT) t = 0;
     int tz = (KZ == 3) ? t / 9 : 0, ty = (t / 3) % 3, tx = t % 3;
-    t_off[i] = (tz * HY + ty) * HX + tx;
+    abase[i] = ((il >> 2) * PSP + kl) * 4 + (il & 3) + ((tz * HY + ty) * HX + tx + (SPLITK ? 4 * wave : 0)) * 4;
   }
-  const int a_lane = ((il >> 2) * PSP + kl) * 4 + (il & 3);   // + (halo slot of quad start + tap offset)*4
-  const int b_lane = ((il >> 2) * DSP + kl) * 4 + (il & 3);   // + (m*4*DSP + voxel slot of quad start)*4
+  const int b_lane = ((il >> 2) * DSP + kl + (SPLITK ? 4 * wave : 0)) * 4 + (il & 3);   // + (m*4*DSP + voxel slot of quad start)*4
 
-  const int box_begin = blockIdx.x * a.boxes_per_group;
-  int box_end = box_begin + a.boxes_per_group;
-  if (box_end > a.nboxes) box_end = a.nboxes;
-  for (int box = box_begin; box < box_end; ++box) {
+  // staging in two phases (loads of box b+1 are in flight during the MFMAs of box b)
+  auto load_box = [&](int box, iw_f32x4 (&xv)[NHX], iw_f32x4 (&dv)[NHD]) {
     int bid = box;
     const int bx = bid % a.nbx; bid /= a.nbx;
     const int by = bid % a.nby; bid /= a.nby;
     const int bz = bid % a.nbz;
     const int n = bid / a.nbz;
     const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
-    __syncthreads();
 #pragma unroll
     for (int i = 0; i < NHX; ++i) {
-      int idx = tid + i * 256;
-      if (idx < 4 * PS) {
-        int s = idx >> 2, q = idx & 3;
-        int hx = s % HX, r = s / HX;
-        int hy = r % HY, hz = r / HY;
-        int pz = z0 + hz - (KZ == 3 ? 1 : 0), py = y0 + hy - 1, px = x0 + hx - 1;
-        iw_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pz >= 0 && pz < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
-          v = *(const iw_f32x4*)(a.x + ((((size_t)n * a.Z + pz) * a.Y + py) * a.X + px) * a.x_cs + ci0 + 4 * q);
-        *(iw_f32x4*)(xl + ((size_t)q * PSP + s) * 4) = v;
-      }
+      const int idx = tid + i * 256;
+      const int s = idx >> 2, q = idx & 3;
+      const int hx = s % HX, r = s / HX;
+      const int hy = r % HY, hz = r / HY;
+      const int pz = z0 + hz - (KZ == 3 ? 1 : 0), py = y0 + hy - 1, px = x0 + hx - 1;
+      iw_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < 4 * PS && pz >= 0 && pz < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
+        v = *(const iw_f32x4*)(a.x + ((((size_t)n * a.Z + pz) * a.Y + py) * a.X + px) * a.x_cs + ci0 + 4 * q);
+      xv[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < NHD; ++i) {
-      int idx = tid + i * 256;
-      if (idx < BN / 4 * DS) {
-        int s = idx / (BN / 4), q = idx % (BN / 4);
-        int vx = s % BX, r = s / BX;
-        int vy = r % BY, vz = r / BY;
-        int pz = z0 + vz, py = y0 + vy, px = x0 + vx;
-        iw_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (pz < a.Z && py < a.Y && px < a.X)
-          v = *(const iw_f32x4*)(a.dz + ((((size_t)n * a.Z + pz) * a.Y + py) * a.X + px) * a.dz_cs + co0 + 4 * q);
-        *(iw_f32x4*)(dl + ((size_t)q * DSP + s) * 4) = v;
-      }
+      const int idx = tid + i * 256;
+      const int s = idx / (BN / 4), q = idx % (BN / 4);
+      const int vx = s % BX, r = s / BX;
+      const int vy = r % BY, vz = r / BY;
+      const int pz = z0 + vz, py = y0 + vy, px = x0 + vx;
+      iw_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < BN / 4 * DS && pz < a.Z && py < a.Y && px < a.X)
+        v = *(const iw_f32x4*)(a.dz + ((((size_t)n * a.Z + pz) * a.Y + py) * a.X + px) * a.dz_cs + co0 + 4 * q);
+      dv[i] = v;
     }
+  };
+  auto store_box = [&](const iw_f32x4 (&xv)[NHX], const iw_f32x4 (&dv)[NHD]) {
+#pragma unroll
+    for (int i = 0; i < NHX; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < 4 * PS) *(iw_f32x4*)(xl + ((size_t)(idx & 3) * PSP + (idx >> 2)) * 4) = xv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NHD; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < BN / 4 * DS) *(iw_f32x4*)(dl + ((size_t)(idx % (BN / 4)) * DSP + idx / (BN / 4)) * 4) = dv[i];
+    }
+  };
+
+  const int box_begin = blockIdx.x * a.boxes_per_group;
+  int box_end = box_begin + a.boxes_per_group;
+  if (box_end > a.nboxes) box_end = a.nboxes;
+  iw_f32x4 xv[NHX], dv[NHD];
+  if (box_begin < box_end) load_box(box_begin, xv, dv);
+  for (int box = box_begin; box < box_end; ++box) {
     __syncthreads();
-#pragma unroll 4
-    for (int ks = SPLITK ? wave : 0; ks < 64; ks += SPLITK ? 4 : 1) {   // voxel quads: row = ks >> 2, x = 4*(ks & 3)
-      const int row = ks >> 2, xq = (ks & 3) * 4;
+    store_box(xv, dv);
+    __syncthreads();
+    if (box + 1 < box_end) load_box(box + 1, xv, dv);
+    // 3-D: every wave sweeps the 16 rows x 4 quads of the box for its taps; 2-D (SPLITK): wave w takes quad w of every row
+#pragma unroll 2
+    for (int row = 0; row < BZ * BY; ++row) {
       const int vz = (MODE == 3) ? row / BY : 0, vy = (MODE == 3) ? row % BY : row;
-      const int hs = (vz * HY + vy) * HX + xq;             // halo slot of the quad's first voxel (tap 0,0,0)
-      const int vs = row * BX + xq;
-      float bv[MT];
+      const float* xr = xl + ((vz * HY + vy) * HX) * 4;
+      const float* dr = dl + (row * BX) * 4;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) bv[m] = dl[b_lane + ((size_t)m * 4 * DSP + vs) * 4];
+      for (int qx = 0; qx < (SPLITK ? 1 : 4); ++qx) {
+        float bv[MT];
 #pragma unroll
-      for (int i = 0; i < TPW; ++i) {
-        float av = xl[a_lane + (hs + t_off[i]) * 4];
-        if (!t_ok[i]) av = 0.f;
+        for (int m = 0; m < MT; ++m) bv[m] = dr[b_lane + ((size_t)m * 4 * DSP + 4 * qx) * 4];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[m], acc[i][m], 0, 0, 0);
+        for (int i = 0; i < TPW; ++i) {
+          const float av = xr[abase[i] + 16 * qx];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[m], acc[i][m], 0, 0, 0);
+        }
       }
     }
   }
