@@ -27,21 +27,27 @@ static bool make_igplan(const ursn_conv_desc& d, ConvPass pass, IGPlan& p, int& 
   p.mode = d.ndim;
   if (d.ndim == 3) { p.Z = d.in_sp[0]; p.Y = d.in_sp[1]; p.X = d.in_sp[2]; }
   else { p.Z = 1; p.Y = d.in_sp[0]; p.X = d.in_sp[1]; }
-  static const int min_x = getenv("URSN_IGEMM_MINX") ? atoi(getenv("URSN_IGEMM_MINX")) : 12;
-  if (p.X < min_x && d.algo != 4) return false;  // 16-wide x tiles: below that the gather kernel wastes less
-  const int BZ = p.mode == 3 ? 4 : 1, BY = p.mode == 3 ? 4 : 16, BX = 16;
+  static const int min_x = getenv("URSN_IGEMM_MINX") ? atoi(getenv("URSN_IGEMM_MINX")) : 5;
+  if (p.X < min_x && d.algo != 4) return false;  // below that the gather kernel wastes less
+  static const int at = getenv("URSN_IGEMM_ALLTAPS") ? atoi(getenv("URSN_IGEMM_ALLTAPS")) : 1;
+  // small deep levels (3-D): boxes of 4x4x12 / 3x6x6 voxels with a per-lane voxel table (all-taps kernel, BM = 16)
+  p.var = 0;
+  if (at && p.mode == 3 && p.X <= 12) p.var = (p.X <= 6) ? 2 : 1;
+  if (p.X < 12 && !p.var && d.algo != 4) return false;
+  const int BZ = p.mode == 3 ? (p.var == 2 ? 3 : 4) : 1, BY = p.mode == 3 ? (p.var == 2 ? 6 : 4) : 16,
+            BX = p.var == 2 ? 6 : (p.var == 1 ? 12 : 16);
   p.nbz = (p.Z + BZ - 1) / BZ;
   p.nby = (p.Y + BY - 1) / BY;
   p.nbx = (p.X + BX - 1) / BX;
   p.gridx = d.n * p.nbz * p.nby * p.nbx;
   // wide cout tiles reuse the staged input more, narrow ones give the small deep levels enough workgroups
-  if (kcout >= 64 && p.gridx >= 512) p.bm = 64;
+  if (p.var) p.bm = 16;
+  else if (kcout >= 64 && p.gridx >= 512) p.bm = 64;
   else if (kcout >= 32 && (int64_t)p.gridx * (kcout / 32) >= 384) p.bm = 32;
   else p.bm = 16;
   p.gridy = (kcout + p.bm - 1) / p.bm;
-  const int HZ = p.mode == 3 ? 6 : 1, HY = BY + 2, HX = BX + 2;
+  const int HZ = p.mode == 3 ? BZ + 2 : 1, HY = BY + 2, HX = BX + 2;
   p.lds = ((size_t)4 * HZ * HY * HX * 4 + (size_t)2 * 16 * (p.bm + 16)) * sizeof(float);
-  static const int at = getenv("URSN_IGEMM_ALLTAPS") ? atoi(getenv("URSN_IGEMM_ALLTAPS")) : 1;
   p.alltaps = (at && p.bm == 16) || (at >= 1 && at != 16 && p.bm == 32);   // URSN_IGEMM_ALLTAPS: 0 off, 16 only BM=16, 1 both
   if (p.alltaps) {
     const int kc = p.bm == 16 ? 16 : 8;
@@ -82,6 +88,18 @@ static int dispatch_bm(const IGPlan& p, const IGemmArgs& a, hipStream_t s) {
   if (p.bm == 32) { ursn_note_kernel(p.flip ? "igemm_dgrad<32>" : "igemm<32>"); return dispatch_flags<MODE, 32>(p, a, s); }
   if (p.alltaps) {
     ursn_note_kernel(p.flip ? "igemm_at_dgrad<16>" : "igemm_at<16>");
+    if constexpr (MODE == 3) {
+      if (p.var == 1) {
+        if (p.flip) return launch_ig_at<3, 16, 16, true, false, 1>(p, a, s);
+        if (a.stats_partial) return launch_ig_at<3, 16, 16, false, true, 1>(p, a, s);
+        return launch_ig_at<3, 16, 16, false, false, 1>(p, a, s);
+      }
+      if (p.var == 2) {
+        if (p.flip) return launch_ig_at<3, 16, 16, true, false, 2>(p, a, s);
+        if (a.stats_partial) return launch_ig_at<3, 16, 16, false, true, 2>(p, a, s);
+        return launch_ig_at<3, 16, 16, false, false, 2>(p, a, s);
+      }
+    }
     if (p.flip) return launch_ig_at<MODE, 16, 16, true, false>(p, a, s);
     if (a.stats_partial) return launch_ig_at<MODE, 16, 16, false, true>(p, a, s);
     return launch_ig_at<MODE, 16, 16, false, false>(p, a, s);

@@ -32,6 +32,11 @@ struct IGemmArgs {
 template <int MODE> struct IBox;
 template <> struct IBox<3> { static constexpr int BZ = 4, BY = 4, BX = 16, NT = 27, KZ = 3; };
 template <> struct IBox<2> { static constexpr int BZ = 1, BY = 16, BX = 16, NT = 9, KZ = 1; };
+// igemm_at_kernel only: boxes for the small deep levels.  The 16 lanes of an MFMA column tile are 16 consecutive voxels
+// of the flattened box (per-lane slot table), so a 12-wide or 6-wide row does not leave lanes idle.
+template <int MODE, int VAR> struct ABox : IBox<MODE> {};
+template <> struct ABox<3, 1> { static constexpr int BZ = 4, BY = 4, BX = 12, NT = 27, KZ = 3; };   // 192 voxels = 12 tiles
+template <> struct ABox<3, 2> { static constexpr int BZ = 3, BY = 6, BX = 6, NT = 27, KZ = 3; };    // 108 voxels -> 7 of 8 tiles
 
 template <int MODE, int BM, bool FLIP, bool STATS>
 __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IGemmArgs a) {
@@ -192,10 +197,11 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IGemmArgs a) {
 // Here ALL taps of the KC x BM weight slab of a chunk are staged at once (27.6 KB, one 16-column plane per co tile ->
 // conflict-free operand reads), the next chunk's halo and weights are prefetched into registers during the MFMAs, and
 // the inner loop runs 27 x 16 MFMAs per wave between barriers.
-template <int MODE, int BM, int KC, bool FLIP, bool STATS>
+template <int MODE, int BM, int KC, bool FLIP, bool STATS, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
-  using B = IBox<MODE>;
+  using B = ABox<MODE, VAR>;
   constexpr int BZ = B::BZ, BY = B::BY, BX = B::BX, NT = B::NT, KZ = B::KZ;
+  constexpr int NV = BZ * BY * BX, TPW = (NV + 63) / 64;     // voxels of the box, 16-voxel tiles per wave
   constexpr int HZ = BZ + (KZ - 1), HY = BY + 2, HX = BX + 2, PS = HZ * HY * HX;
   constexpr int MT = BM / 16, NQ = KC / 4;
   constexpr int NH = (NQ * PS + 255) / 256;
@@ -215,9 +221,9 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
   const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
   const int co0 = blockIdx.y * BM;
 
-  ig_f32x4 acc[4][MT];
+  ig_f32x4 acc[TPW][MT];
 #pragma unroll
-  for (int v = 0; v < 4; ++v)
+  for (int v = 0; v < TPW; ++v)
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[v][m] = (ig_f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -279,12 +285,16 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
     }
   };
 
-  // halo slot of this lane's voxel for tile v (tap 0,0,0): 3-D (z = wave, y = v), 2-D (y = 4*wave + v)
-  int hb[4];
+  // halo slot of this lane's voxel for tile v (tap 0,0,0): voxel (wave*TPW + v)*16 + il of the flattened box
+  // (standard boxes: 3-D z = wave, y = v; 2-D y = 4*wave + v); lanes past the box read slot 0 and store nothing
+  int hb[TPW], vox[TPW];
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int zz = (MODE == 3) ? wave : 0, yb = (MODE == 3) ? v : 4 * wave + v;
-    hb[v] = ((zz * HY + yb) * HX + il) * 4 + kl;
+  for (int v = 0; v < TPW; ++v) {
+    const int id = (wave * TPW + v) * 16 + il;
+    vox[v] = id < NV ? id : -1;
+    const int lx = id % BX, r = id / BX;
+    const int ly = r % BY, lz = r / BY;
+    hb[v] = (id < NV ? ((lz * HY + ly) * HX + lx) * 4 : 0) + kl;
   }
   const int wb = kl * 16 + il;
 
@@ -307,13 +317,13 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
       const int toff = ((tz * HY + ty) * HX + tx) * 4;
 #pragma unroll
       for (int s = 0; s < NQ; ++s) {
-        float av[MT], bv[4];
+        float av[MT], bv[TPW];
 #pragma unroll
         for (int m = 0; m < MT; ++m) av[m] = wl[wb + (((size_t)m * NT + t) * KC + 4 * s) * 16];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) bv[v] = hal[hb[v] + toff + s * PS * 4];
+        for (int v = 0; v < TPW; ++v) bv[v] = hal[hb[v] + toff + s * PS * 4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+        for (int v = 0; v < TPW; ++v)
 #pragma unroll
           for (int m = 0; m < MT; ++m) acc[v][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[v], acc[v][m], 0, 0, 0);
       }
@@ -326,11 +336,11 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
-  const int gx = x0 + il;
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int gz = (MODE == 3) ? z0 + wave : 0;
-    const int gy = (MODE == 3) ? y0 + v : y0 + 4 * wave + v;
+  for (int v = 0; v < TPW; ++v) {
+    if (vox[v] < 0) continue;
+    const int lx = vox[v] % BX, r = vox[v] / BX;
+    const int gx = x0 + lx, gy = y0 + r % BY, gz = z0 + r / BY;
     if (!(gz < a.Z && gy < a.Y && gx < a.X)) continue;
     float* op = a.out + ((((size_t)n * a.Z + gz) * a.Y + gy) * a.X + gx) * a.out_cs + co0;
 #pragma unroll
@@ -369,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
 
 struct IGPlan {
   bool alltaps;   // BM = 16 | 32: igemm_at_kernel
+  int var;        // igemm_at box variant (ABox): 0 standard, 1 = 4x4x12, 2 = 3x6x6
   int mode, bm;
   bool flip;
   int Z, Y, X, nbz, nby, nbx;
@@ -376,9 +387,9 @@ struct IGPlan {
   int gridx, gridy;
 };
 
-template <int MODE, int BM, int KC, bool FLIP, bool STATS>
+template <int MODE, int BM, int KC, bool FLIP, bool STATS, int VAR = 0>
 static int launch_ig_at(const IGPlan& p, const IGemmArgs& a, hipStream_t s) {
-  auto kern = igemm_at_kernel<MODE, BM, KC, FLIP, STATS>;
+  auto kern = igemm_at_kernel<MODE, BM, KC, FLIP, STATS, VAR>;
   static size_t attr_lds = 48 * 1024;
   if (p.lds > attr_lds) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
