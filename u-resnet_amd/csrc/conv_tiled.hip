@@ -41,20 +41,69 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-static bool spatial_plan(const ursn_conv_desc& d, int& Z, int& Y, int& X, int& ntx, int& nty, int& zseg, int& nzseg,
-                         int target_blocks) {
+// z-segments per (image, xy tile) for the marching kernels.  All workgroups of a launch take about the same time
+// (~ zseg + prologue planes), so the launch costs rounds x (zseg + 3) with rounds = ceil(workgroups / resident slots):
+// pick the split that minimises it (2.25 rounds executed as 3 was a 25 % loss on the level-0 weight gradient).
+int ursn_cu_count() {
+  static int n = 0;
+  if (!n) {
+    hipDeviceProp_t pr;
+    int dev = 0;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+            ? pr.multiProcessorCount : 256;
+  }
+  return n;
+}
+void ursn_pick_zseg(int64_t base, int Z, int occ, int min_seg, int& zseg, int& nzseg) {
+  static const int legacy = getenv("URSN_ZSEG_LEGACY") ? atoi(getenv("URSN_ZSEG_LEGACY")) : 0;
+  const int64_t slots = (int64_t)(occ > 0 ? occ : 1) * ursn_cu_count();
+  int best_seg = Z;
+  int64_t best_cost = -1;
+  if (legacy) {   // powers of two up to `legacy` workgroups (A/B)
+    int nz = 1;
+    while (base * nz < legacy && Z / (nz * 2) >= min_seg) nz *= 2;
+    best_seg = (Z + nz - 1) / nz;
+  } else {
+    for (int nz = 1; nz <= Z; ++nz) {
+      const int seg = (Z + nz - 1) / nz;
+      if (seg < min_seg && nz > 1) break;
+      const int ns = (Z + seg - 1) / seg;
+      const int64_t rounds = (base * ns + slots - 1) / slots;
+      const int64_t cost = rounds * (seg + 3);
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_seg = seg; }
+    }
+  }
+  zseg = best_seg;
+  nzseg = (Z + zseg - 1) / zseg;
+}
+
+// resident workgroups per CU of the 3-D tiled kernels: min(VGPR limit from the compiler's resource report, LDS limit)
+static int occ_limit(int vgpr_waves, size_t lds) {
+  int by_lds = lds ? (int)((160 * 1024) / lds) : 8;
+  int o = vgpr_waves < by_lds ? vgpr_waves : by_lds;
+  return o < 1 ? 1 : o;
+}
+static int tconv_vgpr_waves(int mode, int cin, int cout) {
+  if (mode != 3) return 2;
+  if (cin == 8 && cout == 8) return 4;
+  if (cin == 16 && cout == 16) return 2;
+  if (cin <= 8 && cout <= 8) return 6;
+  return 3;
+}
+static int twgrad_vgpr_waves(int mode, int cin, int cout) {
+  if (mode != 3) return 2;
+  if (cin == 16) return 1;
+  if (cin == 1) return 8;
+  return 2;
+}
+
+static bool spatial_tiles(const ursn_conv_desc& d, int& Z, int& Y, int& X, int& ntx, int& nty) {
   if (d.ndim == 3) { Z = d.in_sp[0]; Y = d.in_sp[1]; X = d.in_sp[2]; }
   else { Z = d.in_sp[0]; Y = 1; X = d.in_sp[1]; }
   const int TX = d.ndim == 3 ? 32 : 256, TY = d.ndim == 3 ? 8 : 1;
   if (X < TX / 2 || Y < TY || Z < 8) return false;  // only worth it when tiles are reasonably full
   ntx = (X + TX - 1) / TX;
   nty = (Y + TY - 1) / TY;
-  // enough workgroups to fill the chip, but long marches to amortise the prologue and the weight load
-  int64_t base = (int64_t)d.n * ntx * nty;
-  int nz = 1;
-  while (base * nz < target_blocks && Z / (nz * 2) >= 8) nz *= 2;
-  zseg = (Z + nz - 1) / nz;
-  nzseg = (Z + zseg - 1) / zseg;
   return true;
 }
 
@@ -70,9 +119,8 @@ static bool make_plan(const ursn_conv_desc& d, ConvPass pass, TPlan& p, Blocking
   const bool single_in = (d.cin == 1 && ics == 1 && !p.flip);   // conv0: scalar input fetch, kernel view Cin = 4
   if (((ics & 3) && !single_in) || (ocs & 3)) return false;
   if (d.cin == 1 && p.flip) return false;
-  static const int tb_conv = env_int("URSN_TB_CONV", 2048);
-  if (!spatial_plan(d, p.Z, p.Y, p.X, p.ntx, p.nty, p.zseg, p.nzseg, tb_conv)) return false;
-  p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
+  if (!spatial_tiles(d, p.Z, p.Y, p.X, p.ntx, p.nty)) return false;
+  p.grid = (int)((int64_t)d.n * p.nty * p.ntx);   // x nzseg below, once the kernel shape (-> occupancy) is known
   b = Blocking();
   if (d.in_split) {
     // never-materialised concat: the two halves of the layer input are separate tensors -> two channel blocks on
@@ -84,7 +132,7 @@ static bool make_plan(const ursn_conv_desc& d, ConvPass pass, TPlan& p, Blocking
     b.split = true; b.bsz = half;
     if (p.flip) { b.nbo = 2; p.cout = half; } else { b.nbi = 2; p.cin = half; }
   } else if (!tiled_shape_ok(p.cin, p.cout, p.mode)) {
-    if ((p.cin % 16) || (p.cout % 16) || p.cin > 64 || p.cout > 64 || (p.grid < 192 && d.algo != 3)) return false;
+    if ((p.cin % 16) || (p.cout % 16) || p.cin > 64 || p.cout > 64 || (p.grid * (p.Z / 12) < 192 && d.algo != 3)) return false;
     b.nbi = p.cin / 16;
     b.nbo = p.cout / 16;
     p.cin = p.cout = 16;
@@ -92,7 +140,10 @@ static bool make_plan(const ursn_conv_desc& d, ConvPass pass, TPlan& p, Blocking
   const int TX = p.mode == 3 ? 32 : 256, TY = p.mode == 3 ? 8 : 1;
   const int PX = TX + 2, PY = TY + (p.mode == 3 ? 2 : 0);
   p.lds = (size_t)4 * (p.cin / 4) * PX * PY * 16;
-  return p.lds <= 160 * 1024;
+  if (p.lds > 160 * 1024) return false;
+  ursn_pick_zseg(p.grid, p.Z, occ_limit(tconv_vgpr_waves(p.mode, p.cin, p.cout), p.lds), 8, p.zseg, p.nzseg);
+  p.grid *= p.nzseg;
+  return true;
 }
 
 int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass) {
@@ -201,26 +252,52 @@ static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
   p.mode = d.ndim; p.cin = d.cin; p.cout = (d.cout + 3) & ~3;
   const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
   if (((ics & 3) && !(d.cin == 1 && ics == 1)) || (ocs & 3)) return false;
-  static const int tb_wgrad = env_int("URSN_TB_WGRAD", 1024);
-  if (!spatial_plan(d, p.Z, p.Y, p.X, p.ntx, p.nty, p.zseg, p.nzseg, tb_wgrad)) return false;
-  p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
+  if (!spatial_tiles(d, p.Z, p.Y, p.X, p.ntx, p.nty)) return false;
+  p.grid = (int)((int64_t)d.n * p.nty * p.ntx);   // x nzseg below
   b = Blocking();
+  bool blocked_shape = false;
   if (d.in_split && !(use_wgradz(d) && d.in_split == 8 && d.cin == 16)) return false;   // split input: plane-pair kernel only
   bool c816 = (d.cin == 8 || d.cin == 16) && (p.cout == 8 || p.cout == 16);
   bool extra = d.ndim == 3 ? ((d.cin == 8 && p.cout == 4) || (d.cin == 1 && p.cout == 8))
                            : ((d.cin == 16 && p.cout == 32) || (d.cin == 16 && p.cout == 4) || (d.cin == 1 && p.cout == 16) ||
                               (d.cin == 8 && p.cout == 4));
   if (!(c816 || extra)) {
-    if ((d.cin % 16) || (d.cout % 16) || d.cin > 64 || d.cout > 64 || (p.grid < 96 && d.algo != 3)) return false;
+    if ((d.cin % 16) || (d.cout % 16) || d.cin > 64 || d.cout > 64 || (p.grid * (p.Z / 12) < 96 && d.algo != 3)) return false;
     b.nbi = d.cin / 16;
     b.nbo = d.cout / 16;
     p.cin = p.cout = 16;
+    blocked_shape = true;
   }
   const int TX = p.mode == 3 ? 32 : 256, TY = p.mode == 3 ? 8 : 1;
   const int PX = TX + 2, PY = TY + (p.mode == 3 ? 2 : 0);
   p.lds = ((size_t)4 * PX * PY * p.cin + (size_t)2 * TX * TY * p.cout) * sizeof(float) + 256;
-  if (use_wgradz(d)) p.lds = ((size_t)6 * PX * PY * 8 + (size_t)4 * TX * TY * 8) * sizeof(float) + 256;
-  return p.lds <= 160 * 1024;
+  int vg = twgrad_vgpr_waves(p.mode, p.cin, p.cout);
+  if (use_wgradz(d)) {
+    int ty = TY;
+    if (p.mode == 3) {   // plane-pair kernel: 32 x 4 tiles, 4 waves (wgradz_tiled_kernel.h ZTile<3>)
+      ty = 4;
+      p.nty = (p.Y + ty - 1) / ty;
+      p.grid = (int)((int64_t)d.n * p.nty * p.ntx);
+    }
+    const int py = ty + (p.mode == 3 ? 2 : 0);
+    p.lds = ((size_t)6 * PX * py * 8 + (size_t)4 * TX * ty * 8) * sizeof(float) + 256;
+    vg = 2;
+  } else if (!blocked_shape && use_wgrad4(d, p)) vg = 2;
+  {  // the per-wave accumulator copies of the final cross-wave sum reuse the plane rings
+    const int taps = p.mode == 3 ? 27 : 9;
+    size_t red = use_wgradz(d) ? (size_t)(p.mode == 3 ? 4 : 8) * 2 * taps * 64 * sizeof(float)
+                               : (size_t)4 * taps * p.cin * p.cout * sizeof(float);
+    if (red > p.lds) p.lds = red;
+  }
+  if (p.lds > 160 * 1024) return false;
+  ursn_pick_zseg(p.grid, p.Z, occ_limit(vg, p.lds), 8, p.zseg, p.nzseg);
+  if (use_wgradz(d)) {
+    static const int force_nz = getenv("URSN_WGRADZ_NZ") ? atoi(getenv("URSN_WGRADZ_NZ")) : 0;   // A/B
+    if (force_nz > 0) { p.zseg = (p.Z + force_nz - 1) / force_nz; p.nzseg = (p.Z + p.zseg - 1) / p.zseg; }
+    if ((p.zseg & 1) && p.nzseg > 1) { p.zseg += 1; p.nzseg = (p.Z + p.zseg - 1) / p.zseg; }   // plane pairs
+  }
+  p.grid *= p.nzseg;
+  return true;
 }
 
 int tiled_wgrad_supported(const ursn_conv_desc& d) {

@@ -50,10 +50,7 @@ static bool make_dplan(const ursn_conv_desc& d, ConvPass pass, TDPlan& p, DBlock
   p.ntx = (p.X + TX - 1) / TX;
   p.nty = (p.Y + TY - 1) / TY;
   int64_t base = (int64_t)d.n * p.ntx * p.nty;
-  int nz = 1;
-  while (base * nz < 1024 && p.Z / (nz * 2) >= 6) nz *= 2;
-  p.zseg = (p.Z + nz - 1) / nz;
-  p.nzseg = (p.Z + p.zseg - 1) / p.zseg;
+  ursn_pick_zseg(base, p.Z, p.mode == 3 ? 1 : 2, 6, p.zseg, p.nzseg);   // resident workgroups per CU: 1 (3-D, 190-256 VGPRs)
   p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
   b = DBlocking();
   if (ck % 16 || ck > 64) return false;

@@ -542,8 +542,9 @@ int launch_fill(float* p, float value, int64_t n, hipStream_t s) {
 
 // dst[i] += sum_c src[c*n + i]; a block owns 64 elements, its 4 waves split the chunks (coalesced 256-B rows),
 // chunk order inside a wave and the 4-way combine are fixed -> bitwise reproducible.
+// cstride = distance (elements) between consecutive chunks.
 __global__ __launch_bounds__(256) void reduce_accum_kernel(float* __restrict__ dst, const float* __restrict__ src,
-                                                           int64_t n, int nchunks) {
+                                                           int64_t n, int nchunks, int64_t cstride) {
   __shared__ float sm[4][64];
   const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + e;
@@ -551,20 +552,59 @@ __global__ __launch_bounds__(256) void reduce_accum_kernel(float* __restrict__ d
   if (i < n) {
     int c = cg;
     for (; c + 12 < nchunks; c += 16) {
-      s0 += src[(int64_t)c * n + i];
-      s1 += src[(int64_t)(c + 4) * n + i];
-      s2 += src[(int64_t)(c + 8) * n + i];
-      s3 += src[(int64_t)(c + 12) * n + i];
+      s0 += src[(int64_t)c * cstride + i];
+      s1 += src[(int64_t)(c + 4) * cstride + i];
+      s2 += src[(int64_t)(c + 8) * cstride + i];
+      s3 += src[(int64_t)(c + 12) * cstride + i];
     }
-    for (; c < nchunks; c += 4) s0 += src[(int64_t)c * n + i];
+    for (; c < nchunks; c += 4) s0 += src[(int64_t)c * cstride + i];
   }
   sm[cg][e] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (cg == 0 && i < n) dst[i] += (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
 }
+
+// Stage 1 of long slab reductions, in place: chunk g*gs <- sum of chunks [g*gs, min((g+1)*gs, nchunks)).  A block owns
+// 64 elements of one group (grid = element blocks x groups): thousands of slabs are summed by ~1000 workgroups instead
+// of n/64 (27 for a 27x8x8 weight gradient, which cost 50-200 us per launch).  Fixed order -> reproducible.
+#define URSN_REDUCE_GS 64
+__global__ __launch_bounds__(256) void reduce_groups_kernel(float* __restrict__ src, int64_t n, int nchunks) {
+  __shared__ float sm[4][64];
+  const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  const int c0 = blockIdx.y * URSN_REDUCE_GS;
+  int c1 = c0 + URSN_REDUCE_GS;
+  if (c1 > nchunks) c1 = nchunks;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int c = c0 + cg;
+    for (; c + 12 < c1; c += 16) {
+      s0 += src[(int64_t)c * n + i];
+      s1 += src[(int64_t)(c + 4) * n + i];
+      s2 += src[(int64_t)(c + 8) * n + i];
+      s3 += src[(int64_t)(c + 12) * n + i];
+    }
+    for (; c < c1; c += 4) s0 += src[(int64_t)c * n + i];
+  }
+  sm[cg][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();   // all reads of chunk c0 (by wave 0) are done before it is overwritten
+  if (cg == 0 && i < n) src[(int64_t)c0 * n + i] = (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
+}
+// returns the number of chunks left (stride URSN_REDUCE_GS * n) after the optional in-place stage
+static int reduce_stage1(float* src, int64_t n, int nchunks, int64_t& cstride, hipStream_t s) {
+  cstride = n;
+  if (nchunks < 4 * URSN_REDUCE_GS) return nchunks;
+  const int groups = (nchunks + URSN_REDUCE_GS - 1) / URSN_REDUCE_GS;
+  hipLaunchKernelGGL(reduce_groups_kernel, dim3((unsigned)cdiv64(n, 64), groups), dim3(256), 0, s, src, n, nchunks);
+  cstride = (int64_t)URSN_REDUCE_GS * n;
+  return groups;
+}
+// NOTE: src is scratch: long reductions overwrite the first chunk of every group.
 int launch_reduce_accum(float* dst, const float* src, int64_t n, int nchunks, hipStream_t s) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(reduce_accum_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, dst, src, n, nchunks);
+  int64_t cstride;
+  const int left = reduce_stage1(const_cast<float*>(src), n, nchunks, cstride, s);
+  hipLaunchKernelGGL(reduce_accum_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, dst, src, n, left, cstride);
   URSN_HIP(hipGetLastError());
   return 0;
 }
@@ -572,7 +612,7 @@ int launch_reduce_accum(float* dst, const float* src, int64_t n, int nchunks, hi
 // dst[t*dst_tap_stride + r*dst_row_stride + c] += sum_k src[k*(taps*rows*cols) + (t*rows + r)*cols + c]
 __global__ __launch_bounds__(256) void reduce_accum_blocked_kernel(float* __restrict__ dst, const float* __restrict__ src,
                                                                    int taps, int rows, int cols, int64_t dst_tap_stride,
-                                                                   int dst_row_stride, int nchunks) {
+                                                                   int dst_row_stride, int nchunks, int64_t cstride) {
   __shared__ float sm[4][64];
   const int e = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const int64_t n = (int64_t)taps * rows * cols;
@@ -581,10 +621,10 @@ __global__ __launch_bounds__(256) void reduce_accum_blocked_kernel(float* __rest
   if (i < n) {
     int c = cg;
     for (; c + 4 < nchunks; c += 8) {
-      s0 += src[(int64_t)c * n + i];
-      s1 += src[(int64_t)(c + 4) * n + i];
+      s0 += src[(int64_t)c * cstride + i];
+      s1 += src[(int64_t)(c + 4) * cstride + i];
     }
-    for (; c < nchunks; c += 4) s0 += src[(int64_t)c * n + i];
+    for (; c < nchunks; c += 4) s0 += src[(int64_t)c * cstride + i];
   }
   sm[cg][e] = s0 + s1;
   __syncthreads();
@@ -599,8 +639,10 @@ __global__ __launch_bounds__(256) void reduce_accum_blocked_kernel(float* __rest
 int launch_reduce_accum_blocked(float* dst, const float* src, int taps, int rows, int cols, int64_t dst_tap_stride,
                                 int dst_row_stride, int nchunks, hipStream_t s) {
   int64_t n = (int64_t)taps * rows * cols;
+  int64_t cstride;
+  const int left = reduce_stage1(const_cast<float*>(src), n, nchunks, cstride, s);
   hipLaunchKernelGGL(reduce_accum_blocked_kernel, dim3((unsigned)cdiv64(n, 64)), dim3(256), 0, s, dst, src, taps, rows,
-                     cols, dst_tap_stride, dst_row_stride, nchunks);
+                     cols, dst_tap_stride, dst_row_stride, left, cstride);
   URSN_HIP(hipGetLastError());
   return 0;
 }

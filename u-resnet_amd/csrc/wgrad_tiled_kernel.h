@@ -190,33 +190,30 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
     __syncthreads();
   }
 
-  // Sum the 4 waves in LDS (plane ring is free now) in fixed wave order -> one slab per workgroup (reproducible).
-  float* red = wlds;  // [NT*CIN*cout_w]
+  // Sum the 4 waves in fixed order -> one slab per workgroup (reproducible).  Every wave stores its accumulators to its
+  // own copy in LDS (plain stores, the plane ring is free now; a read-modify-write chain through one copy serialises on
+  // LDS latency: ~15 us per workgroup), then all threads add the four copies.
   const int nred = NT * CIN * a.cout_w;
-  for (int i = tid; i < nred; i += 256) red[i] = 0.f;
-  __syncthreads();
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
+  float* part = wlds + (size_t)wave * nred;
 #pragma unroll
-      for (int m = 0; m < NA; ++m)
+  for (int m = 0; m < NA; ++m)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          int col = c * 16 + il;
+    for (int c = 0; c < CT; ++c) {
+      int col = c * 16 + il;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int row = 4 * kl + r;
-            int tap, ci;
-            if (CIN >= 16) { tap = m / MT; ci = (m % MT) * 16 + row; }
-            else if (CIN == 1) { tap = 16 * m + row; ci = 0; }
-            else { tap = 2 * m + (row >> 3); ci = row & 7; }
-            if (tap < NT && col < a.cout_w) red[(tap * CIN + ci) * a.cout_w + col] += acc[m][c][r];
-          }
-        }
+      for (int r = 0; r < 4; ++r) {
+        int row = 4 * kl + r;
+        int tap, ci;
+        if (CIN >= 16) { tap = m / MT; ci = (m % MT) * 16 + row; }
+        else if (CIN == 1) { tap = 16 * m + row; ci = 0; }
+        else { tap = 2 * m + (row >> 3); ci = row & 7; }
+        if (tap < NT && col < a.cout_w) part[(tap * CIN + ci) * a.cout_w + col] = acc[m][c][r];
+      }
     }
-    __syncthreads();
-  }
+  __syncthreads();
   float* slab = a.slab + (size_t)blockIdx.x * (size_t)nred;
-  for (int i = tid; i < nred; i += 256) slab[i] = red[i];
+  for (int i = tid; i < nred; i += 256)
+    slab[i] = ((wlds[i] + wlds[nred + i]) + wlds[2 * nred + i]) + wlds[3 * nred + i];
 }
 
 struct TWPlan {

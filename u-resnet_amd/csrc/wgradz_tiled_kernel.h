@@ -12,12 +12,21 @@
 // two slabs per workgroup (one per column half) go to the deterministic reduce.  Cin = 16 runs as two 8-channel slices.
 #pragma once
 #include "wgrad_tiled_kernel.h"
+#ifndef URSN_SCHED_PIPELINE
+#define URSN_SCHED_PIPELINE 1
+#endif
+
+// 3-D: 4 waves on a 32 x 4 tile (one row per wave), two workgroups per CU so one computes while the other sits in its
+// plane barrier (55 KB LDS each); 2-D: 8 waves x 32 voxels of a 256-wide row.
+template <int MODE> struct ZTile;
+template <> struct ZTile<3> { static constexpr int TX = 32, TY = 4, NTY = 3, NT = 27, NW = 4; };
+template <> struct ZTile<2> { static constexpr int TX = 256, TY = 1, NTY = 1, NT = 9, NW = 8; };
 
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void twgradz_kernel(TWgradArgs a) {
+__global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgradArgs a) {
   constexpr int CIN = 8, COUT = 8;
-  constexpr int NW = 8, NTHR = 64 * NW, NG = 64 / NW;           // 8 waves (2 per SIMD), NG voxel groups per wave and plane
-  using TL = WTile<MODE>;
+  using TL = ZTile<MODE>;
+  constexpr int NW = TL::NW, NTHR = 64 * NW, NG = 8;            // 32 voxels = 8 groups of 4 per wave and plane
   constexpr int TX = TL::TX, TY = TL::TY, NTY = TL::NTY, NT = TL::NT;
   constexpr int NT4 = 4 * NTY * 3;                              // tap rows incl. the 4th z plane
   constexpr int PX = TX + 2, PY = TY + (NTY == 3 ? 2 : 0), PS = PX * PY;
@@ -40,18 +49,39 @@ __global__ __launch_bounds__(512, 2) void twgradz_kernel(TWgradArgs a) {
   const int z0 = zs * a.zseg;
   const int z1 = (z0 + a.zseg < a.Z) ? z0 + a.zseg : a.Z;
 
-  int a_off[NA], a_tz[NA];
-#pragma unroll
-  for (int m = 0; m < NA; ++m) {
-    int tap = 2 * m + (il >> 3), ci = il & 7;
-    a_tz[m] = tap / (NTY * 3);
-    a_off[m] = (((tap / 3) % NTY) * PX + (tap % 3)) * CIN + ci;
-  }
   const int wrow = (MODE == 3) ? wave : 0;          // 3-D: one 32-wide tile row per wave; 2-D: 32 x per wave
   const int wcol = (MODE == 3) ? 0 : 32 * wave;
   const int a_lane = ((wrow * PX) + wcol + kl) * CIN;
   const int b_lane = ((wrow * TX) + wcol + kl) * COUT + (il & 7);
   const bool hi = il >= 8;
+  int a_cm[NA];   // lane constant of tile m: in-plane offset of its tap (lanes 0-7: tap 2m, lanes 8-15: tap 2m+1) + ci
+#pragma unroll
+  for (int m = 0; m < NA; ++m) {
+    int tap = 2 * m + (il >> 3), ci = il & 7;
+    a_cm[m] = a_lane + (((tap / 3) % NTY) * PX + (tap % 3)) * CIN + ci;
+  }
+
+  // staging tables: the tile's (y, x) footprint is the same for every plane, only the plane base moves
+  int xgo[NSX], dgo[NSD];
+  bool xok[NSX], dok[NSD];
+#pragma unroll
+  for (int i = 0; i < NSX; ++i) {
+    int idx = tid + i * NTHR;
+    int sl = idx / XQ, q = idx - sl * XQ;
+    int yy = sl / PX, xx = sl - yy * PX;
+    int py = y0 + yy - (NTY == 3 ? 1 : 0), px = x0 + xx - 1;
+    xok[i] = idx < XQ * PS && py >= 0 && py < a.Y && px >= 0 && px < a.X;
+    xgo[i] = (py * a.X + px) * a.x_cs + 4 * q;
+  }
+#pragma unroll
+  for (int i = 0; i < NSD; ++i) {
+    int idx = tid + i * NTHR;
+    int sl = idx / DQ, q = idx - sl * DQ;
+    int yy = sl / TX, xx = sl - yy * TX;
+    int py = y0 + yy, px = x0 + xx;
+    dok[i] = idx < DQ * TX * TY && py < a.Y && px < a.X;
+    dgo[i] = (py * a.X + px) * a.dz_cs + 4 * q;
+  }
 
   wg_f32x4 acc[NA];
 #pragma unroll
@@ -59,17 +89,12 @@ __global__ __launch_bounds__(512, 2) void twgradz_kernel(TWgradArgs a) {
 
   auto xslot = [](int p) { return (p + 6) % 6; };
   auto load_x = [&](int zin, wg_f32x4 (&sx)[NSX]) {
+    const bool zok = zin >= 0 && zin < a.Z;
+    const float* base = a.x + ((size_t)n * a.Z + (zok ? zin : 0)) * a.Y * a.X * a.x_cs;
 #pragma unroll
     for (int i = 0; i < NSX; ++i) {
-      int idx = tid + i * NTHR;
       wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < XQ * PS) {
-        int s = idx / XQ, q = idx - s * XQ;
-        int yy = s / PX, xx = s - yy * PX;
-        int py = y0 + yy - (NTY == 3 ? 1 : 0), px = x0 + xx - 1;
-        if (zin >= 0 && zin < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
-          v = *(const wg_f32x4*)(a.x + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.x_cs + 4 * q);
-      }
+      if (zok && xok[i]) v = *(const wg_f32x4*)(base + xgo[i]);
       sx[i] = v;
     }
   };
@@ -81,17 +106,12 @@ __global__ __launch_bounds__(512, 2) void twgradz_kernel(TWgradArgs a) {
     }
   };
   auto load_d = [&](int zin, wg_f32x4 (&sd)[NSD]) {
+    const bool zok = zin < z1;
+    const float* base = a.dz + ((size_t)n * a.Z + (zok ? zin : 0)) * a.Y * a.X * a.dz_cs;
 #pragma unroll
     for (int i = 0; i < NSD; ++i) {
-      int idx = tid + i * NTHR;
       wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < DQ * TX * TY) {
-        int s = idx / DQ, q = idx - s * DQ;
-        int yy = s / TX, xx = s - yy * TX;
-        int py = y0 + yy, px = x0 + xx;
-        if (zin < z1 && py < a.Y && px < a.X)
-          v = *(const wg_f32x4*)(a.dz + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.dz_cs + 4 * q);
-      }
+      if (zok && dok[i]) v = *(const wg_f32x4*)(base + dgo[i]);
       sd[i] = v;
     }
   };
@@ -119,9 +139,18 @@ __global__ __launch_bounds__(512, 2) void twgradz_kernel(TWgradArgs a) {
     load_x(z + 4, sxb);
     load_d(z + 2, sda);
     load_d(z + 3, sdb);
-    int abase[NA];
+    // ring slot bases of the 4 x planes of this step (uniform); tile m's two taps sit in plane (2m)/(3 NTY) and
+    // (2m+1)/(3 NTY) -- known at compile time, so a tile costs one add (or select + add where the pair straddles)
+    int sb[4];
 #pragma unroll
-    for (int m = 0; m < NA; ++m) abase[m] = xslot(z - 1 + a_tz[m]) * XPLANE + a_lane + a_off[m];
+    for (int j = 0; j < 4; ++j) sb[j] = xslot(z - 1 + j) * XPLANE;
+    int abase[NA];
+    wg_static_for<NA>([&](auto M) {
+      constexpr int m = decltype(M)::value;
+      constexpr int tzA = (2 * m) / (NTY * 3), tzB = (2 * m + 1) / (NTY * 3);
+      if constexpr (tzA == tzB) abase[m] = sb[tzA] + a_cm[m];
+      else abase[m] = (hi ? sb[tzB] : sb[tzA]) + a_cm[m];
+    });
     const float* dcur = dr + (size_t)((hi ? z + 1 : z) & 3) * DPLANE + b_lane;
     wg_static_for<NG>([&](auto G) {
       constexpr int g = decltype(G)::value;
@@ -134,6 +163,15 @@ __global__ __launch_bounds__(512, 2) void twgradz_kernel(TWgradArgs a) {
         acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[m], 0, 0, 0);
       }
     });
+#if URSN_SCHED_PIPELINE
+    // software pipelining hint: keep LDS operand reads a few MFMAs ahead instead of read-batch / MFMA-batch phases
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int i = 0; i < NG * NA / 2; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#endif
     store_x(z + 3, sxa);
     store_x(z + 4, sxb);
     store_d(z + 2, sda);
@@ -141,30 +179,32 @@ __global__ __launch_bounds__(512, 2) void twgradz_kernel(TWgradArgs a) {
     __syncthreads();
   }
 
-  // Sum the 8 waves in LDS (the plane ring is free now) in fixed wave order -> ONE pair of slabs per workgroup,
-  // bitwise reproducible.  Half 0: columns 0..7 (plane z, tap tz4); half 1: columns 8..15 (plane z+1, tap tz4-1).
-  float* red = wldz;  // [2][NT*CIN*COUT]
-  for (int i = tid; i < 2 * NT * CIN * COUT; i += NTHR) red[i] = 0.f;
-  __syncthreads();
-  for (int w = 0; w < NW; ++w) {
-    if (wave == w) {
+  // Sum the waves in fixed order -> ONE pair of slabs per workgroup, bitwise reproducible.  Each wave stores its
+  // accumulators to its own copy (plain stores into the free plane ring; a read-modify-write chain through one copy
+  // serialises on LDS latency), then all threads add the copies.  Half 0: columns 0..7 (plane z, tap tz4); half 1:
+  // columns 8..15 (plane z+1, tap tz4-1).
+  constexpr int NRED = 2 * NT * CIN * COUT;
+  float* part = wldz + (size_t)wave * NRED;
 #pragma unroll
-      for (int m = 0; m < NA; ++m) {
+  for (int m = 0; m < NA; ++m) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int row = 4 * kl + r;
-          int tap4 = 2 * m + (row >> 3), ci = row & 7;
-          int tz4 = tap4 / (NTY * 3), rest = tap4 - tz4 * (NTY * 3);
-          int tz = hi ? tz4 - 1 : tz4;
-          if (tz >= 0 && tz <= 2)
-            red[(hi ? NT * CIN * COUT : 0) + ((tz * (NTY * 3) + rest) * CIN + ci) * COUT + (il & 7)] += acc[m][r];
-        }
-      }
+    for (int r = 0; r < 4; ++r) {
+      int row = 4 * kl + r;
+      int tap4 = 2 * m + (row >> 3), ci = row & 7;
+      int tz4 = tap4 / (NTY * 3), rest = tap4 - tz4 * (NTY * 3);
+      int tz = hi ? tz4 - 1 : tz4;
+      if (tz >= 0 && tz <= 2)
+        part[(hi ? NT * CIN * COUT : 0) + ((tz * (NTY * 3) + rest) * CIN + ci) * COUT + (il & 7)] = acc[m][r];
     }
-    __syncthreads();
   }
-  float* slab = a.slab + (size_t)blockIdx.x * 2 * (size_t)(NT * CIN * COUT);
-  for (int i = tid; i < 2 * NT * CIN * COUT; i += NTHR) slab[i] = red[i];
+  __syncthreads();
+  float* slab = a.slab + (size_t)blockIdx.x * (size_t)NRED;
+  for (int i = tid; i < NRED; i += NTHR) {
+    float v = wldz[i];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += wldz[(size_t)w * NRED + i];
+    slab[i] = v;
+  }
 }
 
 template <int MODE>
@@ -175,7 +215,7 @@ static int launch_twz(const TWPlan& p, const TWgradArgs& a, hipStream_t s) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
     attr_lds = p.lds;
   }
-  hipLaunchKernelGGL(kern, dim3(p.grid), dim3(512), p.lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(p.grid), dim3(ZTile<MODE>::NW * 64), p.lds, s, a);
   URSN_HIP(hipGetLastError());
   return 0;
 }
