@@ -165,6 +165,13 @@ typedef struct ursn_conv_desc {
   const float* pw_w;   /* [cin][cout] shortcut weights                                                                 */
   int32_t pw_dy_cstride; /* 0 = compact (= cout)                                                                       */
   int32_t reserved_;
+  /* Normalise-on-load (forward and weight gradient): x is the RAW output z of the preceding conv whose BatchNorm has no
+   * activation (resnet_conv1 inside a residual unit, lib/resnet_module.py:43-51); the kernel stages
+   * (z - in_mean) * in_rstd + in_beta per input channel (zero padding stays zero), so that activation is never
+   * written.  NULL: x is used as is.  k3 s1 tiled kernels with 8 / 16 input channels only.                          */
+  const float* in_mean;
+  const float* in_rstd;
+  const float* in_beta;
 } ursn_conv_desc;
 
 /* y = conv(x, w).  w layout [k..,Cin,Cout] (transposed: [k..,Cout,Cin]). */

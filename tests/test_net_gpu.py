@@ -252,3 +252,22 @@ def test_split_concat_matches_materialised_concat(monkeypatch):
     assert max_rel(out["1"][2], out["0"][2]) < 1e-5
     for k, g0 in out["0"][1].items():
         assert l2_rel(out["1"][1][k], g0) < 1e-3, k   # fp32 summation order + the odd ReLU-mask flip
+
+
+def test_normalise_on_load_plan_matches_default(monkeypatch):
+    """URSN_NORM_ON_LOAD=1 (resnet_conv1's BatchNorm applied while conv2 stages its input, a1 never written) against the
+    default plan: same loss and gradients up to fp32 rounding of the affine."""
+    dims, base, ncls, N, ns = (32, 32, 64, 1), 8, 3, 2, 2
+    P = as_f32_exact(oracle_params(dims, base, ncls, num_strides=ns))
+    data, label, weight = make_inputs(dims, ncls, N, seed=12)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("URSN_NORM_ON_LOAD", mode)
+        net = build(dims, base, ncls, True, num_strides=ns)
+        net.set_variables(P)
+        net.zero_gradients(None)
+        res, _ = net.accum_gradients(None, data, label, weight)
+        out[mode] = (res[1], net.get_gradients(), net._sizes.workspace_bytes if hasattr(net, "_sizes") else 0)
+    assert abs(out["0"][0] - out["1"][0]) <= 1e-5 * abs(out["0"][0])
+    for k, g0 in out["0"][1].items():
+        assert l2_rel(out["1"][1][k], g0) < 1e-3, k

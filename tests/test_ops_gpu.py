@@ -660,3 +660,44 @@ def test_lds_scatter_stride2_conv_data_gradient(case):
     assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
     base = torch.ones(x.shape, dtype=torch.float32, device="cuda")
     assert rel_err(conv_backward_data(d, dyg, wg, x.shape, accumulate=1, dx_init=base).cpu().numpy(), dx + 1.0) < TOL
+
+
+@pytest.mark.parametrize("ndim,S,C", [(3, (8, 16, 32), 8), (3, (9, 11, 37), 16), (3, (16, 16, 32), 16), (2, (16, 256), 16),
+                                      (2, (12, 300), 8)])
+def test_normalise_on_load_conv_and_weight_gradient(ndim, S, C):
+    """resnet_conv2 reading the RAW output of resnet_conv1 (lib/resnet_module.py:43-51: BatchNorm without activation in
+    between): the kernels apply (z - mean) * rstd + beta while staging (in_mean / in_rstd / in_beta), padding stays zero."""
+    N = 2
+    rng = np.random.default_rng(3 * ndim + C)
+    z = _rand(rng, (N,) + S + (C,)) * 2.0 + 0.5
+    mean, rstd, beta = _rand(rng, (C,)) * 0.3, 0.5 + rng.random(C), _rand(rng, (C,)) * 0.2
+    x = (z - mean) * rstd + beta
+    w = _rand(rng, (3,) * ndim + (C, C)) * 0.2
+    y = O.conv_fwd(x, w, 1)
+    dy = _rand(rng, y.shape)
+    _, dw = O.conv_bwd(x, w, 1, dy)
+    zg, wg, dyg = dev(z), dev(w), dev(dy)
+    mg_, rg_, bg_ = dev(mean), dev(rstd), dev(beta)
+    d = desc(ndim, N, S, C, C, 3, 1)
+    d.in_mean, d.in_rstd, d.in_beta = mg_.data_ptr(), rg_.data_ptr(), bg_.data_ptr()
+    lib = _lib.load()
+    assert rel_err(conv_forward(d, zg, wg, y.shape).cpu().numpy(), y) < TOL
+    yg = torch.full(y.shape, float("nan"), dtype=torch.float32, device="cuda")
+    mo, ro = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    nb = 1 << 24
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.ursn_conv_forward_stats(ctypes.byref(d), P(zg), P(wg), P(yg), P(mo), P(ro), 1e-3, P(scratch), nb,
+                                           stream()))
+    torch.cuda.synchronize()
+    assert rel_err(yg.cpu().numpy(), y) < TOL
+    ax = tuple(range(y.ndim - 1))
+    assert np.abs(mo.cpu().numpy() - y.mean(axis=ax)).max() < 1e-5 * np.sqrt(y.var(axis=ax).max())
+    dwg = conv_backward_weight(d, zg, dyg, w.shape)
+    assert rel_err(dwg.cpu().numpy(), dw) < 5e-5
+    # shapes without a staging-affine kernel must be refused
+    d2 = desc(ndim, N, S, C, 32, 3, 1)
+    d2.in_mean, d2.in_rstd, d2.in_beta = mg_.data_ptr(), rg_.data_ptr(), bg_.data_ptr()
+    w2 = dev(_rand(rng, (3,) * ndim + (C, 32)))
+    yy = torch.empty((N,) + S + (32,), dtype=torch.float32, device="cuda")
+    if not (ndim == 2 and C == 16):   # 2-D 16 -> 32 is a native tiled shape
+        assert lib.ursn_conv_forward(ctypes.byref(d2), P(zg), P(w2), P(yy), stream()) != 0

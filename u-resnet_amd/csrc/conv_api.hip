@@ -229,6 +229,10 @@ int launch_tiled_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, c
 
 int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out, int accumulate,
                   hipStream_t s) {
+  if (d.in_mean && pass != PASS_DGRAD) {   // normalise-on-load: tiled kernels only (the data gradient does not read x)
+    URSN_REQUIRE(d.in_rstd && d.in_beta && tiled_conv_supported(d, pass), "conv: normalise-on-load (in_mean) not supported for this shape / pass");
+    return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
+  }
   if (d.pw_dy) {      // fused shortcut data gradient: tiled kernels only
     URSN_REQUIRE(pass == PASS_DGRAD && tiled_conv_supported(d, pass), "conv: fused pointwise term (pw_dy) not supported for this shape / pass");
     return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
@@ -289,6 +293,8 @@ extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, 
   for (int j = 0; j < 3; ++j) V *= g[0].out_d[j];
   if (d->transposed) { V = (int64_t)d->n; for (int j = 0; j < d->ndim; ++j) V *= 2 * d->in_sp[j]; }
   const int ocs = d->out_cstride > 0 ? d->out_cstride : d->cout;
+  if (d->in_mean)
+    URSN_REQUIRE(d->in_rstd && d->in_beta && tiled_conv_supported(*d, PASS_FWD), "conv_forward_stats: normalise-on-load (in_mean) not supported for this shape");
   if (d->in_split)
     URSN_REQUIRE(pointwise_conv_supported(*d, PASS_FWD, 0) || tiled_conv_supported(*d, PASS_FWD),
                  "conv_forward_stats: split input (in_split=%d) not supported for this shape", d->in_split);
@@ -317,7 +323,7 @@ extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, 
                  "conv_forward_stats: scratch too small");
     return launch_tiled_deconv(*d, PASS_FWD, x, w, y, 0, (double*)scratch, eps, mean, rstd, s);
   }
-  if ((d->algo == 0 || d->algo == 3 || d->in_split) && tiled_conv_supported(*d, PASS_FWD)) {
+  if ((d->algo == 0 || d->algo == 3 || d->in_split || d->in_mean) && tiled_conv_supported(*d, PASS_FWD)) {
     URSN_REQUIRE(tiled_conv_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
                  "conv_forward_stats: scratch too small");
     return launch_tiled_conv_bn(*d, x, w, y, (double*)scratch, eps, mean, rstd, s);
@@ -356,6 +362,10 @@ extern "C" size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d) {
 
 int wgrad_dispatch(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
                    size_t scratch_bytes, hipStream_t s) {
+  if (d.in_mean) {
+    URSN_REQUIRE(d.in_rstd && d.in_beta && tiled_wgrad_supported(d), "conv wgrad: normalise-on-load (in_mean) not supported for this shape");
+    return launch_tiled_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
+  }
   if (d.in_split) {
     if (pointwise_wgrad_supported(d)) return launch_pointwise_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
     URSN_REQUIRE(tiled_wgrad_supported(d), "conv wgrad: split input (in_split=%d) not supported for this shape", d.in_split);

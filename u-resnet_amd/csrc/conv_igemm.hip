@@ -15,7 +15,7 @@ static bool make_igplan(const ursn_conv_desc& d, ConvPass pass, IGPlan& p, int& 
     if (off < 0) { const char* e = getenv("URSN_DISABLE_TILED"); off = (e && e[0] == '1') ? 1 : 0; }
     if ((off || igemm_mode() == 0) && d.algo != 4) return false;
   }
-  if (d.transposed || d.k != 3 || d.stride != 1 || d.in_split) return false;
+  if (d.transposed || d.k != 3 || d.stride != 1 || d.in_split || d.in_mean) return false;
   if (pass != PASS_FWD && pass != PASS_DGRAD) return false;
   p.flip = (pass == PASS_DGRAD);
   kcin = p.flip ? d.cout : d.cin;

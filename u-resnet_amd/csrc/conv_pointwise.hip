@@ -247,7 +247,7 @@ static bool pw_enabled() {
 }
 
 static bool pw_geometry(const ursn_conv_desc& d, int lo[3], int sm[3], int64_t& nvox) {
-  if (d.transposed || d.k != 1) return false;
+  if (d.transposed || d.k != 1 || d.in_mean) return false;
   nvox = d.n;
   for (int j = 0; j < 3; ++j) { lo[j] = 1; sm[j] = 1; }
   for (int j = 0; j < d.ndim; ++j) {

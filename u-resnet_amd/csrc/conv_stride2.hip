@@ -441,7 +441,7 @@ static bool s2_enabled(const ursn_conv_desc& d) {
 // gather-type stride-2 geometry of a descriptor (conv s2: x hi-res; transposed: dy hi-res)
 static bool make_s2plan(const ursn_conv_desc& d, S2Plan& p) {
   if (!s2_enabled(d)) return false;
-  if (d.k != 3 || d.stride != 2 || d.in_split) return false;
+  if (d.k != 3 || d.stride != 2 || d.in_split || d.in_mean) return false;
   if (d.ndim != 2 && d.ndim != 3) return false;
   const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
   p.mode = d.ndim;

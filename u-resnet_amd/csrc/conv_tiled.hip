@@ -151,6 +151,7 @@ int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass) {
   Blocking b;
   if (!make_plan(d, pass, p, b)) return 0;
   if (d.pw_dy && !(pass == PASS_DGRAD && p.cin <= 16)) return 0;
+  if (d.in_mean && pass == PASS_FWD && (b.nbi > 1 || b.nbo > 1 || p.cin != p.cout || !(p.cin == 8 || p.cin == 16))) return 0;   // normalise-on-load: 8->8 / 16->16
   return 1;
 }
 
@@ -175,6 +176,11 @@ static int launch_blocks(const ursn_conv_desc& d, const TPlan& p, const Blocking
   a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
   a.cin_w = d.cin; a.cout_w = d.cout;
   a.pw_in = nullptr; a.pw_w = nullptr; a.pw_in_cs = d.pw_dy_cstride > 0 ? d.pw_dy_cstride : d.cout; a.pw_ws = d.cout;
+  a.aff_mean = a.aff_rstd = a.aff_beta = nullptr;
+  if (d.in_mean && !p.flip) {
+    URSN_REQUIRE(b.nbi == 1 && b.nbo == 1 && d.in_rstd && d.in_beta, "tiled conv: normalise-on-load needs a native 8 / 16 channel shape");
+    a.aff_mean = d.in_mean; a.aff_rstd = d.in_rstd; a.aff_beta = d.in_beta;
+  }
   if (d.pw_dy) URSN_REQUIRE(p.flip && d.pw_w && p.cin <= 16 && (a.pw_in_cs & 3) == 0, "tiled conv: fused pointwise term needs the data-gradient pass with <= 16 contraction channels");
   const int64_t V = (int64_t)d.n * p.Z * p.Y * p.X;
   const int real_out = p.flip ? d.cin : d.cout;
@@ -256,6 +262,7 @@ static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
   p.grid = (int)((int64_t)d.n * p.nty * p.ntx);   // x nzseg below
   b = Blocking();
   bool blocked_shape = false;
+  if (d.in_mean && !(d.cin == 8 || d.cin == 16)) return false;
   if (d.in_split && !(use_wgradz(d) && d.in_split == 8 && d.cin == 16)) return false;   // split input: plane-pair kernel only
   bool c816 = (d.cin == 8 || d.cin == 16) && (p.cout == 8 || p.cout == 16);
   bool extra = d.ndim == 3 ? ((d.cin == 8 && p.cout == 4) || (d.cin == 1 && p.cout == 8))
@@ -290,6 +297,7 @@ static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
     if (red > p.lds) p.lds = red;
   }
   if (p.lds > 160 * 1024) return false;
+  if (d.in_mean && (blocked_shape || (!use_wgradz(d) && use_wgrad4(d, p)))) return false;   // kernels without the staging affine
   ursn_pick_zseg(p.grid, p.Z, occ_limit(vg, p.lds), 8, p.zseg, p.nzseg);
   if (use_wgradz(d)) {
     static const int force_nz = getenv("URSN_WGRADZ_NZ") ? atoi(getenv("URSN_WGRADZ_NZ")) : 0;   // A/B
@@ -331,12 +339,15 @@ int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy,
   a.dz_cs = d.out_cstride > 0 ? d.out_cstride : d.cout;
   a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
   a.cout_w = blocked ? 16 : d.cout;
+  a.aff_mean = d.in_mean; a.aff_rstd = d.in_rstd; a.aff_beta = d.in_beta;
+  URSN_REQUIRE(!d.in_mean || (d.in_rstd && d.in_beta), "tiled wgrad: normalise-on-load needs in_rstd and in_beta");
   const int taps = d.ndim == 3 ? 27 : 9;
   if (!blocked && use_wgradz(d)) {  // Cout == 8: two output planes share each MFMA; Cin = 16 as two 8-channel slices
     a.dz = dy;
     a.cout_w = 8;
     for (int bi = 0; bi < d.cin / 8; ++bi) {
       a.x = x + 8 * bi;
+      if (d.in_mean) { a.aff_mean = d.in_mean + 8 * bi; a.aff_rstd = d.in_rstd + 8 * bi; a.aff_beta = d.in_beta + 8 * bi; }
       if (d.in_split && bi) {   // second half of a split input
         URSN_REQUIRE(d.x2, "tiled wgrad: split input without x2");
         a.x = d.x2;

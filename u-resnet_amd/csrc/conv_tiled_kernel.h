@@ -52,6 +52,10 @@ struct TConvArgs {
   const float* pw_in;
   const float* pw_w;      // rows = produced channels of this launch, row stride pw_ws
   int pw_in_cs, pw_ws;
+  // forward only: normalise-on-load, in = raw z of the preceding conv: staged value = (z - mean) * rstd + beta
+  const float* aff_mean;
+  const float* aff_rstd;
+  const float* aff_beta;
 };
 
 template <int MODE> struct Tile;
@@ -59,7 +63,7 @@ template <> struct Tile<3> { static constexpr int TX = 32, TY = 8, NTY = 3, NT =
 template <> struct Tile<2> { static constexpr int TX = 256, TY = 1, NTY = 1, NT = 9; };
 
 // CIN = contraction channels, COUT = produced channels (already swapped for the data gradient).
-template <int CIN, int COUT, int MODE, bool FLIP>
+template <int CIN, int COUT, int MODE, bool FLIP, bool AFF = false>
 __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
   constexpr bool STATS = !FLIP;  // the data gradient never feeds a BatchNorm
   using TL = Tile<MODE>;
@@ -114,9 +118,34 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
     }
   }
 
+  __shared__ f32x4 aff_s[AFF ? NQ : 1], aff_t[AFF ? NQ : 1];   // per-channel scale / shift of the normalise-on-load
+  constexpr bool aff = AFF && !FLIP;   // separate instantiation: the plain kernels keep their register allocation
+  if constexpr (aff) {
+    if (tid < CIN) {
+      const float r = a.aff_rstd[tid];
+      ((float*)aff_s)[tid] = r;
+      ((float*)aff_t)[tid] = a.aff_beta[tid] - a.aff_mean[tid] * r;
+    }
+    __syncthreads();
+  }
+
+  // scale / shift of the elements this thread stages (their channel quad is fixed per staging slot)
+  f32x4 sreg[aff ? NSTAGE : 1], treg[aff ? NSTAGE : 1];
+  if constexpr (aff) {
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+      int q = (tid + i * 256) / PS;
+      if (q >= NQ) q = NQ - 1;
+      sreg[i] = aff_s[q];
+      treg[i] = aff_t[q];
+    }
+  }
+
   // ---- plane staging --------------------------------------------------------------------------------------
   f32x4 stage[NSTAGE];
+  unsigned stage_inb = 0;   // which staged elements are real voxels (the affine must not touch the zero padding)
   auto stage_load = [&](int zin) {
+    stage_inb = 0;
 #pragma unroll
     for (int i = 0; i < NSTAGE; ++i) {
       int idx = tid + i * 256;
@@ -129,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
           const float* src = a.in + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.in_cs + 4 * q;
           if (a.cin_w == 1 && !FLIP) v[0] = *src;   // single-channel input (conv0): scalar fetch, lanes 1..3 stay 0
           else v = *(const f32x4*)src;
+          if constexpr (aff) stage_inb |= 1u << i;
         }
       }
       stage[i] = v;
@@ -138,7 +168,14 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NSTAGE; ++i) {
       int idx = tid + i * 256;
-      if (idx < NQ * PS) lds[(size_t)slot * NQ * PS + idx] = stage[i];
+      if (idx < NQ * PS) {
+        f32x4 v = stage[i];
+        // normalise-on-load is applied here, not at the load: the loads stay in flight during the MFMA block
+        if constexpr (aff) {
+          if ((stage_inb >> i) & 1u) v = v * sreg[i] + treg[i];
+        }
+        lds[(size_t)slot * NQ * PS + idx] = v;
+      }
     }
   };
 
@@ -251,9 +288,9 @@ struct TPlan {
   int grid;
 };
 
-template <int CIN, int COUT, int MODE, bool FLIP>
+template <int CIN, int COUT, int MODE, bool FLIP, bool AFF = false>
 static int launch_t(const TPlan& p, const TConvArgs& a, hipStream_t s) {
-  auto kern = tconv_kernel<CIN, COUT, MODE, FLIP>;
+  auto kern = tconv_kernel<CIN, COUT, MODE, FLIP, AFF>;
   static size_t attr_lds = 48 * 1024;  // dynamic LDS above the default limit must be opted into per kernel
   if (p.lds > attr_lds) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
@@ -267,6 +304,11 @@ static int launch_t(const TPlan& p, const TConvArgs& a, hipStream_t s) {
 #define URSN_TC(ci, co)                                  \
   if (p.cin == ci && p.cout == co) {                     \
     ursn_note_kernel(flip ? "tconv_dgrad<" #ci "," #co ">" : "tconv<" #ci "," #co ">"); \
+    if (!flip && a.aff_mean) {                           \
+      if constexpr (ci == co && (ci == 8 || ci == 16)) return launch_t<ci, co, MODE, false, true>(p, a, s); \
+      ursn_set_error("tiled conv: no normalise-on-load instantiation for %d->%d", ci, co); \
+      return 3;                                          \
+    }                                                    \
     return flip ? launch_t<ci, co, MODE, true>(p, a, s) : launch_t<ci, co, MODE, false>(p, a, s); \
   }
 

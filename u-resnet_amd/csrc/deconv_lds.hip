@@ -218,7 +218,7 @@ static bool make_scplan(const ursn_conv_desc& d, ConvPass pass, ScPlan& p) {
     }
     if (off && d.algo != 7) return false;
   }
-  if (d.in_split || d.pw_dy) return false;
+  if (d.in_split || d.pw_dy || d.in_mean) return false;
   const bool fwd_t = d.transposed && pass == PASS_FWD;
   const bool dgrad_s2 = !d.transposed && d.k == 3 && d.stride == 2 && pass == PASS_DGRAD;
   if (!fwd_t && !dgrad_s2) return false;

@@ -26,7 +26,7 @@ static bool make_dplan(const ursn_conv_desc& d, ConvPass pass, TDPlan& p, DBlock
     if (off && d.algo != 3) return false;
   }
   // transposed conv forward, or data gradient of a k3 stride-2 conv
-  if (d.in_split) return false;
+  if (d.in_split || d.in_mean) return false;
   const bool fwd_t = d.transposed && pass == PASS_FWD;
   const bool dgrad_s2 = !d.transposed && d.k == 3 && d.stride == 2 && pass == PASS_DGRAD;
   if (!fwd_t && !dgrad_s2) return false;

@@ -55,6 +55,7 @@ struct Unit {
   int sc = -1, c1 = -1, c2 = -1;  // layer indices
   Act in, a1, out;
   Act in2;   // C > 0: the unit input is the never-materialised concat [in | in2] (decoder, narrow levels)
+  bool a1_virtual = false;   // a1 = BN(z1) is never written: conv2 and its weight gradient normalise z1 while staging
 };
 
 }  // namespace
@@ -105,13 +106,13 @@ int new_flag(ursn_net* n) {
   return (int)n->ginit.size() - 1;
 }
 
-Act make_act(ursn_net* n, Arena& A, int lvl, int C, bool grad) {
+Act make_act(ursn_net* n, Arena& A, int lvl, int C, bool grad, bool grad_only = false) {
   Act a;
   a.C = C;
   a.cs = C;
   a.lvl = lvl;
   int64_t e = (int64_t)n->cfg.max_batch * n->lvox[lvl] * C;
-  a.p = A.floats(e);
+  a.p = grad_only ? nullptr : A.floats(e);
   a.g = grad ? A.floats(e) : nullptr;
   a.flag = new_flag(n);
   return a;
@@ -224,7 +225,24 @@ int plan(ursn_net* n, Arena& A) {
     const int cin = in.C + (in2 ? in2->C : 0);
     if (!(cin == co && s == 1)) u.sc = add_layer(n, A, scope + "/shortcut", 0, 1, s, cin, co, in.lvl, lout, poff);
     u.c1 = add_layer(n, A, scope + "/resnet_conv1", 0, 3, s, cin, co, in.lvl, lout, poff);
-    u.a1 = make_act(n, A, lout, co, tr);
+    {  // normalise-on-load (URSN_NORM_ON_LOAD=1, off by default): resnet_conv1's BatchNorm has no activation, so where
+       // conv2 (forward + weight gradient) runs on the tiled kernels they can apply it while staging and a1 is never
+       // written.  Measured at cfg3: -0.7 ms of bn_act passes, +0.3..0.5 ms in the MFMA-bound conv kernels (the staging
+       // VALU work is not free there) -> within run-to-run noise, so the plain plan stays the default.
+      const char* e = getenv("URSN_NORM_ON_LOAD");
+      ursn_conv_desc d2;
+      memset(&d2, 0, sizeof(d2));
+      d2.ndim = c.ndim; d2.n = c.max_batch;
+      for (int j = 0; j < c.ndim; ++j) d2.in_sp[j] = n->ldim[lout][3 - c.ndim + j];
+      d2.cin = co; d2.cout = co; d2.k = 3; d2.stride = 1;
+      d2.in_mean = d2.in_rstd = d2.in_beta = n->layers[u.c1].mean;   // placeholders: only "non-null" matters here
+      ursn_conv_desc d2p = d2;
+      d2p.in_mean = d2p.in_rstd = d2p.in_beta = nullptr;
+      // 8-channel layers only: the 16 -> 16 kernel has no registers to spare (245 VGPRs; measured +28 % with the affine)
+      u.a1_virtual = (e && e[0] == '1') && co == 8 && tiled_conv_supported(d2, PASS_FWD) &&
+                     !igemm_conv_supported(d2p, PASS_FWD) && (!tr || tiled_wgrad_supported(d2));
+    }
+    u.a1 = make_act(n, A, lout, co, tr, u.a1_virtual);
     u.c2 = add_layer(n, A, scope + "/resnet_conv2", 0, 3, 1, co, co, lout, lout, poff);
     u.out = out_view ? *out_view : make_act(n, A, lout, co, tr);
     n->units.push_back(u);
@@ -344,13 +362,17 @@ double layer_bytes(const ursn_net* n, const Layer& L, int N) {  // x + y + w  (=
 }
 
 // ---- forward pieces -----------------------------------------------------------------------
-int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s, const Act* in2 = nullptr) {
+int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s, const Act* in2 = nullptr, int aff = -1) {
   Layer& L = n->layers[li];
   ursn_conv_desc d = L.desc;
   d.n = N;
   d.in_cstride = in.cs;
   d.out_cstride = L.zcs;
   if (in2) { d.in_split = in.C; d.in2_cstride = in2->cs; d.x2 = in2->p; }
+  if (aff >= 0) {   // `in` is the raw z of layer aff: normalise on load
+    Layer& P = n->layers[aff];
+    d.in_mean = P.mean; d.in_rstd = P.rstd; d.in_beta = n->params + P.b_off;
+  }
   if (pointwise_conv_supported(d, PASS_FWD, 0)) {  // 1x1 shortcut + BN-statistics partials in one pass
     ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
     URSN_TRY(launch_pointwise_conv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)n->red_scratch,
@@ -428,8 +450,14 @@ int unit_fwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
   const Act* in2 = u.in2.C ? &u.in2 : nullptr;
   if (u.sc >= 0) URSN_TRY(conv_stats(n, u.sc, u.in, N, s, in2));
   URSN_TRY(conv_stats(n, u.c1, u.in, N, s, in2));
-  URSN_TRY(bn_out(n, u.c1, u.a1, 0, N, -1, nullptr, 0, s));
-  URSN_TRY(conv_stats(n, u.c2, u.a1, N, s));
+  if (u.a1_virtual) {
+    Act z1 = u.a1;
+    z1.p = n->layers[u.c1].z; z1.cs = n->layers[u.c1].zcs;
+    URSN_TRY(conv_stats(n, u.c2, z1, N, s, nullptr, u.c1));
+  } else {
+    URSN_TRY(bn_out(n, u.c1, u.a1, 0, N, -1, nullptr, 0, s));
+    URSN_TRY(conv_stats(n, u.c2, u.a1, N, s));
+  }
   if (u.sc >= 0) URSN_TRY(bn_out(n, u.c2, u.out, 1, N, u.sc, nullptr, 0, s));
   else URSN_TRY(bn_out(n, u.c2, u.out, 1, N, -1, u.in.p, u.in.cs, s));
   return 0;
@@ -483,13 +511,18 @@ bool take_flag(ursn_net* n, const Act& a) {  // returns "accumulate?" and marks 
   return acc;
 }
 
-// desc of layer li for the backward passes; sc >= 0: with the fused data gradient of the unit's 1x1 shortcut
-ursn_conv_desc bwd_desc(ursn_net* n, int li, const Act& in, int N, const Act* in2, int sc) {
+// desc of layer li for the backward passes; sc >= 0: with the fused data gradient of the unit's 1x1 shortcut;
+// aff >= 0 (weight gradient only): x is the raw z of layer aff, normalised on load
+ursn_conv_desc bwd_desc(ursn_net* n, int li, const Act& in, int N, const Act* in2, int sc, int aff = -1) {
   Layer& L = n->layers[li];
   ursn_conv_desc d = L.desc;
   d.n = N;
   d.in_cstride = in.cs;
   d.out_cstride = L.zcs;
+  if (aff >= 0) {
+    Layer& P = n->layers[aff];
+    d.in_mean = P.mean; d.in_rstd = P.rstd; d.in_beta = n->params + P.b_off;
+  }
   if (in2) { d.in_split = in.C; d.in2_cstride = in2->cs; d.x2 = in2->p; d.dx2 = in2->g; }
   if (sc >= 0) {
     Layer& S = n->layers[sc];
@@ -499,9 +532,9 @@ ursn_conv_desc bwd_desc(ursn_net* n, int li, const Act& in, int N, const Act* in
 }
 
 int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStream_t s, const Act* in2 = nullptr,
-             int fused_sc = -1, bool dgrad_done_elsewhere = false) {
+             int fused_sc = -1, bool dgrad_done_elsewhere = false, int aff = -1) {
   Layer& L = n->layers[li];
-  ursn_conv_desc d = bwd_desc(n, li, in, N, in2, -1);
+  ursn_conv_desc d = bwd_desc(n, li, in, N, in2, -1, aff);
   hipStream_t ws = s;
   if (n->s2) {  // dz is final once the kernels queued so far on the main stream are done
     if (n->sync_used == n->sync_pool.size()) {
@@ -524,7 +557,7 @@ int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStre
   if (need_dgrad) {
     bool acc = take_flag(n, in);
     if (in2) URSN_REQUIRE(take_flag(n, *in2) == acc, "split input: the two halves disagree on gradient initialisation");
-    if (fused_sc >= 0) d = bwd_desc(n, li, in, N, in2, fused_sc);
+    d = bwd_desc(n, li, in, N, in2, fused_sc);   // the data gradient does not read x: no normalise-on-load fields
     ProfScope pd(n, s, li, 1, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
     URSN_TRY(conv_dispatch(d, PASS_DGRAD, L.dz, n->params + L.w_off, in.g, acc ? 1 : 0, s));
     pd.done(ursn_last_kernel_name());
@@ -562,7 +595,13 @@ int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
     bool acc = take_flag(n, u.in);
     URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, -1, u.in.g, u.in.cs, acc ? 1 : 0, N, s));
   }
-  URSN_TRY(conv_bwd(n, u.c2, u.a1, true, N, s));
+  if (u.a1_virtual) {
+    Act z1 = u.a1;   // x = z1 normalised on load, dx -> a1.g
+    z1.p = n->layers[u.c1].z; z1.cs = n->layers[u.c1].zcs;
+    URSN_TRY(conv_bwd(n, u.c2, z1, true, N, s, nullptr, -1, false, u.c1));
+  } else {
+    URSN_TRY(conv_bwd(n, u.c2, u.a1, true, N, s));
+  }
   URSN_TRY(bn_back(n, u.c1, u.a1.g, u.a1.cs, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
   const Act* in2 = u.in2.C ? &u.in2 : nullptr;
   // stride-1 shortcut next to a tiled conv1: its data gradient rides in conv1's data-gradient kernel
@@ -831,6 +870,7 @@ extern "C" int ursn_tensor(const ursn_net* net, const char* name, float** ptr, i
   auto it = net->named.find(s);
   URSN_REQUIRE(it != net->named.end(), "tensor: no activation named %s", s.c_str());
   *ptr = want_g ? it->second.g : it->second.p;
+  URSN_REQUIRE(*ptr, "tensor: %s is not materialised (normalised on load inside the consuming convolution, URSN_NORM_ON_LOAD=1)", name);
   *voxels = net->lvox[it->second.lvl];
   *channels = it->second.C;
   *cstride = it->second.cs;

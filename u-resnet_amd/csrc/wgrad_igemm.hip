@@ -219,7 +219,7 @@ static bool make_igwplan(const ursn_conv_desc& d, IGWPlan& p) {
     }
     if (off && d.algo != 4) return false;
   }
-  if (d.transposed || d.k != 3 || d.stride != 1 || d.in_split) return false;
+  if (d.transposed || d.k != 3 || d.stride != 1 || d.in_split || d.in_mean) return false;
   if ((d.cin % 16) || (d.cout % 16)) return false;
   if (d.cin <= 16 && d.cout <= 16 && d.algo != 4) return false;
   const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;

@@ -27,6 +27,10 @@ struct TWgradArgs {
   int x_cs, dz_cs;
   int zseg, nzseg, nty, ntx;
   int cout_w;  // stored output channels (<= COUT, which is padded to 4)
+  // normalise-on-load of x (x = raw z of the preceding conv): staged value = (z - mean) * rstd + beta; null = none
+  const float* aff_mean;
+  const float* aff_rstd;
+  const float* aff_beta;
 };
 
 template <int MODE> struct WTile;
@@ -97,8 +101,20 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[m][c] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
 
+  __shared__ wg_f32x4 aff_s[XQ], aff_t[XQ];
+  const bool aff = a.aff_mean != nullptr && CIN >= 4;
+  if (aff) {
+    if (tid < CIN) {
+      const float r = a.aff_rstd[tid];
+      ((float*)aff_s)[tid] = r;
+      ((float*)aff_t)[tid] = a.aff_beta[tid] - a.aff_mean[tid] * r;
+    }
+    __syncthreads();
+  }
   wg_f32x4 sx[NSX], sd[NSD];
+  unsigned sx_inb = 0;   // staged x elements that are real voxels
   auto load_x = [&](int zin) {
+    sx_inb = 0;
 #pragma unroll
     for (int i = 0; i < NSX; ++i) {
       int idx = tid + i * 256;
@@ -111,6 +127,7 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
           const float* src = a.x + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.x_cs + 4 * q;
           if (CIN == 1) v[0] = *src;
           else v = *(const wg_f32x4*)src;
+          sx_inb |= 1u << i;
         }
       }
       sx[i] = v;
@@ -122,7 +139,11 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
       int idx = tid + i * 256;
       if (idx < XQ * PS) {
         if (CIN == 1) xr[(size_t)slot * XPLANE + idx] = sx[i][0];
-        else *(wg_f32x4*)(xr + (size_t)slot * XPLANE + idx * 4) = sx[i];
+        else {
+          wg_f32x4 v = sx[i];
+          if (aff && ((sx_inb >> i) & 1u)) { const int q = idx % XQ; v = v * aff_s[q] + aff_t[q]; }   // at the store: loads stay in flight
+          *(wg_f32x4*)(xr + (size_t)slot * XPLANE + idx * 4) = v;
+        }
       }
     }
   };

@@ -61,6 +61,21 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
     a_cm[m] = a_lane + (((tap / 3) % NTY) * PX + (tap % 3)) * CIN + ci;
   }
 
+  // normalise-on-load of x: this thread always stages channel quad (tid & 1)
+  __shared__ wg_f32x4 aff_st[2 * XQ];
+  const bool aff = a.aff_mean != nullptr;
+  wg_f32x4 aff_s4 = {1.f, 1.f, 1.f, 1.f}, aff_t4 = {0.f, 0.f, 0.f, 0.f};
+  if (aff) {
+    if (tid < CIN) {
+      const float r = a.aff_rstd[tid];
+      ((float*)aff_st)[tid] = r;
+      ((float*)aff_st)[CIN + tid] = a.aff_beta[tid] - a.aff_mean[tid] * r;
+    }
+    __syncthreads();
+    static_assert(XQ == 2 && (NTHR % XQ) == 0, "channel quad of a staging thread must not depend on the iteration");
+    aff_s4 = aff_st[tid & 1];
+    aff_t4 = aff_st[XQ + (tid & 1)];
+  }
   // staging tables: the tile's (y, x) footprint is the same for every plane, only the plane base moves
   int xgo[NSX], dgo[NSD];
   bool xok[NSX], dok[NSD];
@@ -88,23 +103,32 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
   for (int m = 0; m < NA; ++m) acc[m] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto xslot = [](int p) { return (p + 6) % 6; };
-  auto load_x = [&](int zin, wg_f32x4 (&sx)[NSX]) {
+  auto load_x = [&](int zin, wg_f32x4 (&sx)[NSX], unsigned& inb) {
     const bool zok = zin >= 0 && zin < a.Z;
+    inb = 0;
     const float* base = a.x + ((size_t)n * a.Z + (zok ? zin : 0)) * a.Y * a.X * a.x_cs;
 #pragma unroll
     for (int i = 0; i < NSX; ++i) {
       wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (zok && xok[i]) v = *(const wg_f32x4*)(base + xgo[i]);
+      if (zok && xok[i]) {
+        v = *(const wg_f32x4*)(base + xgo[i]);
+        inb |= 1u << i;
+      }
       sx[i] = v;
     }
   };
-  auto store_x = [&](int zin, const wg_f32x4 (&sx)[NSX]) {
+  auto store_x = [&](int zin, const wg_f32x4 (&sx)[NSX], unsigned inb) {
 #pragma unroll
     for (int i = 0; i < NSX; ++i) {
       int idx = tid + i * NTHR;
-      if (idx < XQ * PS) *(wg_f32x4*)(xr + (size_t)xslot(zin) * XPLANE + idx * 4) = sx[i];
+      if (idx < XQ * PS) {
+        wg_f32x4 v = sx[i];
+        if (aff && ((inb >> i) & 1u)) v = v * aff_s4 + aff_t4;   // normalise-on-load, applied at the store: loads stay in flight
+        *(wg_f32x4*)(xr + (size_t)xslot(zin) * XPLANE + idx * 4) = v;
+      }
     }
   };
+
   auto load_d = [&](int zin, wg_f32x4 (&sd)[NSD]) {
     const bool zok = zin < z1;
     const float* base = a.dz + ((size_t)n * a.Z + (zok ? zin : 0)) * a.Y * a.X * a.dz_cs;
@@ -124,9 +148,10 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
   };
 
   wg_f32x4 sxa[NSX], sxb[NSX], sda[NSD], sdb[NSD];
+  unsigned inba = 0, inbb = 0;
   for (int p = -1; p <= 2; ++p) {
-    load_x(z0 + p, sxa);
-    store_x(z0 + p, sxa);
+    load_x(z0 + p, sxa, inba);
+    store_x(z0 + p, sxa, inba);
   }
   for (int p = 0; p <= 1; ++p) {
     load_d(z0 + p, sda);
@@ -135,8 +160,8 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
   __syncthreads();
 
   for (int z = z0; z < z1; z += 2) {
-    load_x(z + 3, sxa);
-    load_x(z + 4, sxb);
+    load_x(z + 3, sxa, inba);
+    load_x(z + 4, sxb, inbb);
     load_d(z + 2, sda);
     load_d(z + 3, sdb);
     // ring slot bases of the 4 x planes of this step (uniform); tile m's two taps sit in plane (2m)/(3 NTY) and
@@ -172,8 +197,8 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
 #endif
-    store_x(z + 3, sxa);
-    store_x(z + 4, sxb);
+    store_x(z + 3, sxa, inba);
+    store_x(z + 4, sxb, inbb);
     store_d(z + 2, sda);
     store_d(z + 3, sdb);
     __syncthreads();
