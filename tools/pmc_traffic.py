@@ -1,0 +1,44 @@
+"""Aggregates gpurun_out/pmc_traffic/{FETCH_SIZE,WRITE_SIZE} (tools/pmc_traffic.sh) into profiles/r01_pmc_traffic_cfg3.csv and
+profiles/pmc_traffic.json (bench.py reads the latter for roofline.traffic).  gfx950: FETCH_SIZE counts 64 B per 128-B
+request for wide coalesced loads (MI355X_MICROARCH.md) -> hbm_bytes = 2 * fetch + write."""
+import collections
+import csv
+import glob
+import json
+import re
+
+LABEL = [  # rocprof kernel name (regex) -> bench.py kernel label
+    (r"twgradz_kernel<3>", "twgradz<8,8>"),
+    (r"tconv_kernel<8, 8, 3, false", "tconv<8,8>"), (r"tconv_kernel<8, 8, 3, true", "tconv_dgrad<8,8>"),
+    (r"tconv_kernel<16, 16, 3, false", "tconv<16,16>"), (r"tconv_kernel<16, 16, 3, true", "tconv_dgrad<16,16>"),
+    (r"twgrad_kernel<16, 16, 3>", "twgrad<16,16>"),
+    (r"igemm_at_kernel<3, 32, 8, false", "igemm_at<32>"), (r"igemm_at_kernel<3, 32, 8, true", "igemm_at_dgrad<32>"),
+    (r"igemm_at_kernel<3, 16, 16, false", "igemm_at<16>"), (r"igemm_wgrad_kernel<3, 2>", "igemm_wgrad<32>"),
+    (r"s2conv_kernel<3", "s2conv"), (r"s2wgrad_kernel<3>", "s2wgrad"), (r"s2scatter_kernel<3", "s2scatter"),
+    (r"bn_bwd_apply_kernel", "bn_bwd_apply"), (r"bn_bwd_reduce_kernel", "bn_bwd_reduce"), (r"bn_act_kernel", "bn_act"),
+]
+vals = {c: collections.defaultdict(list) for c in ("FETCH_SIZE", "WRITE_SIZE")}
+for c in vals:
+    for f in glob.glob("gpurun_out/pmc_traffic/%s/*/*_counter_collection.csv" % c):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c:
+                vals[c][r["Kernel_Name"]].append(float(r["Counter_Value"]))
+rows, out = [], {"_note": "cfg3_3d192_f8_b4, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/pmc_traffic.sh, "
+                          "URSN_WGRAD_STREAM=0). Units KiB per dispatch averaged over all launches of the kernel. gfx950: FETCH_SIZE counts "
+                          "64 B per 128-B request for wide coalesced loads (MI355X_MICROARCH.md, HBM) -> hbm_bytes_per_launch = 2*fetch + write."}
+for k in sorted(vals["FETCH_SIZE"], key=lambda k: -sum(vals["FETCH_SIZE"][k])):
+    f = vals["FETCH_SIZE"][k]
+    w = vals["WRITE_SIZE"].get(k, [0.0])
+    fa, wa = sum(f) / len(f), sum(w) / max(len(w), 1)
+    rows.append((k, len(f), round(fa, 1), round(wa, 1)))
+    for pat, lab in LABEL:
+        if re.search(pat, k) and lab not in out:
+            out[lab] = {"launches": len(f), "fetch_kib_raw": fa, "write_kib": wa, "hbm_bytes_per_launch": (2 * fa + wa) * 1024}
+with open("profiles/r01_pmc_traffic_cfg3.csv", "w") as fh:
+    fh.write("kernel,launches,FETCH_SIZE_KiB_raw_per_launch,WRITE_SIZE_KiB_per_launch\n")
+    for k, n, fa, wa in rows:
+        fh.write('"%s",%d,%s,%s\n' % (k, n, fa, wa))
+json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+for lab in out:
+    if lab != "_note":
+        print("%-22s %8.1f MB/launch" % (lab, out[lab]["hbm_bytes_per_launch"] / 1e6))
