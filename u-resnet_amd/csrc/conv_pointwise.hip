@@ -186,8 +186,8 @@ __global__ __launch_bounds__(256) void pwgrad_kernel(PWgradArgs a) {
           int64_t n = r / a.lo[0];
           hv = ((n * hi_z + a.sm[0] * z) * hi_y + a.sm[1] * y) * hi_x + a.sm[2] * x;
         }
-        val = (a.split && 4 * q >= a.split) ? *(const pw_f32x4*)(a.x2 + hv * a.x2_cs + 4 * q - a.split)
-                                            : *(const pw_f32x4*)(a.x + hv * a.x_cs + 4 * q);
+        val = __builtin_nontemporal_load((a.split && 4 * q >= a.split) ? (const pw_f32x4*)(a.x2 + hv * a.x2_cs + 4 * q - a.split)
+                                                                        : (const pw_f32x4*)(a.x + hv * a.x_cs + 4 * q));
       }
       *(pw_f32x4*)(xl + ((size_t)q * SP + s) * 4) = val;
     }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void pwgrad_kernel(PWgradArgs a) {
       int s = idx / DQ, q = idx - s * DQ;
       int64_t v = v0 + s;
       pw_f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (v < v_end) val = *(const pw_f32x4*)(a.dz + v * a.dz_cs + 4 * q);
+      if (v < v_end) val = __builtin_nontemporal_load((const pw_f32x4*)(a.dz + v * a.dz_cs + 4 * q));
       *(pw_f32x4*)(dl + ((size_t)q * SP + s) * 4) = val;
     }
     __syncthreads();

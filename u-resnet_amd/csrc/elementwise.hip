@@ -15,8 +15,26 @@ template <int VEC> struct VT;
 template <> struct VT<1> { typedef float T; };
 template <> struct VT<4> { typedef f32x4 T; };
 
-template <int VEC> __device__ inline typename VT<VEC>::T ldv(const float* p) { return *(const typename VT<VEC>::T*)p; }
-template <int VEC> __device__ inline void stv(float* p, typename VT<VEC>::T v) { *(typename VT<VEC>::T*)p = v; }
+// Streaming tensors are read once per pass: non-temporal loads keep them from evicting the reusable lines (weights,
+// halos of the concurrent conv kernels) -- measured bn_bwd 13.0 -> 11.7 ms, bn_act 4.5 -> 3.9 ms per cfg3 step together
+// with 8192-block grids (tools/ew_sweep.sh; non-temporal stores did not help).  Bit 0: loads, bit 1: stores.
+#ifndef URSN_EW_NT
+#define URSN_EW_NT 1
+#endif
+template <int VEC> __device__ inline typename VT<VEC>::T ldv(const float* p) {
+#if URSN_EW_NT & 1
+  return __builtin_nontemporal_load((const typename VT<VEC>::T*)p);
+#else
+  return *(const typename VT<VEC>::T*)p;
+#endif
+}
+template <int VEC> __device__ inline void stv(float* p, typename VT<VEC>::T v) {
+#if URSN_EW_NT & 2
+  __builtin_nontemporal_store(v, (typename VT<VEC>::T*)p);
+#else
+  *(typename VT<VEC>::T*)p = v;
+#endif
+}
 __device__ inline float elem(float v, int) { return v; }
 __device__ inline float elem(f32x4 v, int j) { return v[j]; }
 __device__ inline void setelem(float& v, int, float x) { v = x; }
@@ -32,8 +50,9 @@ static Map make_map(int64_t V, int C, int VEC) {
   m.shift = 0;
   while ((1 << m.shift) < m.CP) ++m.shift;
   m.VPB = 256 / m.CP;
+  static const int cap = getenv("URSN_EW_GRID") ? atoi(getenv("URSN_EW_GRID")) : 8192;
   int64_t blocks = cdiv64(V, (int64_t)m.VPB * 8);
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   m.grid = (int)blocks;
   return m;
