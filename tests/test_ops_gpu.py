@@ -411,6 +411,7 @@ IGEMM_CASES = [
     (2, 2, (32, 48), 32, 64), (2, 1, (19, 37), 64, 128), (2, 1, (16, 16), 256, 32),
     (3, 2, (24, 48, 48), 32, 32), (2, 4, (160, 160), 32, 32),   # enough boxes for the 32-wide co tiles (all-taps, 8-channel chunks)
     (3, 2, (6, 6, 6), 64, 32), (3, 1, (5, 7, 6), 32, 16), (3, 1, (7, 9, 10), 32, 32), (3, 2, (12, 12, 12), 32, 48),  # small-box variants
+    (3, 4, (24, 24, 24), 32, 64),   # 24-wide rows as 2 x 12 with 32-wide co tiles
 ]
 
 

@@ -33,6 +33,8 @@ static bool make_igplan(const ursn_conv_desc& d, ConvPass pass, IGPlan& p, int& 
   // small deep levels (3-D): boxes of 4x4x12 / 3x6x6 voxels with a per-lane voxel table (all-taps kernel, BM = 16)
   p.var = 0;
   if (at && p.mode == 3 && p.X <= 12) p.var = (p.X <= 6) ? 2 : 1;
+  const bool at32 = at >= 1 && at != 16;   // 32-wide co tiles also have the all-taps kernel
+  if (!p.var && at32 && p.mode == 3 && (p.X % 16) != 0 && (p.X % 16) <= 8 && (p.X % 12) == 0) p.var = 1;   // e.g. 24: 2 x 12 instead of 16 + 8
   if (p.X < 12 && !p.var && d.algo != 4) return false;
   const int BZ = p.mode == 3 ? (p.var == 2 ? 3 : 4) : 1, BY = p.mode == 3 ? (p.var == 2 ? 6 : 4) : 16,
             BX = p.var == 2 ? 6 : (p.var == 1 ? 12 : 16);
@@ -41,7 +43,8 @@ static bool make_igplan(const ursn_conv_desc& d, ConvPass pass, IGPlan& p, int& 
   p.nbx = (p.X + BX - 1) / BX;
   p.gridx = d.n * p.nbz * p.nby * p.nbx;
   // wide cout tiles reuse the staged input more, narrow ones give the small deep levels enough workgroups
-  if (p.var) p.bm = 16;
+  if (p.var == 2 || (p.var == 1 && !(at32 && kcout >= 32 && (int64_t)p.gridx * (kcout / 32) >= 384))) p.bm = 16;
+  else if (p.var == 1) p.bm = 32;
   else if (kcout >= 64 && p.gridx >= 512) p.bm = 64;
   else if (kcout >= 32 && (int64_t)p.gridx * (kcout / 32) >= 384) p.bm = 32;
   else p.bm = 16;
@@ -52,6 +55,8 @@ static bool make_igplan(const ursn_conv_desc& d, ConvPass pass, IGPlan& p, int& 
   if (p.alltaps) {
     const int kc = p.bm == 16 ? 16 : 8;
     p.lds = ((size_t)(kc / 4) * HZ * HY * HX * 4 + (size_t)(p.mode == 3 ? 27 : 9) * kc * p.bm) * sizeof(float);
+    static const int pad_kb = getenv("URSN_IGEMM_LDS_KB") ? atoi(getenv("URSN_IGEMM_LDS_KB")) : 0;   // A/B: caps the occupancy
+    if (pad_kb > 0 && p.lds < (size_t)pad_kb * 1024) p.lds = (size_t)pad_kb * 1024;
   }
   return true;
 }
@@ -81,6 +86,13 @@ static int dispatch_bm(const IGPlan& p, const IGemmArgs& a, hipStream_t s) {
   if (p.bm == 64) { ursn_note_kernel(p.flip ? "igemm_dgrad<64>" : "igemm<64>"); return dispatch_flags<MODE, 64>(p, a, s); }
   if (p.bm == 32 && p.alltaps) {
     ursn_note_kernel(p.flip ? "igemm_at_dgrad<32>" : "igemm_at<32>");
+    if constexpr (MODE == 3) {
+      if (p.var == 1) {
+        if (p.flip) return launch_ig_at<3, 32, 8, true, false, 1>(p, a, s);
+        if (a.stats_partial) return launch_ig_at<3, 32, 8, false, true, 1>(p, a, s);
+        return launch_ig_at<3, 32, 8, false, false, 1>(p, a, s);
+      }
+    }
     if (p.flip) return launch_ig_at<MODE, 32, 8, true, false>(p, a, s);
     if (a.stats_partial) return launch_ig_at<MODE, 32, 8, false, true>(p, a, s);
     return launch_ig_at<MODE, 32, 8, false, false>(p, a, s);
