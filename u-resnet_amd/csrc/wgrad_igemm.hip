@@ -24,13 +24,14 @@ struct IGWArgs {
   int nbz, nby, nbx, nboxes, boxes_per_group;
 };
 
-template <int MODE> struct WBox;
-template <> struct WBox<3> { static constexpr int BZ = 4, BY = 4, BX = 16, NT = 27, KZ = 3; };
-template <> struct WBox<2> { static constexpr int BZ = 1, BY = 16, BX = 16, NT = 9, KZ = 1; };
+template <int MODE, int VAR = 0> struct WBox;
+template <> struct WBox<3, 0> { static constexpr int BZ = 4, BY = 4, BX = 16, NT = 27, KZ = 3; };
+template <> struct WBox<3, 1> { static constexpr int BZ = 4, BY = 4, BX = 12, NT = 27, KZ = 3; };   // 12- and 24-wide rows
+template <> struct WBox<2, 0> { static constexpr int BZ = 1, BY = 16, BX = 16, NT = 9, KZ = 1; };
 
-template <int MODE, int MT>
+template <int MODE, int MT, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(IGWArgs a) {
-  using B = WBox<MODE>;
+  using B = WBox<MODE, VAR>;
   constexpr int BZ = B::BZ, BY = B::BY, BX = B::BX, NT = B::NT, KZ = B::KZ;
   constexpr int HZ = BZ + (KZ - 1), HY = BY + 2, HX = BX + 2, PS = HZ * HY * HX;
   constexpr int PSP = PS + ((2 - PS % 8) + 8) % 8;          // plane stride == 2 (mod 8) slots
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(IGWArgs a) {
       const float* xr = xl + ((vz * HY + vy) * HX) * 4;
       const float* dr = dl + (row * BX) * 4;
 #pragma unroll
-      for (int qx = 0; qx < (SPLITK ? 1 : 4); ++qx) {
+      for (int qx = 0; qx < (SPLITK ? 1 : BX / 4); ++qx) {
         float bv[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) bv[m] = dr[b_lane + ((size_t)m * 4 * DSP + 4 * qx) * 4];
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(256) void igw_reduce_kernel(float* __restrict__ dw,
 }
 
 struct IGWPlan {
+  int var;   // 1: 4x4x12 boxes (3-D rows of 12 / 24 voxels)
   int mode, mt, Z, Y, X, nbz, nby, nbx, nboxes, ngroups, bpg;
   size_t lds, scratch;
 };
@@ -229,7 +231,8 @@ static bool make_igwplan(const ursn_conv_desc& d, IGWPlan& p) {
   else { p.Z = 1; p.Y = d.in_sp[0]; p.X = d.in_sp[1]; }
   static const int min_x = getenv("URSN_IGEMM_MINX") ? atoi(getenv("URSN_IGEMM_MINX")) : 12;
   if (p.X < min_x && d.algo != 4) return false;
-  const int BZ = p.mode == 3 ? 4 : 1, BY = p.mode == 3 ? 4 : 16, BX = 16;
+  p.var = (p.mode == 3 && (p.X % 16) != 0 && (p.X % 16) <= 12 && (p.X % 12) == 0) ? 1 : 0;
+  const int BZ = p.mode == 3 ? 4 : 1, BY = p.mode == 3 ? 4 : 16, BX = p.var ? 12 : 16;
   p.nbz = (p.Z + BZ - 1) / BZ;
   p.nby = (p.Y + BY - 1) / BY;
   p.nbx = (p.X + BX - 1) / BX;
@@ -244,7 +247,7 @@ static bool make_igwplan(const ursn_conv_desc& d, IGWPlan& p) {
   const int taps = p.mode == 3 ? 27 : 9;
   const int HZ = p.mode == 3 ? 6 : 1, PS = HZ * (BY + 2) * (BX + 2);
   const int PSP = PS + ((2 - PS % 8) + 8) % 8;
-  p.lds = ((size_t)4 * PSP * 4 + (size_t)(4 * p.mt) * 258 * 4) * sizeof(float);
+  p.lds = ((size_t)4 * PSP * 4 + (size_t)(4 * p.mt) * (BZ * BY * BX + 2) * 4) * sizeof(float);
   p.scratch = (size_t)blocks * p.ngroups * taps * 16 * (16 * p.mt) * sizeof(float);
   return p.scratch <= ((size_t)1 << 30);
 }
@@ -258,9 +261,9 @@ size_t igemm_wgrad_scratch_bytes(const ursn_conv_desc& d) {
   return make_igwplan(d, p) ? p.scratch : 0;
 }
 
-template <int MODE, int MT>
+template <int MODE, int MT, int VAR = 0>
 static int launch_igw(const IGWPlan& p, const IGWArgs& a, dim3 grid, hipStream_t s) {
-  auto kern = igemm_wgrad_kernel<MODE, MT>;
+  auto kern = igemm_wgrad_kernel<MODE, MT, VAR>;
   static size_t attr_lds = 48 * 1024;
   if (p.lds > attr_lds) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
@@ -285,7 +288,8 @@ int launch_igemm_wgrad(const ursn_conv_desc& d, const float* x, const float* dy,
   dim3 grid(p.ngroups, d.cin / 16, d.cout / (16 * p.mt));
   ursn_note_kernel(p.mt == 2 ? "igemm_wgrad<32>" : "igemm_wgrad<16>");
   int rc;
-  if (p.mode == 3) rc = (p.mt == 2) ? launch_igw<3, 2>(p, a, grid, s) : launch_igw<3, 1>(p, a, grid, s);
+  if (p.mode == 3 && p.var == 1) rc = (p.mt == 2) ? launch_igw<3, 2, 1>(p, a, grid, s) : launch_igw<3, 1, 1>(p, a, grid, s);
+  else if (p.mode == 3) rc = (p.mt == 2) ? launch_igw<3, 2>(p, a, grid, s) : launch_igw<3, 1>(p, a, grid, s);
   else rc = (p.mt == 2) ? launch_igw<2, 2>(p, a, grid, s) : launch_igw<2, 1>(p, a, grid, s);
   if (rc) return rc;
   const int taps = p.mode == 3 ? 27 : 9;
