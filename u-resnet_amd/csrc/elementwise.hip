@@ -232,17 +232,29 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, int shift) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t v = v0 + u * stride;
-      if (v >= a.V) continue;
+      const bool ok = v < a.V;
       typename VT<VEC>::T y;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        float t = fmaf(elem(x[u], j), sc[j], sh[j]);
-        if (a.z2) t += fmaf(elem(x2[u], j), sc2[j], sh2[j]);
-        if (a.res) t += elem(r[u], j);
-        if (a.relu) t = fmaxf(t, 0.f);
+        float t = 0.f;
+        if (ok) {
+          t = fmaf(elem(x[u], j), sc[j], sh[j]);
+          if (a.z2) t += fmaf(elem(x2[u], j), sc2[j], sh2[j]);
+          if (a.res) t += elem(r[u], j);
+          if (a.relu) t = fmaxf(t, 0.f);
+        }
         setelem(y, j, t);
       }
-      stv<VEC>(a.y + v * a.ycs + c, y);
+      if (ok) stv<VEC>(a.y + v * a.ycs + c, y);
+      if (VEC == 4 && a.mask_out) {   // wave-uniform: the wave's 256 consecutive elements -> 4 ballots
+        const int lane = threadIdx.x & 63;
+        const int64_t grp = ((v - (lane >> shift)) * a.C) >> 8;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const unsigned long long b = __ballot(ok && elem(y, j) > 0.f);
+          if (lane == 0 && ok) a.mask_out[grp * 4 + j] = b;
+        }
+      }
     }
   }
 }
@@ -251,6 +263,7 @@ int launch_bn_act(const BnActArgs& a, hipStream_t s) {
   bool v4 = vec4_ok(a.C, {a.zcs, a.ycs, a.z2 ? a.z2cs : 0, a.res ? a.rescs : 0}, {a.z, a.y, a.z2, a.res});
   URSN_REQUIRE(v4 || a.C <= 256, "bn_act: unsupported channel count %d", a.C);
   Map m = make_map(a.V, a.C, v4 ? 4 : 1);
+  URSN_REQUIRE(!a.mask_out || (v4 && a.relu && bn_mask_ok(a.C)), "bn_act: relu bit mask needs the float4 path and C/4 a power of two");
   if (v4) hipLaunchKernelGGL(bn_act_kernel<4>, dim3(m.grid), dim3(256), 0, s, a, m.shift);
   else hipLaunchKernelGGL(bn_act_kernel<1>, dim3(m.grid), dim3(256), 0, s, a, m.shift);
   URSN_HIP(hipGetLastError());
@@ -271,7 +284,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int shi
   for (int j = 0; j < VEC; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.0;
   if (c < a.C) {
     float mu[VEC], rs[VEC], mu2[VEC], rs2[VEC], be[VEC];
-    const bool ymask = a.relu && a.y != nullptr, zmask = a.relu && a.y == nullptr;
+    const bool bmask = VEC == 4 && a.relu && a.mask != nullptr;
+    const bool ymask = !bmask && a.relu && a.y != nullptr, zmask = !bmask && a.relu && a.y == nullptr;
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       mu[j] = a.mean[c + j];
@@ -284,6 +299,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int shi
     const int64_t stride = (int64_t)gridDim.x * VPB;
     for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += stride * U) {
       typename VT<VEC>::T gv[U], xv[U], yv[U], x2v[U];
+      unsigned long long mw[U][VEC];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t v = v0 + u * stride;
@@ -292,6 +308,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int shi
           xv[u] = ldv<VEC>(a.z + v * a.zcs + c);
           if (ymask) yv[u] = ldv<VEC>(a.y + v * a.ycs + c);
           if (a.z2) x2v[u] = ldv<VEC>(a.z2 + v * a.z2cs + c);
+          if (bmask) {
+            const int64_t grp = ((v - (lane >> shift)) * a.C) >> 8;
+            const ulonglong2* mp = (const ulonglong2*)(a.mask + grp * 4);   // two 16-byte wave-uniform loads
+            const ulonglong2 m0 = mp[0], m1 = mp[1];
+            mw[u][0] = m0.x; mw[u][1] = m0.y; mw[u][VEC > 2 ? 2 : 0] = m1.x; mw[u][VEC > 3 ? 3 : 0] = m1.y;
+          }
         }
       }
 #pragma unroll
@@ -303,6 +325,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int shi
           const float xh0 = (elem(xv[u], j) - mu[j]) * rs[j];
           if (ymask && !(elem(yv[u], j) > 0.f)) gj = 0.f;
           if (zmask && !(fmaf(elem(xv[u], j), rs[j], be[j]) > 0.f)) gj = 0.f;   // same expression as bn_act
+          if (bmask && !((mw[u][j] >> lane) & 1ull)) gj = 0.f;
           double gd = (double)gj;
           acc[0][j] += gd;
           acc[1][j] += gd * (double)xh0;
@@ -337,7 +360,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int shif
   const int vr = threadIdx.x >> shift;
   if (c >= a.C) return;
   float mu[VEC], rs[VEC], mu2[VEC], rs2[VEC], mg[VEC], mgx[VEC], mgx2[VEC], be[VEC];
-  const bool ymask = a.relu && a.y != nullptr, zmask = a.relu && a.y == nullptr;
+  const bool bmask = VEC == 4 && a.relu && a.mask != nullptr;
+  const bool ymask = !bmask && a.relu && a.y != nullptr, zmask = !bmask && a.relu && a.y == nullptr;
+  const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     mu[j] = a.mean[c + j];
@@ -353,6 +378,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int shif
   const int64_t stride = (int64_t)gridDim.x * VPB;
   for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += stride * U) {
     typename VT<VEC>::T gv[U], xv[U], yv[U], x2v[U], drv[U];
+    unsigned long long mw[U][VEC];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t v = v0 + u * stride;
@@ -362,6 +388,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int shif
         if (ymask) yv[u] = ldv<VEC>(a.y + v * a.ycs + c);
         if (a.z2) x2v[u] = ldv<VEC>(a.z2 + v * a.z2cs + c);
         if (a.dres && a.dres_accumulate) drv[u] = ldv<VEC>(a.dres + v * a.drescs + c);
+        if (bmask) {
+          const int64_t grp = ((v - (lane >> shift)) * a.C) >> 8;
+          const ulonglong2* mp = (const ulonglong2*)(a.mask + grp * 4);
+          const ulonglong2 m0 = mp[0], m1 = mp[1];
+          mw[u][0] = m0.x; mw[u][1] = m0.y; mw[u][VEC > 2 ? 2 : 0] = m1.x; mw[u][VEC > 3 ? 3 : 0] = m1.y;
+        }
       }
     }
 #pragma unroll
@@ -375,6 +407,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int shif
         float xh = (elem(xv[u], j) - mu[j]) * rs[j];
         if (ymask && !(elem(yv[u], j) > 0.f)) gj = 0.f;
         if (zmask && !(fmaf(elem(xv[u], j), rs[j], be[j]) > 0.f)) gj = 0.f;
+        if (bmask && !((mw[u][j] >> lane) & 1ull)) gj = 0.f;
         setelem(dz, j, rs[j] * (gj - mg[j] - xh * mgx[j]));
         if (a.z2) {
           float xh2 = (elem(x2v[u], j) - mu2[j]) * rs2[j];
@@ -390,11 +423,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int shif
 }
 
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
-  URSN_REQUIRE(!a.relu || a.y || a.beta, "bn_bwd: relu mask needs y or beta");
-  bool v4 = vec4_ok(a.C, {a.dycs, (a.relu && a.y) ? a.ycs : 0, a.zcs, a.dzcs, a.z2 ? a.z2cs : 0, a.z2 ? a.dz2cs : 0,
+  URSN_REQUIRE(!a.relu || a.y || a.beta || a.mask, "bn_bwd: relu mask needs y, beta or the bit mask");
+  bool v4 = vec4_ok(a.C, {a.dycs, (a.relu && a.y && !a.mask) ? a.ycs : 0, a.zcs, a.dzcs, a.z2 ? a.z2cs : 0, a.z2 ? a.dz2cs : 0,
                           a.dres ? a.drescs : 0},
                     {a.dy, a.relu ? a.y : nullptr, a.z, a.dz, a.z2, a.dz2, a.dres});
   URSN_REQUIRE(v4 || a.C <= 256, "bn_bwd: unsupported channel count %d", a.C);
+  URSN_REQUIRE(!a.mask || (v4 && bn_mask_ok(a.C)), "bn_bwd: relu bit mask needs the float4 path and C/4 a power of two");
   Map m = make_map(a.V, a.C, v4 ? 4 : 1);
   double* partial = (double*)a.scratch;
   double* finals = partial + (size_t)m.grid * 3 * a.C;

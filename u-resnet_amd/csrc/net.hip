@@ -56,6 +56,7 @@ struct Unit {
   Act in, a1, out;
   Act in2;   // C > 0: the unit input is the never-materialised concat [in | in2] (decoder, narrow levels)
   bool a1_virtual = false;   // a1 = BN(z1) is never written: conv2 and its weight gradient normalise z1 while staging
+  unsigned long long* jmask = nullptr;   // bit mask (out > 0) of the join ReLU: the two BN-backward passes read it instead of out
 };
 
 }  // namespace
@@ -245,6 +246,11 @@ int plan(ursn_net* n, Arena& A) {
     u.a1 = make_act(n, A, lout, co, tr, u.a1_virtual);
     u.c2 = add_layer(n, A, scope + "/resnet_conv2", 0, 3, 1, co, co, lout, lout, poff);
     u.out = out_view ? *out_view : make_act(n, A, lout, co, tr);
+    {
+      const char* e = getenv("URSN_RELU_MASK");
+      if (tr && bn_mask_ok(co) && !(e && e[0] == '0'))
+        u.jmask = (unsigned long long*)A.take(bn_mask_words((int64_t)c.max_batch * n->lvox[lout], co) * sizeof(unsigned long long));
+    }
     n->units.push_back(u);
     n->named[u.scope] = u.out;
     n->named[n->layers[u.c1].name] = u.a1;
@@ -429,7 +435,8 @@ int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s, const A
   return 0;
 }
 
-int bn_out(ursn_net* n, int li, const Act& out, int relu, int N, int li2, const float* res, int rescs, hipStream_t s) {
+int bn_out(ursn_net* n, int li, const Act& out, int relu, int N, int li2, const float* res, int rescs, hipStream_t s,
+           unsigned long long* mask_out = nullptr) {
   Layer& L = n->layers[li];
   BnActArgs a;
   memset(&a, 0, sizeof(a));
@@ -440,6 +447,7 @@ int bn_out(ursn_net* n, int li, const Act& out, int relu, int N, int li2, const 
   }
   a.res = res; a.rescs = rescs;
   a.y = out.p; a.ycs = out.cs; a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.cout; a.relu = relu;
+  a.mask_out = mask_out;
   ProfScope ps(n, s, li, 4, 0.0, 4.0 * a.V * a.C * (2 + (li2 >= 0) + (res != nullptr)));
   URSN_TRY(launch_bn_act(a, s));
   ps.done("bn_act");
@@ -458,8 +466,9 @@ int unit_fwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
     URSN_TRY(bn_out(n, u.c1, u.a1, 0, N, -1, nullptr, 0, s));
     URSN_TRY(conv_stats(n, u.c2, u.a1, N, s));
   }
-  if (u.sc >= 0) URSN_TRY(bn_out(n, u.c2, u.out, 1, N, u.sc, nullptr, 0, s));
-  else URSN_TRY(bn_out(n, u.c2, u.out, 1, N, -1, u.in.p, u.in.cs, s));
+  unsigned long long* jm = n->cfg.trainable ? u.jmask : nullptr;
+  if (u.sc >= 0) URSN_TRY(bn_out(n, u.c2, u.out, 1, N, u.sc, nullptr, 0, s, jm));
+  else URSN_TRY(bn_out(n, u.c2, u.out, 1, N, -1, u.in.p, u.in.cs, s, jm));
   return 0;
 }
 
@@ -566,11 +575,11 @@ int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStre
 }
 
 int bn_back(ursn_net* n, int li, const float* dy, int dycs, const float* y, int ycs, int relu, int li2, float* dres,
-            int drescs, int dres_acc, int N, hipStream_t s) {
+            int drescs, int dres_acc, int N, hipStream_t s, const unsigned long long* mask = nullptr) {
   Layer& L = n->layers[li];
   BnBwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.dy = dy; a.dycs = dycs; a.y = y; a.ycs = ycs;
+  a.dy = dy; a.dycs = dycs; a.y = mask ? nullptr : y; a.ycs = ycs; a.mask = mask;
   a.z = L.z; a.zcs = L.zcs; a.mean = L.mean; a.rstd = L.rstd; a.dz = L.dz; a.dzcs = L.zcs;
   a.dbeta = n->grads + L.b_off;
   a.beta = n->params + L.b_off;
@@ -581,7 +590,7 @@ int bn_back(ursn_net* n, int li, const float* dy, int dycs, const float* y, int 
   }
   a.dres = dres; a.drescs = drescs; a.dres_accumulate = dres_acc;
   a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.cout; a.relu = relu; a.scratch = n->red_scratch;
-  ProfScope ps(n, s, li, 5, 0.0, 4.0 * a.V * a.C * (2.0 * (2 + relu + (li2 >= 0)) + 1 + (li2 >= 0) + (dres != nullptr)));
+  ProfScope ps(n, s, li, 5, 0.0, 4.0 * a.V * a.C * (2.0 * (2 + (relu && !mask) + (li2 >= 0)) + 1 + (li2 >= 0) + (dres != nullptr)));
   URSN_TRY(launch_bn_bwd(a, s));
   ps.done("bn_bwd");
   return 0;
@@ -590,10 +599,10 @@ int bn_back(ursn_net* n, int li, const float* dy, int dycs, const float* y, int 
 int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
   // join: g = dout * (out > 0); BN2 (and shortcut BN) backward; identity shortcut adds g into d(in)
   if (u.sc >= 0) {
-    URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, u.sc, nullptr, 0, 0, N, s));
+    URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, u.sc, nullptr, 0, 0, N, s, u.jmask));
   } else {
     bool acc = take_flag(n, u.in);
-    URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, -1, u.in.g, u.in.cs, acc ? 1 : 0, N, s));
+    URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, -1, u.in.g, u.in.cs, acc ? 1 : 0, N, s, u.jmask));
   }
   if (u.a1_virtual) {
     Act z1 = u.a1;   // x = z1 normalised on load, dx -> a1.g

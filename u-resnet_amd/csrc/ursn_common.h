@@ -162,8 +162,14 @@ struct BnActArgs {
   const float* res; int rescs;
   float* y; int ycs;
   int64_t V; int C; int relu;
+  // optional (relu, float4 path, C/4 a power of two): one bit per element, y > 0, for the backward pass -- stored per
+  // wave as 4 ballots (component j of lane l = element 4l + j of the wave's 256 consecutive elements); size
+  // bn_mask_words(V, C) 64-bit words
+  unsigned long long* mask_out;
 };
 int launch_bn_act(const BnActArgs& a, hipStream_t s);
+static inline size_t bn_mask_words(int64_t V, int C) { return (size_t)((V * C + 255) / 256) * 4; }
+static inline bool bn_mask_ok(int C) { int q = C / 4; return (C % 4) == 0 && q >= 1 && q <= 64 && (q & (q - 1)) == 0; }
 
 // Backward of the above.  g = dy * (relu ? y > 0 : 1).
 //   dz  = rstd  * (g - mean(g) - xhat  * mean(g*xhat))      dbeta  += sum g
@@ -177,6 +183,7 @@ struct BnBwdArgs {
   float* dres; int drescs; int dres_accumulate;
   int64_t V; int C; int relu;
   void* scratch;
+  const unsigned long long* mask;  // relu mask bits written by launch_bn_act (mask_out); replaces the y reads
 };
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
 
