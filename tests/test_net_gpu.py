@@ -271,3 +271,29 @@ def test_normalise_on_load_plan_matches_default(monkeypatch):
     assert abs(out["0"][0] - out["1"][0]) <= 1e-5 * abs(out["0"][0])
     for k, g0 in out["0"][1].items():
         assert l2_rel(out["1"][1][k], g0) < 1e-3, k
+
+
+def test_smaller_batch_on_a_larger_plan():
+    """A net planned for batch 3 then fed batch 1 (the workspace, slab scratch and statistics partials are sized at plan
+    time, the launch geometry is chosen per call): same loss and gradients as a net planned for batch 1."""
+    dims, base, ncls, ns = (32, 32, 64, 1), 8, 3, 2
+    P = as_f32_exact(oracle_params(dims, base, ncls, num_strides=ns))
+    d3, l3, w3 = make_inputs(dims, ncls, 3, seed=21)
+    big = build(dims, base, ncls, True, num_strides=ns)
+    big.set_variables(P)
+    big.zero_gradients(None)
+    big.accum_gradients(None, d3, l3, w3)          # plans for batch 3
+    big.zero_gradients(None)
+    r_big, _ = big.accum_gradients(None, d3[:1], l3[:1], w3[:1])
+    g_big = big.get_gradients()
+    one = build(dims, base, ncls, True, num_strides=ns)
+    one.set_variables(P)
+    one.zero_gradients(None)
+    r_one, _ = one.accum_gradients(None, d3[:1], l3[:1], w3[:1])
+    g_one = one.get_gradients()
+    assert abs(r_big[1] - r_one[1]) <= 1e-6 * abs(r_one[1])
+    for k, g0 in g_one.items():
+        assert l2_rel(g_big[k], g0) < 1e-5, k
+    sm_big = big.inference(None, d3[:2])[0]
+    sm_one = one.inference(None, d3[:2])[0]     # grows the second net's plan to batch 2
+    assert max_rel(sm_big, sm_one) < 1e-5

@@ -301,21 +301,27 @@ int plan(ursn_net* n, Arena& A) {
   for (const Layer& L : n->layers) {
     size_t r = reduce_scratch_bytes((int64_t)c.max_batch * n->lvox[L.lout], L.cout, 3);
     if (r > red) red = r;
-    size_t rt = tiled_conv_stats_scratch_doubles(L.desc) * sizeof(double);
-    if (rt > red) red = rt;
-    rt = tiled_deconv_stats_scratch_doubles(L.desc) * sizeof(double);
-    if (rt > red) red = rt;
-    rt = igemm_stats_scratch_doubles(L.desc) * sizeof(double);
-    if (rt > red) red = rt;
-    rt = pointwise_stats_scratch_doubles(L.desc) * sizeof(double);
-    if (rt > red) red = rt;
-    rt = stride2_stats_scratch_doubles(L.desc) * sizeof(double);
-    if (rt > red) red = rt;
-    rt = lds_scatter_stats_scratch_doubles(L.desc) * sizeof(double);
-    if (rt > red) red = rt;
-    if (tr) {
-      size_t w = ursn_conv_wgrad_scratch_bytes(&L.desc);
-      if (w > wg) wg = w;
+    // the launch geometry (z segments, box groups) is chosen per call from the batch actually fed, and a smaller batch
+    // can split finer than the planned one: size the partial-sum and slab scratch for every batch up to max_batch
+    for (int nb = 1; nb <= c.max_batch; ++nb) {
+      ursn_conv_desc d = L.desc;
+      d.n = nb;
+      size_t rt = tiled_conv_stats_scratch_doubles(d) * sizeof(double);
+      if (rt > red) red = rt;
+      rt = tiled_deconv_stats_scratch_doubles(d) * sizeof(double);
+      if (rt > red) red = rt;
+      rt = igemm_stats_scratch_doubles(d) * sizeof(double);
+      if (rt > red) red = rt;
+      rt = pointwise_stats_scratch_doubles(d) * sizeof(double);
+      if (rt > red) red = rt;
+      rt = stride2_stats_scratch_doubles(d) * sizeof(double);
+      if (rt > red) red = rt;
+      rt = lds_scatter_stats_scratch_doubles(d) * sizeof(double);
+      if (rt > red) red = rt;
+      if (tr) {
+        size_t w = ursn_conv_wgrad_scratch_bytes(&d);
+        if (w > wg) wg = w;
+      }
     }
   }
   n->red_scratch = A.take(red + 256);
