@@ -199,6 +199,9 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
     f32x4 acc[CQ];
 #pragma unroll
     for (int cq = 0; cq < CQ; ++cq) acc[cq] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // one produced channel quad (the 3|4-channel logits layer) would be a single chain of dependent MFMAs: split the
+    // contraction over a second accumulator
+    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
     f32x4 pv[(FLIP && CIN <= 16) ? NQ : 1];
     if constexpr (FLIP && CIN <= 16) {
       if (a.pw_in) {  // this lane's voxel of the shortcut gradient (clamped for out-of-range lanes: MFMA needs all lanes)
@@ -222,7 +225,10 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
             constexpr int k = t * CIN + 4 * q + j;
             static_for<CQ>([&](auto C) {
               constexpr int cq = decltype(C)::value;
-              acc[cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[cq][k / 16], xv[j], acc[cq], 4, k % 16, 0);
+              if constexpr (CQ == 1 && (k & 1))
+                acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[cq][k / 16], xv[j], acc2, 4, k % 16, 0);
+              else
+                acc[cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[cq][k / 16], xv[j], acc[cq], 4, k % 16, 0);
             });
           });
         });
@@ -244,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
 #pragma unroll
       for (int cq = 0; cq < CQ; ++cq) {
         f32x4 v = acc[cq];
+        if constexpr (CQ == 1) v += acc2;
         if (a.accumulate) v += *(f32x4*)(op + 4 * cq);
 #if URSN_TCONV_NT_STORE
         __builtin_nontemporal_store(v, (f32x4*)(op + 4 * cq));
