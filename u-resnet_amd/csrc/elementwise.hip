@@ -16,10 +16,13 @@ template <> struct VT<1> { typedef float T; };
 template <> struct VT<4> { typedef f32x4 T; };
 
 // Streaming tensors are read once per pass: non-temporal loads keep them from evicting the reusable lines (weights,
-// halos of the concurrent conv kernels) -- measured bn_bwd 13.0 -> 11.7 ms, bn_act 4.5 -> 3.9 ms per cfg3 step together
-// with 8192-block grids (tools/ew_sweep.sh; non-temporal stores did not help).  Bit 0: loads, bit 1: stores.
+// halos of the concurrent conv kernels) -- measured bn_bwd 13.0 -> 11.7 ms, bn_act 4.5 -> 3.9 ms per cfg3 step
+// (tools/ew_sweep.sh; non-temporal stores did not help).  Bit 0: loads, bit 1: stores.
 #ifndef URSN_EW_NT
 #define URSN_EW_NT 1
+#endif
+#ifndef URSN_EW_U
+#define URSN_EW_U 2   // voxels (float4 per array) in flight per thread: 124-140 VGPRs in the BN-backward kernels (4: 196-228)
 #endif
 template <int VEC> __device__ inline typename VT<VEC>::T ldv(const float* p) {
 #if URSN_EW_NT & 1
@@ -50,7 +53,7 @@ static Map make_map(int64_t V, int C, int VEC) {
   m.shift = 0;
   while ((1 << m.shift) < m.CP) ++m.shift;
   m.VPB = 256 / m.CP;
-  static const int cap = getenv("URSN_EW_GRID") ? atoi(getenv("URSN_EW_GRID")) : 8192;
+  static const int cap = getenv("URSN_EW_GRID") ? atoi(getenv("URSN_EW_GRID")) : 512;   // two long-lived workgroups per CU (tools/lib_ab.sh)
   int64_t blocks = cdiv64(V, (int64_t)m.VPB * 8);
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, int shift) {
   }
   // 4 voxels per iteration, all loads issued before the first use (the struct pointers may alias, so the
   // compiler will not hoist them itself): keeps 4x the bytes in flight per wave
-  constexpr int U = 4;
+  constexpr int U = URSN_EW_U;
   const int64_t stride = (int64_t)gridDim.x * VPB;
   for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += stride * U) {
     typename VT<VEC>::T x[U], x2[U], r[U];
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int shi
       rs2[j] = a.z2 ? a.rstd2[c + j] : 0.f;
       be[j] = zmask ? a.beta[c + j] - mu[j] * rs[j] : 0.f;   // shift of the forward pass
     }
-    constexpr int U = 4;
+    constexpr int U = URSN_EW_U;
     const int64_t stride = (int64_t)gridDim.x * VPB;
     for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += stride * U) {
       typename VT<VEC>::T gv[U], xv[U], yv[U], x2v[U];
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int shif
     mgx[j] = (float)finals[a.C + c + j];
     mgx2[j] = (float)finals[2 * a.C + c + j];
   }
-  constexpr int U = 4;
+  constexpr int U = URSN_EW_U;
   const int64_t stride = (int64_t)gridDim.x * VPB;
   for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += stride * U) {
     typename VT<VEC>::T gv[U], xv[U], yv[U], x2v[U], drv[U];
