@@ -55,5 +55,12 @@ def inter():
     for _ in range(R):
         bn(sa, 1); wg(sb, 1)
 t_int = timed(inter) / R
+# who stretches when both run?  per-stream durations of ONE concurrent pair
+e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+torch.cuda.synchronize()
+e[0].record(sa); bn(sa, 1); e[1].record(sa)
+e[2].record(sb); wg(sb, 1); e[3].record(sb)
+torch.cuda.synchronize()
+print("concurrent pair: bn stream %.3f ms, wgrad stream %.3f ms" % (e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])))
 print("bn_bwd alone %.3f ms, wgrad alone %.3f ms, sum %.3f; both streams %.3f (bulk issue) %.3f (interleaved issue)" % (
     t_bn, t_wg, t_bn + t_wg, t_both, t_int))
