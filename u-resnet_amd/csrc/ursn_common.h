@@ -8,7 +8,23 @@
 
 void ursn_set_error(const char* fmt, ...);
 void ursn_note_kernel(const char* name);  // remembered per thread for the profiling log
-void ursn_relabel_kernel(const char* name);   // rename the last dispatch without counting a launch
+void ursn_relabel_kernel(const char* name);
+#ifdef __HIPCC__
+// Workgroup i runs on XCD i % 8 (each XCD has its own L2).  Maps the hardware workgroup id to a logical tile index so
+// that every XCD works through one contiguous eighth of the tile list: spatial neighbours (shared halos) meet in the
+// same L2.  URSN_XCD_REMAP=0 at build time keeps the identity (A/B).
+#ifndef URSN_XCD_REMAP
+#define URSN_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int ursn_xcd_block(int b, int G) {
+#if URSN_XCD_REMAP
+  const int q = G >> 3, r = G & 7, x = b & 7, i = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+#else
+  return b;
+#endif
+}
+#endif   // rename the last dispatch without counting a launch
 long ursn_kernel_launch_count();
 
 #define URSN_HIP(expr)                                                                   \

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int il = lane & 15, kl = lane >> 4;
-  int bid = blockIdx.x;
+  int bid = ursn_xcd_block(blockIdx.x, gridDim.x);
   const int xt = bid % a.ntx; bid /= a.ntx;
   const int yt = bid % a.nty; bid /= a.nty;
   const int zs = bid % a.nzseg;
