@@ -78,6 +78,7 @@ struct ursn_net {
   float* dlog = nullptr;     // d loss / d logits  [V0, ncls]
   float* metrics = nullptr;  // device [4]
   void* red_scratch = nullptr;
+  void* red_scratch2 = nullptr;   // statistics partials of the shortcut convs running on the second stream (forward)
   void* head_scratch = nullptr;
   void* wg_scratch = nullptr;
   size_t wg_scratch_bytes = 0;
@@ -95,6 +96,8 @@ struct ursn_net {
   hipStream_t s2_owned = nullptr;   // s2 == s2_owned when the overlap is switched on
   std::vector<hipEvent_t> sync_pool;
   size_t sync_used = 0;
+  std::vector<hipEvent_t> fwd_pool;   // forward: fork / join events of the side-stream shortcut convs
+  size_t fwd_used = 0;
   hipEvent_t s2_done = nullptr;
   std::map<std::string, Act> named;       // debug lookup: activations
   std::map<std::string, int> named_z;     // layer name -> layer index
@@ -325,6 +328,22 @@ int plan(ursn_net* n, Arena& A) {
     }
   }
   n->red_scratch = A.take(red + 256);
+  {
+    size_t red2 = 0;
+    for (const Unit& u : n->units) {
+      if (u.sc < 0) continue;
+      const Layer& L = n->layers[u.sc];
+      size_t r = reduce_scratch_bytes((int64_t)c.max_batch * n->lvox[L.lout], L.cout, 3);
+      if (r > red2) red2 = r;
+      for (int nb = 1; nb <= c.max_batch; ++nb) {
+        ursn_conv_desc d = L.desc;
+        d.n = nb;
+        r = pointwise_stats_scratch_doubles(d) * sizeof(double);
+        if (r > red2) red2 = r;
+      }
+    }
+    n->red_scratch2 = A.take(red2 + 256);
+  }
   n->wg_scratch_bytes = wg;
   n->wg_scratch = tr ? A.take(wg + 256) : nullptr;
 
@@ -374,7 +393,9 @@ double layer_bytes(const ursn_net* n, const Layer& L, int N) {  // x + y + w  (=
 }
 
 // ---- forward pieces -----------------------------------------------------------------------
-int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s, const Act* in2 = nullptr, int aff = -1) {
+int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s, const Act* in2 = nullptr, int aff = -1,
+               void* red_scratch = nullptr) {
+  if (!red_scratch) red_scratch = n->red_scratch;
   Layer& L = n->layers[li];
   ursn_conv_desc d = L.desc;
   d.n = N;
@@ -387,42 +408,42 @@ int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s, const A
   }
   if (pointwise_conv_supported(d, PASS_FWD, 0)) {  // 1x1 shortcut + BN-statistics partials in one pass
     ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
-    URSN_TRY(launch_pointwise_conv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)n->red_scratch,
+    URSN_TRY(launch_pointwise_conv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)red_scratch,
                                    n->cfg.bn_eps, L.mean, L.rstd, s));
     ps.done(ursn_last_kernel_name());
     return 0;
   }
   if (igemm_conv_supported(d, PASS_FWD)) {  // LDS-staged implicit GEMM + BN-statistics partials in one pass
     ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
-    URSN_TRY(launch_igemm_conv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)n->red_scratch,
+    URSN_TRY(launch_igemm_conv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)red_scratch,
                                n->cfg.bn_eps, L.mean, L.rstd, s));
     ps.done(ursn_last_kernel_name());
     return 0;
   }
   if (stride2_conv_supported(d, PASS_FWD)) {  // LDS-staged stride-2 conv + BN-statistics partials in one pass
     ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
-    URSN_TRY(launch_stride2_conv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)n->red_scratch,
+    URSN_TRY(launch_stride2_conv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)red_scratch,
                                  n->cfg.bn_eps, L.mean, L.rstd, s));
     ps.done(ursn_last_kernel_name());
     return 0;
   }
   if (prefer_lds_scatter(d, PASS_FWD)) {  // LDS-staged transposed conv + BN-statistics partials in one pass
     ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
-    URSN_TRY(launch_lds_scatter(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)n->red_scratch,
+    URSN_TRY(launch_lds_scatter(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)red_scratch,
                                 n->cfg.bn_eps, L.mean, L.rstd, s));
     ps.done(ursn_last_kernel_name());
     return 0;
   }
   if (tiled_deconv_supported(d, PASS_FWD)) {  // transposed conv + BN-statistics partials in one pass
     ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
-    URSN_TRY(launch_tiled_deconv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)n->red_scratch,
+    URSN_TRY(launch_tiled_deconv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)red_scratch,
                                  n->cfg.bn_eps, L.mean, L.rstd, s));
     ps.done(ursn_last_kernel_name());
     return 0;
   }
   if (tiled_conv_supported(d, PASS_FWD)) {  // conv + BN-statistics partials in one pass
     ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
-    URSN_TRY(launch_tiled_conv_bn(d, in.p, n->params + L.w_off, L.z, (double*)n->red_scratch, n->cfg.bn_eps, L.mean,
+    URSN_TRY(launch_tiled_conv_bn(d, in.p, n->params + L.w_off, L.z, (double*)red_scratch, n->cfg.bn_eps, L.mean,
                                   L.rstd, s));
     ps.done(ursn_last_kernel_name());
     return 0;
@@ -435,7 +456,7 @@ int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s, const A
   {
     ProfScope ps(n, s, li, 3, 0.0, 4.0 * N * n->lvox[L.lout] * L.cout);
     URSN_TRY(launch_bn_stats(L.z, L.zcs, (int64_t)N * n->lvox[L.lout], L.cout, n->cfg.bn_eps, L.mean, L.rstd,
-                             n->red_scratch, s));
+                             red_scratch, s));
     ps.done("bn_stats");
   }
   return 0;
@@ -460,9 +481,33 @@ int bn_out(ursn_net* n, int li, const Act& out, int relu, int N, int li2, const 
   return 0;
 }
 
+hipEvent_t fwd_event(ursn_net* n) {
+  if (n->fwd_used == n->fwd_pool.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    n->fwd_pool.push_back(e);
+  }
+  return n->fwd_pool[n->fwd_used++];
+}
+
 int unit_fwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
   const Act* in2 = u.in2.C ? &u.in2 : nullptr;
-  if (u.sc >= 0) URSN_TRY(conv_stats(n, u.sc, u.in, N, s, in2));
+  // the 1x1 shortcut is HBM-bound and independent of conv1 / conv2 until the join: it runs beside them on the second stream
+  hipEvent_t side_done = nullptr;
+  if (u.sc >= 0) {
+    static const bool side_off = getenv("URSN_FWD_SIDE_STREAM") && getenv("URSN_FWD_SIDE_STREAM")[0] == '0';
+    hipEvent_t fork = (n->s2 && !side_off) ? fwd_event(n) : nullptr;
+    hipEvent_t join = fork ? fwd_event(n) : nullptr;
+    if (fork && join) {
+      URSN_HIP(hipEventRecord(fork, s));
+      URSN_HIP(hipStreamWaitEvent(n->s2, fork, 0));
+      URSN_TRY(conv_stats(n, u.sc, u.in, N, n->s2, in2, -1, n->red_scratch2));
+      URSN_HIP(hipEventRecord(join, n->s2));
+      side_done = join;
+    } else {
+      URSN_TRY(conv_stats(n, u.sc, u.in, N, s, in2));
+    }
+  }
   URSN_TRY(conv_stats(n, u.c1, u.in, N, s, in2));
   if (u.a1_virtual) {
     Act z1 = u.a1;
@@ -473,6 +518,7 @@ int unit_fwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
     URSN_TRY(conv_stats(n, u.c2, u.a1, N, s));
   }
   unsigned long long* jm = n->cfg.trainable ? u.jmask : nullptr;
+  if (side_done) URSN_HIP(hipStreamWaitEvent(s, side_done, 0));
   if (u.sc >= 0) URSN_TRY(bn_out(n, u.c2, u.out, 1, N, u.sc, nullptr, 0, s, jm));
   else URSN_TRY(bn_out(n, u.c2, u.out, 1, N, -1, u.in.p, u.in.cs, s, jm));
   return 0;
@@ -480,6 +526,7 @@ int unit_fwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
 
 int forward(ursn_net* n, const float* data, int N, hipStream_t s) {
   const int ns = n->cfg.num_strides;
+  n->fwd_used = 0;
   Act din = n->a_data;
   din.p = const_cast<float*>(data);
   URSN_TRY(conv_stats(n, n->conv0, din, N, s));
@@ -714,7 +761,7 @@ extern "C" int ursn_create(const ursn_config* cfg, float* params, float* grads, 
   n->params = params; n->grads = grads; n->adam_m = adam_m; n->adam_v = adam_v;
   {
     const char* e = getenv("URSN_WGRAD_STREAM");
-    if (n->cfg.trainable && !(e && e[0] == '0')) {
+    if (!(e && e[0] == '0')) {   // also for inference-only nets: the forward pass runs the shortcut convs on it
       int prio_lo = 0, prio_hi = 0;   // lowest priority: the dgrad / BN chain on the caller's stream is the critical path
       (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
       const char* pe = getenv("URSN_WGRAD_PRIO");
@@ -746,6 +793,7 @@ extern "C" int ursn_destroy(ursn_net* net) {
   if (net->s2_owned) { (void)hipStreamSynchronize(net->s2_owned); (void)hipStreamDestroy(net->s2_owned); }
   if (net->s2_done) (void)hipEventDestroy(net->s2_done);
   for (hipEvent_t e : net->sync_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : net->fwd_pool) (void)hipEventDestroy(e);
   for (hipEvent_t e : net->ev_pool) (void)hipEventDestroy(e);
   delete net;
   return 0;
