@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IGemmArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int il = lane & 15, kl = lane >> 4;
-  int bid = blockIdx.x;
+  int bid = ursn_xcd_block(blockIdx.x, gridDim.x);
   const int bx = bid % a.nbx; bid /= a.nbx;
   const int by = bid % a.nby; bid /= a.nby;
   const int bz = bid % a.nbz;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int il = lane & 15, kl = lane >> 4;
-  int bid = blockIdx.x;
+  int bid = ursn_xcd_block(blockIdx.x, gridDim.x);
   const int bx = bid % a.nbx; bid /= a.nbx;
   const int by = bid % a.nby; bid /= a.nby;
   const int bz = bid % a.nbz;

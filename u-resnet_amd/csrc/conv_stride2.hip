@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(S2Args a) {
 
   // work items = (box, 8-channel chunk); the next item's global loads are in flight during this item's MFMAs
   const int nchunks = a.cin / 8;
-  const int box_begin = blockIdx.x * a.bpw;
+  const int box_begin = ursn_xcd_block(blockIdx.x, gridDim.x) * a.bpw;
   int box_end = box_begin + a.bpw;
   if (box_end > a.nboxes) box_end = a.nboxes;
   const int nitems = (box_end - box_begin) * nchunks;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void s2wgrad_kernel(S2WArgs a) {
     }
   };
 
-  const int box_begin = blockIdx.x * a.bpg;
+  const int box_begin = ursn_xcd_block(blockIdx.x, gridDim.x) * a.bpg;
   int box_end = box_begin + a.bpg;
   if (box_end > a.nboxes) box_end = a.nboxes;
   s2_f32x4 sv4[NH], cv4[NC];

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
   extern __shared__ __attribute__((aligned(16))) f32x4 dlds[];  // [3 ring slots][NQ][PS]
 
   const int tid = threadIdx.x, lane = tid & 63;
-  int bid = blockIdx.x;
+  int bid = ursn_xcd_block(blockIdx.x, gridDim.x);
   const int xt = bid % a.ntx; bid /= a.ntx;
   const int yt = bid % a.nty; bid /= a.nty;
   const int zs = bid % a.nzseg;

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(512, 2) void twgrad4_kernel(TWgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bl = lane >> 2, il = lane & 3;
-  int bid = blockIdx.x;
+  int bid = ursn_xcd_block(blockIdx.x, gridDim.x);
   const int xt = bid % a.ntx; bid /= a.ntx;
   const int yt = bid % a.nty; bid /= a.nty;
   const int zs = bid % a.nzseg;

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(IGWArgs a) {
     }
   };
 
-  const int box_begin = blockIdx.x * a.boxes_per_group;
+  const int box_begin = ursn_xcd_block(blockIdx.x, gridDim.x) * a.boxes_per_group;
   int box_end = box_begin + a.boxes_per_group;
   if (box_end > a.nboxes) box_end = a.nboxes;
   iw_f32x4 xv[NHX], dv[NHD];
