@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int shi
 // finals: [3][C] doubles = mean(g), mean(g*xhat), mean(g*xhat2); dbeta(+2) += sum g
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ partial, int nblocks, int C,
                                                            int64_t V, double* __restrict__ finals,
-                                                           float* __restrict__ dbeta, float* __restrict__ dbeta2) {
+                                                           float* __restrict__ dbeta, float* __restrict__ dbeta2, int Cw) {
   const int c = blockIdx.x;
   double s[3];
   reduce_partials<3>(partial, nblocks, C, c, s);
@@ -351,6 +351,7 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restr
   finals[c] = s[0] / (double)V;
   finals[C + c] = s[1] / (double)V;
   finals[2 * C + c] = s[2] / (double)V;
+  if (c >= Cw) return;   // padded channel of the logits layer: no parameter behind it
   if (dbeta) dbeta[c] += (float)s[0];
   if (dbeta2) dbeta2[c] += (float)s[0];
 }
@@ -439,7 +440,7 @@ int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(m.grid), dim3(256), 0, s, a, m.shift, partial);
   URSN_HIP(hipGetLastError());
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(a.C), dim3(256), 0, s, (const double*)partial, m.grid, a.C, a.V, finals,
-                     a.dbeta, a.z2 ? a.dbeta2 : nullptr);
+                     a.dbeta, a.z2 ? a.dbeta2 : nullptr, a.Cw > 0 ? a.Cw : a.C);
   URSN_HIP(hipGetLastError());
   if (v4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(m.grid), dim3(256), 0, s, a, m.shift, (const double*)finals);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(m.grid), dim3(256), 0, s, a, m.shift, (const double*)finals);
@@ -470,10 +471,14 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a, double* __restric
     float z[URSN_MAX_CLASS];
     float m = -INFINITY;
     int arg = 0;
+    const bool v4 = a.z_cs == 4 && a.ncls <= 4;   // 3|4 classes in 4-padded logits: one 16-byte load
+    f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+    if (v4) zv = __builtin_nontemporal_load((const f32x4*)(a.z + p * 4));
 #pragma unroll
     for (int k = 0; k < URSN_MAX_CLASS; ++k) {
       if (k < a.ncls) {
-        z[k] = fmaf(a.z[p * a.z_cs + k], sc[k], sh[k]);
+        const float raw = (v4 && k < 4) ? zv[k & 3] : a.z[p * a.z_cs + k];
+        z[k] = fmaf(raw, sc[k], sh[k]);
         if (z[k] > m) { m = z[k]; arg = k; }  // strict '>' keeps the lowest index on ties
       }
     }
@@ -510,9 +515,18 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a, double* __restric
       n_nz += nz;
       n_ok_nz += (okp && nz);
       if (a.dlogits) {
+        const int dcs = a.dl_cs > 0 ? a.dl_cs : a.ncls;
+        if (dcs == 4 && a.ncls <= 4) {
+          f32x4 dv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < URSN_MAX_CLASS; ++k)
-          if (k < a.ncls) a.dlogits[p * a.ncls + k] = w * invn * (e[k] * inv - (k == labc ? 1.f : 0.f));
+          for (int k = 0; k < 4; ++k)
+            if (k < a.ncls) dv[k] = w * invn * (e[k] * inv - (k == labc ? 1.f : 0.f));
+          *(f32x4*)(a.dlogits + p * 4) = dv;
+        } else {
+#pragma unroll
+          for (int k = 0; k < URSN_MAX_CLASS; ++k)
+            if (k < a.ncls) a.dlogits[p * dcs + k] = w * invn * (e[k] * inv - (k == labc ? 1.f : 0.f));
+        }
       }
     }
   }

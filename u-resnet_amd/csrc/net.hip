@@ -150,8 +150,8 @@ int add_layer(ursn_net* n, Arena& A, const std::string& name, int kind, int k, i
   int64_t e = (int64_t)n->cfg.max_batch * n->lvox[lout] * L.zcs;
   L.z = A.floats(e);
   L.dz = n->cfg.trainable ? A.floats(e) : nullptr;
-  L.mean = A.floats(co);
-  L.rstd = A.floats(co);
+  L.mean = A.floats(L.zcs);   // padded like z: pad entries stay 0 (a BN over the padded channel count yields dz = 0 there)
+  L.rstd = A.floats(L.zcs);
   n->layers.push_back(L);
   n->named_z[L.name] = (int)n->layers.size() - 1;
   return (int)n->layers.size() - 1;
@@ -297,7 +297,7 @@ int plan(ursn_net* n, Arena& A) {
   n->conv2 = add_layer(n, A, "conv2", 0, 3, 1, F, c.num_class, 0, 0, poff);
 
   const int64_t V0 = (int64_t)c.max_batch * n->lvox[0];
-  n->dlog = tr ? A.floats(V0 * c.num_class) : nullptr;
+  n->dlog = tr ? A.floats(V0 * n->layers[n->conv2].zcs) : nullptr;   // channel stride = conv2's padded stride
   n->metrics = A.floats(8);
   n->head_scratch = A.take(head_scratch_bytes(c.max_batch, n->lvox[0]) + 64);
   size_t red = 0, wg = 0;
@@ -558,6 +558,7 @@ int head(ursn_net* n, const float* data, const float* label, const float* weight
   a.data_cs = n->cfg.cin;
   a.label = label; a.weight = weight; a.n = N; a.pix = n->lvox[0]; a.ncls = n->cfg.num_class;
   a.softmax_out = softmax_out; a.dlogits = want_grad ? n->dlog : nullptr;
+  a.dl_cs = L.zcs;
   a.ana_out = ana_out;
   a.scratch = n->head_scratch; a.metrics = n->metrics;
   ProfScope ps(n, s, n->conv2, 6, 0.0, 4.0 * N * n->lvox[0] * (2.0 * a.ncls + 3));
@@ -643,6 +644,7 @@ int bn_back(ursn_net* n, int li, const float* dy, int dycs, const float* y, int 
   }
   a.dres = dres; a.drescs = drescs; a.dres_accumulate = dres_acc;
   a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.cout; a.relu = relu; a.scratch = n->red_scratch;
+  if (L.zcs != L.cout && li2 < 0 && !relu && dycs == L.zcs && !dres) { a.C = L.zcs; a.Cw = L.cout; }   // logits layer: float4 path
   ProfScope ps(n, s, li, 5, 0.0, 4.0 * a.V * a.C * (2.0 * (2 + (relu && !mask) + (li2 >= 0)) + 1 + (li2 >= 0) + (dres != nullptr)));
   URSN_TRY(launch_bn_bwd(a, s));
   ps.done("bn_bwd");
@@ -683,7 +685,7 @@ int backward(ursn_net* n, const float* data, int N, hipStream_t s) {
   for (size_t i = 0; i < n->ginit.size(); ++i) n->ginit[i] = 0;
   n->sync_used = 0;
   Layer& L2 = n->layers[n->conv2];
-  URSN_TRY(bn_back(n, n->conv2, n->dlog, L2.cout, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
+  URSN_TRY(bn_back(n, n->conv2, n->dlog, L2.zcs, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));   // over the padded channels
   URSN_TRY(conv_bwd(n, n->conv2, n->a_conv1, true, N, s));
   URSN_TRY(bn_back(n, n->conv1, n->a_conv1.g, n->a_conv1.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
   URSN_TRY(conv_bwd(n, n->conv1, n->a_pre1, true, N, s));
@@ -778,8 +780,17 @@ extern "C" int ursn_create(const ursn_config* cfg, float* params, float* grads, 
   for (const Layer& L : n->layers) {  // pad channels of z/dz are never written afterwards: keep them 0 (not NaN)
     if (L.zcs == L.cout) continue;
     size_t bytes = (size_t)n->cfg.max_batch * n->lvox[L.lout] * L.zcs * sizeof(float);
-    if (hipMemset(L.z, 0, bytes) != hipSuccess || (L.dz && hipMemset(L.dz, 0, bytes) != hipSuccess)) {
+    if (hipMemset(L.mean, 0, L.zcs * sizeof(float)) != hipSuccess || hipMemset(L.rstd, 0, L.zcs * sizeof(float)) != hipSuccess ||
+        hipMemset(L.z, 0, bytes) != hipSuccess || (L.dz && hipMemset(L.dz, 0, bytes) != hipSuccess)) {
       ursn_set_error("create: hipMemset of padded logits buffers failed");
+      delete n;
+      return 1;
+    }
+  }
+  if (n->dlog) {  // pad lanes of the logits gradient (3|5 classes in 4|8 channels) must be finite: the BN backward runs over them
+    const Layer& LL = n->layers[n->conv2];
+    if (hipMemset(n->dlog, 0, (size_t)n->cfg.max_batch * n->lvox[0] * LL.zcs * sizeof(float)) != hipSuccess) {
+      ursn_set_error("create: hipMemset of the logits gradient failed");
       delete n;
       return 1;
     }

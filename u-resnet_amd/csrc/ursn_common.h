@@ -200,6 +200,7 @@ struct BnBwdArgs {
   int64_t V; int C; int relu;
   void* scratch;
   const unsigned long long* mask;  // relu mask bits written by launch_bn_act (mask_out); replaces the y reads
+  int Cw;  // channels that own a dbeta entry (0 = C); C may be the 4-padded count of the logits layer (pad: mean = rstd = 0)
 };
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
 
@@ -209,6 +210,7 @@ struct HeadArgs {
   const float* data; int data_cs; const float* label; const float* weight;
   int n; int64_t pix; int ncls;
   float* softmax_out; float* dlogits;  // nullable
+  int dl_cs;                           // channel stride of dlogits (0 = ncls); 4 with ncls <= 4: one 16-byte store per pixel
   float* ana_out;                      // nullable: ssnet label volume (lib/ssnet_trainval.py:285-287), [n*pix]
   double* partial;                     // [nblocks][4]
   float* metrics;                      // device [3 + 1]
