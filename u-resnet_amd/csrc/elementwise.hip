@@ -544,21 +544,31 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a, double* __restric
   if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] = sm[threadIdx.x][0];
 }
 
-__global__ void head_final_kernel(const double* __restrict__ partial, int nblocks, int n, int64_t pix,
-                                  float* __restrict__ metrics) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void head_final_kernel(const double* __restrict__ partial, int nblocks, int n, int64_t pix,
+                                                         float* __restrict__ metrics) {
+  // 256 threads, fixed assignment of partials to threads and a fixed tree: reproducible
+  __shared__ double sm[4][256];
   double s[4] = {0, 0, 0, 0};
-  for (int b = 0; b < nblocks; ++b)
+  for (int b = threadIdx.x; b < nblocks; b += 256)
     for (int k = 0; k < 4; ++k) s[k] += partial[(size_t)b * 4 + k];
-  metrics[0] = (float)(s[0] / (double)n);
-  metrics[1] = (float)(s[1] / ((double)n * (double)pix));
-  metrics[2] = s[2] > 0 ? (float)(s[3] / s[2]) : NAN;
-  metrics[3] = (float)s[2];
+  for (int k = 0; k < 4; ++k) sm[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (threadIdx.x < st)
+      for (int k = 0; k < 4; ++k) sm[k][threadIdx.x] += sm[k][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  metrics[0] = (float)(sm[0][0] / (double)n);
+  metrics[1] = (float)(sm[1][0] / ((double)n * (double)pix));
+  metrics[2] = sm[2][0] > 0 ? (float)(sm[3][0] / sm[2][0]) : NAN;
+  metrics[3] = (float)sm[2][0];
 }
 
 static int head_blocks(int n, int64_t pix) {
+  static const int cap = getenv("URSN_HEAD_GRID") ? atoi(getenv("URSN_HEAD_GRID")) : 4096;
   int64_t b = cdiv64((int64_t)n * pix, 256 * 4);
-  if (b > 2048) b = 2048;
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -570,7 +580,7 @@ int launch_head(const HeadArgs& a, hipStream_t s) {
   double* partial = (double*)a.scratch;
   hipLaunchKernelGGL(head_kernel, dim3(nb), dim3(256), 0, s, a, partial);
   URSN_HIP(hipGetLastError());
-  hipLaunchKernelGGL(head_final_kernel, dim3(1), dim3(64), 0, s, (const double*)partial, nb, a.n, a.pix, a.metrics);
+  hipLaunchKernelGGL(head_final_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, nb, a.n, a.pix, a.metrics);
   URSN_HIP(hipGetLastError());
   return 0;
 }
