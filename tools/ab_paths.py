@@ -8,7 +8,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = {"3d": ((96, 96, 96, 1), 8, 3, 2), "2d": ((512, 512, 1), 16, 5, 3), "3db": ((64, 96, 160, 1), 8, 3, 3)}
+CASES = {"3d": ((96, 96, 96, 1), 8, 3, 2), "2d": ((512, 512, 1), 16, 5, 3), "3db": ((64, 96, 160, 1), 8, 3, 3),
+         "3dbig": ((256, 256, 256, 1), 8, 3, 4)}   # tensors above 2^31 bytes
 
 
 def child(which, tag):
