@@ -223,6 +223,12 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
           static_for<4>([&](auto J) {
             constexpr int j = decltype(J)::value;
             constexpr int k = t * CIN + 4 * q + j;
+            if constexpr (CIN == 4 && !FLIP && j > 0) {
+              if (a.cin_w == 1) return;   // conv0: channels 1..3 of the padded input quad are zeros (uniform branch)
+            }
+            if constexpr (CIN == 4 && FLIP && j > 0) {
+              if (4 * q + j >= a.cout_w) return;   // logits layer dgrad: padded class channels carry zero weights
+            }
             static_for<CQ>([&](auto C) {
               constexpr int cq = decltype(C)::value;
               if constexpr (CQ == 1 && (k & 1))
