@@ -180,6 +180,21 @@ def main():
         elapsed = float(t.item())
     metrics = net.read_metrics()
 
+    # the non-conv parts of the step, each timed alone (Adam and the all-reduce reported separately)
+    def timed_ms(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        tt = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - tt) / reps * 1e3
+    parts = {"zero_gradients_ms": round(timed_ms(lambda: net.zero_gradients(None)), 4),
+             "allreduce_ms": round(timed_ms(net.allreduce_gradients), 4) if world > 1 else 0.0}
+    # Adam last (it moves the weights; the bench is over): gradient buffer zeroed so the update is a pure decay of m, v
+    net.zero_gradients(None)
+    parts["adam_ms"] = round(timed_ms(lambda: _lib.check(lib.ursn_apply_adam(net._handle, 1e-4, None))), 4)
+
     # per-launch HIP-event records of the timed region (rank 0)
     cnt = ctypes.c_int64(0)
     _lib.check(lib.ursn_profile_read(net._handle, None, 0, ctypes.byref(cnt)))
@@ -259,6 +274,7 @@ def main():
                        "step": "zero_gradients+accum_gradients(fwd+loss+bwd)+allreduce+adam",
                        "parallelism": "dp%d" % world},
             "last_metrics": {"loss": metrics[0], "acc_all": metrics[1], "acc_nonzero": metrics[2]},
+            "step_parts": parts,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
