@@ -52,13 +52,13 @@ __device__ __forceinline__ void s2_static_for(F&& f) {
 
 // per-thread staging table of the hi-res halo box: element offset from the box origin and LDS offset of every
 // float4 this thread moves -- box independent, so the per-box work is one add per load (interior boxes)
-template <int MODE>
+template <int MODE, int NTHR = 256>
 struct HaloGeom {
   using B = SBox<MODE>;
   static constexpr int HZ = (B::KZ == 3) ? 2 * B::BZ + 1 : 1, HY = 2 * B::BY + 1, HX = 2 * B::BX + 1, HXH = B::BX + 1;
   static constexpr int PS = HZ * HY * 2 * HXH;   // slots: [hz][hy][x parity][x / 2]
   static constexpr int NLD = HZ * HY * HX * 2;   // float4 loads (2 channel quads per voxel)
-  static constexpr int NH = (NLD + 255) / 256;
+  static constexpr int NH = (NLD + NTHR - 1) / NTHR;
 };
 
 struct BoxPos { int n, z0, y0, x0; };
@@ -73,11 +73,11 @@ __device__ __forceinline__ BoxPos s2_box(const S2Geom& g, int box, int BZ, int B
 }
 
 // loads the halo box of `bp` (channels c0..c0+7 of tensor `src`) into hv[]
-template <int MODE>
+template <int MODE, int NTHR = 256>
 __device__ __forceinline__ void s2_load_halo(const float* __restrict__ src, int cs, int c0, const S2Geom& g, const BoxPos& bp,
-                                             const int (&goff)[HaloGeom<MODE>::NH], int tid,
-                                             s2_f32x4 (&hv)[HaloGeom<MODE>::NH]) {
-  using H = HaloGeom<MODE>;
+                                             const int (&goff)[HaloGeom<MODE, NTHR>::NH], int tid,
+                                             s2_f32x4 (&hv)[HaloGeom<MODE, NTHR>::NH]) {
+  using H = HaloGeom<MODE, NTHR>;
   constexpr int KZ = SBox<MODE>::KZ;
   const int oz0 = (KZ == 3) ? 2 * bp.z0 - g.pz : 0, oy0 = 2 * bp.y0 - g.py, ox0 = 2 * bp.x0 - g.px;
   const int64_t base = ((((int64_t)bp.n * g.IZ + oz0) * g.IY + oy0) * g.IX + ox0) * cs + c0;
@@ -86,13 +86,13 @@ __device__ __forceinline__ void s2_load_halo(const float* __restrict__ src, int 
 #pragma unroll
     for (int i = 0; i < H::NH; ++i) {
       s2_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((i + 1) * 256 <= H::NLD || tid + i * 256 < H::NLD) v = *(const s2_f32x4*)(src + base + goff[i]);
+      if ((i + 1) * NTHR <= H::NLD || tid + i * NTHR < H::NLD) v = *(const s2_f32x4*)(src + base + goff[i]);
       hv[i] = v;
     }
   } else {
 #pragma unroll
     for (int i = 0; i < H::NH; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NTHR;
       const int sv = idx >> 1;
       const int hx = sv % H::HX, r = sv / H::HX;
       const int hy = r % H::HY, hz = r / H::HY;
@@ -106,13 +106,16 @@ __device__ __forceinline__ void s2_load_halo(const float* __restrict__ src, int 
 }
 
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(256, 2) void s2conv_kernel(S2Args a) {
+__global__ __launch_bounds__(512, 4) void s2conv_kernel(S2Args a) {
+  // 8 waves share one staged box (one 16-voxel row each in 3-D): 4 waves per SIMD with two workgroups per CU hide the
+  // barrier / staging phases of a kernel with only ~100 MFMAs per wave and box
+  constexpr int NTHR = 512, NWAVE = NTHR / 64;
   using B = SBox<MODE>;
-  using H = HaloGeom<MODE>;
+  using H = HaloGeom<MODE, NTHR>;
   constexpr int BZ = B::BZ, BY = B::BY, BX = B::BX, NT = B::NT, KZ = B::KZ;
   constexpr int HY = H::HY, HX = H::HX, HXH = H::HXH, PS = H::PS, NLD = H::NLD, NH = H::NH;
   constexpr int PSP = PS + ((16 - PS % 32) + 32) % 32;        // channel-plane stride == 16 (mod 32)
-  constexpr int NR = (BZ * BY) / 4;                           // 16-voxel rows per wave
+  constexpr int NR = (BZ * BY) / NWAVE;                       // 16-voxel rows per wave
   extern __shared__ __attribute__((aligned(16))) float s2l[];  // [8][PSP] halo, then [NT][8][16] weights
   float* hal = s2l;
   float* wl = s2l + 8 * PSP;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(S2Args a) {
   int goff[NH], loff[NH];
 #pragma unroll
   for (int i = 0; i < NH; ++i) {
-    const int idx = tid + i * 256;
+    const int idx = tid + i * NTHR;
     const int sv = idx >> 1, q = idx & 1;
     const int hx = sv % HX, r = sv / HX;
     const int hy = r % HY, hz = r / HY;
@@ -144,17 +147,17 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(S2Args a) {
   auto store_halo = [&](const s2_f32x4 (&hv)[NH]) {
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
-      if ((i + 1) * 256 <= NLD || tid + i * 256 < NLD) {
+      if ((i + 1) * NTHR <= NLD || tid + i * NTHR < NLD) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) hal[loff[i] + j * PSP] = hv[i][j];
       }
     }
   };
-  constexpr int NWL = (NT * 32 + 255) / 256;
+  constexpr int NWL = (NT * 32 + NTHR - 1) / NTHR;
   auto load_w = [&](int ci0, s2_f32x4 (&wv)[NWL]) {
 #pragma unroll
     for (int i = 0; i < NWL; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NTHR;
       const int t = idx >> 5, rem = idx & 31;
       const int k = rem >> 2, c4 = (rem & 3) * 4;
       s2_f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(S2Args a) {
   auto store_w = [&](const s2_f32x4 (&wv)[NWL]) {
 #pragma unroll
     for (int i = 0; i < NWL; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NTHR;
       if (idx < NT * 32) *(s2_f32x4*)(wl + idx * 4) = wv[i];
     }
   };
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(S2Args a) {
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   s2_f32x4 hv[NH], wv[NWL];
   BoxPos cur = s2_box(g, box_begin, BZ, BY, BX);
-  s2_load_halo<MODE>(a.in, a.in_cs, 0, g, cur, goff, tid, hv);
+  s2_load_halo<MODE, NTHR>(a.in, a.in_cs, 0, g, cur, goff, tid, hv);
   load_w(0, wv);
   int box = box_begin, ch = 0;
   for (int it = 0; it < nitems; ++it) {
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(S2Args a) {
     BoxPos nxt = cur;
     if (it + 1 < nitems) {
       if (nbox != box) nxt = s2_box(g, nbox, BZ, BY, BX);
-      s2_load_halo<MODE>(a.in, a.in_cs, 8 * nch, g, nxt, goff, tid, hv);
+      s2_load_halo<MODE, NTHR>(a.in, a.in_cs, 8 * nch, g, nxt, goff, tid, hv);
       if (nchunks > 1) load_w(8 * nch, wv);
     }
     if (ch == 0) {
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(S2Args a) {
     box = nbox; ch = nch; cur = nxt;
   }
   if constexpr (STATS) {
-    __shared__ float red[4][32];
+    __shared__ float red[NWAVE][32];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float u = s1[r], w2 = s2[r];
@@ -250,7 +253,8 @@ __global__ __launch_bounds__(256, 2) void s2conv_kernel(S2Args a) {
     __syncthreads();
     if (tid < 32)
       a.stats_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + tid] =
-          (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
+          ((double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid]) +
+          ((double)red[4][tid] + (double)red[5][tid] + (double)red[6][tid] + (double)red[7][tid]);
   }
 }
 
@@ -517,7 +521,7 @@ static int launch_s2c(const S2Plan& p, const S2Args& a, hipStream_t s) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_conv));
     attr_lds = p.lds_conv;
   }
-  hipLaunchKernelGGL(kern, dim3(p.gridx, p.Nn / 16), dim3(256), p.lds_conv, s, a);
+  hipLaunchKernelGGL(kern, dim3(p.gridx, p.Nn / 16), dim3(512), p.lds_conv, s, a);
   URSN_HIP(hipGetLastError());
   return 0;
 }
