@@ -297,3 +297,24 @@ def test_smaller_batch_on_a_larger_plan():
     sm_big = big.inference(None, d3[:2])[0]
     sm_one = one.inference(None, d3[:2])[0]     # grows the second net's plan to batch 2
     assert max_rel(sm_big, sm_one) < 1e-5
+
+
+def test_training_step_is_bitwise_reproducible():
+    """Fixed-order slab / statistics reductions and event-ordered streams: two nets with the same seed and batch give
+    bit-identical gradients and post-Adam weights (the reference's TF kernels make no such promise; a stronger property)."""
+    dims, base, ncls, N, ns = (32, 32, 64, 1), 8, 3, 2, 2
+    data, label, weight = make_inputs(dims, ncls, N, seed=31)
+    out = []
+    for _ in range(2):
+        net = uresnet(dims=list(dims), num_class=ncls, base_num_outputs=base, num_strides=ns)
+        net.construct(trainable=True, use_weight=True, learning_rate=1e-3, seed=9)
+        for _ in range(2):
+            net.zero_gradients(None)
+            res, _ = net.accum_gradients(None, data, label, weight)
+            net.apply_gradients(None)
+        out.append((res[1], net.get_gradients(), net.get_variables()))
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert np.array_equal(out[0][1][k], out[1][1][k]), k
+    for k in out[0][2]:
+        assert np.array_equal(out[0][2][k], out[1][2][k]), k
