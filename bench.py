@@ -35,7 +35,7 @@ WORKLOADS = {
     "cfg2_2d512_f16_b16": ((512, 512, 1), 16, 5, 16, "lartpc_sparse"),
     "cfg1_2d256_f16_b4": ((256, 256, 1), 16, 3, 4, "dense_uniform"),
     "tiny_3d64_f8_b2": ((64, 64, 64, 1), 8, 3, 2, "lartpc_sparse"),
-    # BASELINE.json cfg5's volume in fp32 (the bf16 variant is not built): 90 GB of workspace, sized for 288 GB HBM
+    # BASELINE.json cfg5's volume in fp32 (the bf16 variant is not built): 96.5 GB of workspace, sized for 288 GB HBM
     "cfg5shape_3d256_f8_b4_fp32": ((256, 256, 256, 1), 8, 3, 4, "lartpc_sparse"),
 }
 
