@@ -702,3 +702,23 @@ def test_normalise_on_load_conv_and_weight_gradient(ndim, S, C):
     yy = torch.empty((N,) + S + (32,), dtype=torch.float32, device="cuda")
     if not (ndim == 2 and C == 16):   # 2-D 16 -> 32 is a native tiled shape
         assert lib.ursn_conv_forward(ctypes.byref(d2), P(zg), P(w2), P(yy), stream()) != 0
+
+
+@pytest.mark.parametrize("ndim,N,S,ci,co", [(3, 2, (8, 8, 32), 64, 32), (3, 1, (6, 6, 6), 64, 32), (3, 2, (12, 12, 12), 32, 16),
+                                            (3, 2, (24, 48, 48), 64, 32), (2, 2, (32, 48), 32, 16), (2, 4, (160, 160), 64, 32)])
+def test_igemm_dgrad_with_fused_shortcut_term(ndim, N, S, ci, co):
+    """Decoder units (2C -> C): dx of resnet_conv1 and of the parallel 1x1 shortcut (lib/resnet_module.py:25-43) in the
+    all-taps implicit-GEMM data-gradient kernel (pw_dy / pw_w), standard and small-box variants, 16- and 32-wide tiles."""
+    rng = np.random.default_rng(11 * ndim + ci + co + S[-1])
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (3,) * ndim + (ci, co)) * 0.1
+    ws = _rand(rng, (1,) * ndim + (ci, co)) * 0.3
+    dy, dys = _rand(rng, (N,) + S + (co,)), _rand(rng, (N,) + S + (co,))
+    dx = O.conv_bwd(x, w, 1, dy)[0] + O.conv_bwd(x, ws, 1, dys)[0]
+    wg, wsg, dyg, dysg = dev(w), dev(ws), dev(dy), dev(dys)
+    d = desc(ndim, N, S, ci, co, 3, 1)
+    d.pw_dy, d.pw_w = dysg.data_ptr(), wsg.data_ptr()
+    for acc in (0, 1):
+        base = torch.full(x.shape, 1.0 if acc else float("nan"), dtype=torch.float32, device="cuda")
+        got = conv_backward_data(d, dyg, wg, x.shape, accumulate=acc, dx_init=base).cpu().numpy()
+        assert rel_err(got, dx + acc) < TOL

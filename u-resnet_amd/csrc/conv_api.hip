@@ -233,8 +233,11 @@ int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const
     URSN_REQUIRE(d.in_rstd && d.in_beta && tiled_conv_supported(d, pass), "conv: normalise-on-load (in_mean) not supported for this shape / pass");
     return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
   }
-  if (d.pw_dy) {      // fused shortcut data gradient: tiled kernels only
-    URSN_REQUIRE(pass == PASS_DGRAD && tiled_conv_supported(d, pass), "conv: fused pointwise term (pw_dy) not supported for this shape / pass");
+  if (d.pw_dy) {      // fused shortcut data gradient: all-taps implicit GEMM or tiled kernels
+    URSN_REQUIRE(pass == PASS_DGRAD, "conv: fused pointwise term (pw_dy) applies to the data gradient only");
+    if (!d.in_split && igemm_conv_supported(d, pass))
+      return launch_igemm_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
+    URSN_REQUIRE(tiled_conv_supported(d, pass), "conv: fused pointwise term (pw_dy) not supported for this shape");
     return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
   }
   if (d.in_split) {   // never-materialised concat: only the kernels that take two input tensors

@@ -52,9 +52,14 @@ static bool make_igplan(const ursn_conv_desc& d, ConvPass pass, IGPlan& p, int& 
   const int HZ = p.mode == 3 ? BZ + 2 : 1, HY = BY + 2, HX = BX + 2;
   p.lds = ((size_t)4 * HZ * HY * HX * 4 + (size_t)2 * 16 * (p.bm + 16)) * sizeof(float);
   p.alltaps = (at && p.bm == 16) || (at >= 1 && at != 16 && p.bm == 32);   // URSN_IGEMM_ALLTAPS: 0 off, 16 only BM=16, 1 both
+  if (d.pw_dy && !(p.flip && p.alltaps)) return false;   // the fused shortcut term lives in the all-taps data-gradient kernel
   if (p.alltaps) {
     const int kc = p.bm == 16 ? 16 : 8;
     p.lds = ((size_t)(kc / 4) * HZ * HY * HX * 4 + (size_t)(p.mode == 3 ? 27 : 9) * kc * p.bm) * sizeof(float);
+    if (d.pw_dy) {   // fused shortcut term: the box's voxels of the shortcut gradient + the KC x BM slab of its weights
+      const int nv = BZ * BY * BX;
+      p.lds += ((size_t)(kc / 4) * nv * 4 + (size_t)p.bm * kc) * sizeof(float);
+    }
     static const int pad_kb = getenv("URSN_IGEMM_LDS_KB") ? atoi(getenv("URSN_IGEMM_LDS_KB")) : 0;   // A/B: caps the occupancy
     if (pad_kb > 0 && p.lds < (size_t)pad_kb * 1024) p.lds = (size_t)pad_kb * 1024;
   }
@@ -135,6 +140,14 @@ int launch_igemm_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, c
   a.cin_w = d.cin; a.cout_w = d.cout;
   a.nbz = p.nbz; a.nby = p.nby; a.nbx = p.nbx;
   a.accumulate = accumulate;
+  a.pw_in = nullptr; a.pw_w = nullptr; a.pw_cs = 0; a.pw_ws = 0;
+  if (d.pw_dy) {
+    URSN_REQUIRE(p.flip && p.alltaps && d.pw_w, "igemm conv: fused pointwise term needs the all-taps data-gradient kernel");
+    a.pw_in = d.pw_dy; a.pw_w = d.pw_w;
+    a.pw_cs = d.pw_dy_cstride > 0 ? d.pw_dy_cstride : d.cout;
+    a.pw_ws = d.cout;   // shortcut weights [cin][cout]
+    URSN_REQUIRE((a.pw_cs & 3) == 0, "igemm conv: pw_dy channel stride must be a multiple of 4");
+  }
   URSN_TRY(p.mode == 3 ? dispatch_bm<3>(p, a, s) : dispatch_bm<2>(p, a, s));
   if (stats_partial) {
     const int64_t V = (int64_t)d.n * p.Z * p.Y * p.X;

@@ -27,6 +27,10 @@ struct IGemmArgs {
   int cin_w, cout_w;      // stored weight dims [t][cin_w][cout_w]
   int nbz, nby, nbx;
   int accumulate;
+  // data gradient (igemm_at_kernel, FLIP) only: fused 1x1 shortcut term  out[v][ci] += sum_co pw_in[v][co] * pw_w[ci][co]
+  const float* pw_in;   // shortcut dz, same channel count as the contraction; null = none
+  const float* pw_w;    // [produced channels][contraction channels], row stride pw_ws
+  int pw_cs, pw_ws;
 };
 
 template <int MODE> struct IBox;
@@ -285,6 +289,49 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
     }
   };
 
+  // fused pointwise term (FLIP): the box's own voxels of the shortcut gradient [NQ][NV][4] and the KC x BM slab of Ws^T
+  constexpr int NPX = (NQ * NV + 255) / 256, NPW = (BM * KC / 4 + 255) / 256;
+  float* pwx = wl + (size_t)MT * NT * KC * 16;
+  float* pww = pwx + (size_t)NQ * NV * 4;
+  const bool pw = FLIP && a.pw_in != nullptr;
+  auto load_pw = [&](int ci0, ig_f32x4 (&px)[NPX], ig_f32x4 (&pq)[NPW]) {
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int idx = tid + i * 256;
+      const int vox = idx / NQ, q = idx % NQ;
+      const int lx = vox % BX, r = vox / BX;
+      const int gx = x0 + lx, gy = y0 + r % BY, gz = z0 + r / BY;
+      ig_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < NQ * NV && gz < a.Z && gy < a.Y && gx < a.X)
+        v = *(const ig_f32x4*)(a.pw_in + ((((size_t)n * a.Z + gz) * a.Y + gy) * a.X + gx) * a.pw_cs + ci0 + 4 * q);
+      px[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int idx = tid + i * 256;
+      const int nn = idx / (KC / 4), k4 = (idx % (KC / 4)) * 4;
+      ig_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < BM * KC / 4 && co0 + nn < a.cout) v = *(const ig_f32x4*)(a.pw_w + (size_t)(co0 + nn) * a.pw_ws + ci0 + k4);
+      pq[i] = v;
+    }
+  };
+  auto store_pw = [&](const ig_f32x4 (&px)[NPX], const ig_f32x4 (&pq)[NPW]) {
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < NQ * NV) *(ig_f32x4*)(pwx + ((size_t)(idx % NQ) * NV + idx / NQ) * 4) = px[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < BM * KC / 4) {
+        const int nn = idx / (KC / 4), k4 = (idx % (KC / 4)) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pww[(((size_t)(nn >> 4)) * KC + k4 + j) * 16 + (nn & 15)] = pq[i][j];
+      }
+    }
+  };
+
   // halo slot of this lane's voxel for tile v (tap 0,0,0): voxel (wave*TPW + v)*16 + il of the flattened box
   // (standard boxes: 3-D z = wave, y = v; 2-D y = 4*wave + v); lanes past the box read slot 0 and store nothing
   int hb[TPW], vox[TPW];
@@ -298,18 +345,21 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
   }
   const int wb = kl * 16 + il;
 
-  ig_f32x4 hv[NH], wv[NW];
+  ig_f32x4 hv[NH], wv[NW], px[NPX], pq[NPW];
   const int nchunks = a.cin / KC;
   load_h(0, hv);
   load_w(0, wv);
+  if (pw) load_pw(0, px, pq);
   for (int ch = 0; ch < nchunks; ++ch) {
     if (ch) __syncthreads();
     store_h(hv);
     store_w(wv);
+    if (pw) store_pw(px, pq);
     __syncthreads();
     if (ch + 1 < nchunks) {
       load_h((ch + 1) * KC, hv);
       load_w((ch + 1) * KC, wv);
+      if (pw) load_pw((ch + 1) * KC, px, pq);
     }
 #pragma unroll 3
     for (int t = 0; t < NT; ++t) {
@@ -322,6 +372,20 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
         for (int m = 0; m < MT; ++m) av[m] = wl[wb + (((size_t)m * NT + t) * KC + 4 * s) * 16];
 #pragma unroll
         for (int v = 0; v < TPW; ++v) bv[v] = hal[hb[v] + toff + s * PS * 4];
+#pragma unroll
+        for (int v = 0; v < TPW; ++v)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[v][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[v], acc[v][m], 0, 0, 0);
+      }
+    }
+    if (pw) {   // one more "tap": the shortcut's 1x1 weights on the box's own voxels
+#pragma unroll
+      for (int s = 0; s < NQ; ++s) {
+        float av[MT], bv[TPW];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = pww[wb + ((size_t)m * KC + 4 * s) * 16];
+#pragma unroll
+        for (int v = 0; v < TPW; ++v) bv[v] = pwx[((size_t)s * NV + (vox[v] < 0 ? 0 : vox[v])) * 4 + kl];
 #pragma unroll
         for (int v = 0; v < TPW; ++v)
 #pragma unroll

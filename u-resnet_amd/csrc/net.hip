@@ -673,7 +673,9 @@ int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
   if (u.sc >= 0 && n->layers[u.sc].stride == 1) {
     static const bool off = getenv("URSN_FUSE_SHORTCUT_DGRAD") && getenv("URSN_FUSE_SHORTCUT_DGRAD")[0] == '0';
     ursn_conv_desc d = bwd_desc(n, u.c1, u.in, N, in2, u.sc), d0 = bwd_desc(n, u.c1, u.in, N, in2, -1);
-    fuse = !off && tiled_conv_supported(d, PASS_DGRAD) && !igemm_conv_supported(d0, PASS_DGRAD);   // only where conv1's dgrad is tiled anyway
+    // where conv1's dgrad runs on the all-taps implicit GEMM it carries the term itself; else only where it is tiled anyway
+    fuse = !off && ((!in2 && igemm_conv_supported(d, PASS_DGRAD)) ||
+                    (tiled_conv_supported(d, PASS_DGRAD) && !igemm_conv_supported(d0, PASS_DGRAD)));
   }
   URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, in2, fuse ? u.sc : -1));
   if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, !fuse, N, s, in2, -1, fuse));
