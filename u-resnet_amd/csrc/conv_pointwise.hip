@@ -285,7 +285,7 @@ int pointwise_conv_supported(const ursn_conv_desc& d, ConvPass pass, int accumul
 
 size_t pointwise_stats_scratch_doubles(const ursn_conv_desc& d) {
   if (!pointwise_conv_supported(d, PASS_FWD, 0)) return 0;
-  return (size_t)2048 * 2 * d.cout;
+  return (size_t)8192 * 2 * d.cout;
 }
 
 template <int CK, int CP>
@@ -316,8 +316,9 @@ int launch_pointwise_conv(const ursn_conv_desc& d, ConvPass pass, const float* i
     else { URSN_REQUIRE(d.x2, "pointwise conv: split input without x2"); a.in2 = d.x2; a.in2_cs = i2; }
   }
   const int ck = flip ? d.cout : d.cin, cp = flip ? d.cin : d.cout;
+  static const int cap = getenv("URSN_PCONV_GRID") ? atoi(getenv("URSN_PCONV_GRID")) : 1024;
   int64_t blocks = cdiv64(a.nvox, 256 * 4);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   const int grid = (int)blocks;
   ursn_note_kernel(flip ? "pconv_dgrad" : "pconv");
