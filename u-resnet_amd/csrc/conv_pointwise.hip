@@ -283,9 +283,14 @@ int pointwise_conv_supported(const ursn_conv_desc& d, ConvPass pass, int accumul
   return 0;
 }
 
+static int pconv_grid_cap() {   // workgroups of the forward / data-gradient kernel (URSN_PCONV_GRID, A/B)
+  static const int cap = getenv("URSN_PCONV_GRID") ? atoi(getenv("URSN_PCONV_GRID")) : 1024;
+  return cap < 1 ? 1 : cap;
+}
+
 size_t pointwise_stats_scratch_doubles(const ursn_conv_desc& d) {
   if (!pointwise_conv_supported(d, PASS_FWD, 0)) return 0;
-  return (size_t)8192 * 2 * d.cout;
+  return (size_t)pconv_grid_cap() * 2 * d.cout;
 }
 
 template <int CK, int CP>
@@ -316,7 +321,7 @@ int launch_pointwise_conv(const ursn_conv_desc& d, ConvPass pass, const float* i
     else { URSN_REQUIRE(d.x2, "pointwise conv: split input without x2"); a.in2 = d.x2; a.in2_cs = i2; }
   }
   const int ck = flip ? d.cout : d.cin, cp = flip ? d.cin : d.cout;
-  static const int cap = getenv("URSN_PCONV_GRID") ? atoi(getenv("URSN_PCONV_GRID")) : 1024;
+  const int cap = pconv_grid_cap();
   int64_t blocks = cdiv64(a.nvox, 256 * 4);
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
