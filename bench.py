@@ -40,8 +40,10 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline_child(size, reps):
-    """Runs in a child process: torch-CPU oracle, one image of size^3, fwd + loss + bwd."""
+def cpu_baseline_child(kind, size, reps, warm):
+    """Runs in a child process: the torch-CPU oracle, fwd + loss + bwd (one accum_gradients-equivalent).
+    kind '3d': ONE image of size^3 x1 with cfg3's model (F=8, 3 classes, lartpc_sparse);
+    kind 'cfg1': BASELINE configs[0] exactly (2-D 256^2, F=16, 3 classes, batch 4, dense_uniform, USE_WEIGHTS False)."""
     import numpy as np
     import torch
     from oracle import uresnet_np as O, uresnet_torch as T
@@ -50,44 +52,81 @@ def cpu_baseline_child(size, reps):
     sio = import_module("uresnet_amd.synthetic_io")
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(ncpu, 16)))   # one-GPU box share is 16 cores (the host reports 256)
-    dims, base, ncls = (size, size, size, 1), 8, 3
-    P = T.params_from_numpy(O.init_params(3, 1, base, ncls, seed=1234, dtype=np.float32), dtype=torch.float32)
-    d, l, w = sio.lartpc_sparse(dims, ncls, 0)
-    w = w / w.sum()
-    best = None
-    for i in range(reps):
+    if kind == "cfg1":
+        dims, base, ncls, n, gen, use_w = (256, 256, 1), 16, 3, 4, sio.dense_uniform, False
+    else:
+        dims, base, ncls, n, gen, use_w = (size, size, size, 1), 8, 3, 1, sio.lartpc_sparse, True
+    P = T.params_from_numpy(O.init_params(len(dims) - 1, 1, base, ncls, seed=1234, dtype=np.float32), dtype=torch.float32)
+    b = [gen(dims, ncls, i) for i in range(n)]
+    d, l, w = (np.stack([x[j] for x in b]) for j in range(3))
+    w = w / w.sum(axis=1, keepdims=True)
+    times = []
+    for i in range(warm + reps):
         t0 = time.time()
-        T.step_gradients(P, dims, base, d[None], l[None], w[None])
+        T.step_gradients(P, dims, base, d, l, w if use_w else None)
         dt = time.time() - t0
-        sys.stderr.write("cpu_baseline rep %d: %.2f s on %d threads\n" % (i, dt, torch.get_num_threads()))
+        sys.stderr.write("cpu_baseline %s rep %d%s: %.2f s on %d threads\n" % (kind, i, " (warm-up)" if i < warm else "", dt,
+                                                                             torch.get_num_threads()))
         sys.stderr.flush()
-        best = dt if best is None else min(best, dt)
-    print(json.dumps({"sec_per_image": best, "threads": torch.get_num_threads(), "size": size}))
+        if i >= warm:
+            times.append(dt)
+    times.sort()
+    print(json.dumps({"sec_per_step": times[len(times) // 2], "images": n, "threads": torch.get_num_threads(),
+                      "size": size, "reps": reps, "warm": warm}))
 
 
-def run_cpu_baseline(full_size):
-    """images/s of the CPU port on a bounded sample; oneDNN first, native ATen if that crashes."""
-    attempts = [(min(full_size, 128), "1", 2), (96, "0", 2)]
-    for size, mkldnn, reps in attempts:
-        env = dict(os.environ, URSN_ORACLE_MKLDNN=mkldnn)
-        try:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(size),
-                                  "--cpu-reps", str(reps)], env=env, stdout=subprocess.PIPE, text=True, timeout=300)
-            line = [x for x in out.stdout.strip().split("\n") if x.startswith("{")]
-            if out.returncode != 0 or not line:
-                continue
-            r = json.loads(line[-1])
-            scale = (float(size) / full_size) ** 3   # work is linear in voxels
-            sec_full = r["sec_per_image"] / scale
-            return {"value": 1.0 / sec_full, "unit": "images/s", "cores": r["threads"], "kind": "port",
-                    "sample": "torch-CPU restatement of the reference graph (not TensorFlow), fp32, %s convs: "
-                              "1 image of %d^3x1 (F=8, 3 classes) fwd+loss+bwd, best of %d; %s"
-                              % ("oneDNN" if mkldnn == "1" else "ATen-native", size, reps,
-                                 "measured at full size" if size == full_size else
-                                 "scaled by voxel count to %d^3" % full_size)}
-        except Exception:
+def _cpu_child(kind, size, reps, warm, mkldnn, timeout):
+    env = dict(os.environ, URSN_ORACLE_MKLDNN=mkldnn)
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", kind, "--cpu-size", str(size),
+                              "--cpu-reps", str(reps), "--cpu-warm", str(warm)], env=env, stdout=subprocess.PIPE,
+                             text=True, timeout=timeout)
+        line = [x for x in out.stdout.strip().split("\n") if x.startswith("{")]
+        if out.returncode != 0 or not line:
+            return None
+        return json.loads(line[-1])
+    except Exception:
+        return None
+
+
+def run_cpu_baseline(full_size, reps=5, warm=2):
+    """the torch-CPU port on ONE full 192^3 image, median of >= 5 after 2 warm-ups (oneDNN convs; if
+    that build crashes here the ATen-native path at 128^3, scaled by voxel count and labelled so), plus cfg1 exactly."""
+    attempts = [(full_size, "1", reps, warm, 600), (min(full_size, 128), "0", 3, 1, 600)]
+    out = None
+    for size, mkldnn, r, wm, to in attempts:
+        res = _cpu_child("3d", size, r, wm, mkldnn, to)
+        if res is None:
             continue
-    return None
+        scale = (float(size) / full_size) ** 3   # work is linear in voxels
+        sec_full = res["sec_per_step"] / scale
+        out = {"value": round(1.0 / sec_full, 5), "unit": "images/s", "cores": res["threads"], "kind": "port",
+               "sample": "torch-CPU restatement of the reference graph (not TensorFlow), fp32, %s convs: ONE image of "
+                         "%d^3x1 (F=8, 3 classes) fwd+loss+bwd, median of %d after %d warm-ups (%.2f s per image); %s"
+                         % ("oneDNN" if mkldnn == "1" else "ATen-native", size, r, wm, res["sec_per_step"],
+                            "measured at the config's full size" if size == full_size else
+                            "FALLBACK: oneDNN crashed at full size, scaled by voxel count to %d^3" % full_size)}
+        break
+    c1 = _cpu_child("cfg1", 256, reps, warm, "0", 300)   # oneDNN's 2-D backward segfaults intermittently in this image
+    if out is not None and c1 is not None:
+        out["cfg1_exact"] = {"value": round(c1["images"] / c1["sec_per_step"], 3), "unit": "images/s",
+                             "sample": "BASELINE configs[0] exactly: 2-D 256^2x1, F=16, 3 classes, batch 4, dense_uniform, "
+                                       "USE_WEIGHTS False; ATen-native convs, median of %d after %d warm-ups" % (reps, warm)}
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N-rank job as a CHILD process (nothing in this
+    process has touched the GPU yet -- never re-exec a process that has) and relay its JSON line and exit code."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, env=env)
+    sys.exit(p.returncode)
 
 
 def main():
@@ -100,11 +139,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="per-kernel time table on stderr")
     ap.add_argument("--layers", action="store_true", help="per-(layer, pass) time table on stderr")
-    ap.add_argument("--cpu-baseline-child", type=int, default=0)
-    ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--host-feed", action="store_true",
+                    help="feed host (numpy) batches through the pinned copy-stream path every step; value stays the "
+                         "device-resident rate, the PCIe-inclusive rate is reported beside it")
+    ap.add_argument("--cpu-baseline-child", default="")
+    ap.add_argument("--cpu-size", type=int, default=192)
+    ap.add_argument("--cpu-reps", type=int, default=5)
+    ap.add_argument("--cpu-warm", type=int, default=2)
     args = ap.parse_args()
     if args.cpu_baseline_child:
-        return cpu_baseline_child(args.cpu_baseline_child, args.cpu_reps)
+        return cpu_baseline_child(args.cpu_baseline_child, args.cpu_size, args.cpu_reps, args.cpu_warm)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     import numpy as np
     import torch
@@ -122,7 +168,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl")   # RCCL over xGMI
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node == --gpus\n" % (args.gpus, world))
+        sys.exit(2)
 
     dims, base, ncls, batch, gen = WORKLOADS[args.workload]
     if args.batch:
@@ -180,6 +228,38 @@ def main():
         elapsed = float(t.item())
     metrics = net.read_metrics()
 
+    host_feed = None
+    if args.host_feed:
+        # the same step fed from host memory every iteration (lib/ssnet_trainval.py:167-188 hands over host buffers):
+        # pinned source, copy stream, copy of step k+1 overlapped with the kernels of step k (ssnet.py::_feed)
+        pin = [torch.from_numpy(a).pin_memory().numpy() for a in (data, label, weight)]
+
+        def hstep():
+            net.zero_gradients(None)
+            net.accum_gradients(None, pin[0], pin[1], pin[2], fetch=False)
+            net.apply_gradients(None)
+        for _ in range(2):
+            hstep()
+        barrier()
+        th = time.perf_counter()
+        for _ in range(args.steps):
+            hstep()
+        barrier()
+        h_el = time.perf_counter() - th
+        nbytes = sum(a.nbytes for a in pin)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cs = net._copy_stream()
+        with torch.cuda.stream(cs):
+            ev0.record(cs)
+            for a, dd in zip(pin, (data_d, label_d, weight_d)):
+                dd.copy_(torch.from_numpy(a), non_blocking=True)
+            ev1.record(cs)
+        ev1.synchronize()
+        host_feed = {"images_per_s_pcie_inclusive": round(batch * world * args.steps / h_el, 3),
+                     "ms_per_step": round(h_el / args.steps * 1e3, 3), "h2d_bytes_per_step": nbytes,
+                     "h2d_ms_alone": round(ev0.elapsed_time(ev1), 3),
+                     "note": "pinned source buffers, copy stream, H2D of step k+1 overlaps the kernels of step k"}
+
     # the non-conv parts of the step, each timed alone (Adam and the all-reduce reported separately)
     def timed_ms(fn, reps=5):
         fn()
@@ -233,6 +313,10 @@ def main():
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
                     "traffic": (round(pmc[dom_name]["hbm_bytes_per_launch"]) if dom_name in pmc else None),
+                    # PMC counters cannot be read from inside this process: the figure is the committed result of the
+                    # separate rocprofv3 --pmc passes of this same command (tools/pmc_traffic.sh), not of this run
+                    "traffic_source": ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                       "this command, committed; not measured by this run)" if dom_name in pmc else None),
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                     "kernel_share_of_step": round(dom["ms"] / max(all_ms, 1e-9), 3),
@@ -274,7 +358,7 @@ def main():
                        "step": "zero_gradients+accum_gradients(fwd+loss+bwd)+allreduce+adam",
                        "parallelism": "dp%d" % world},
             "last_metrics": {"loss": metrics[0], "acc_all": metrics[1], "acc_nonzero": metrics[2]},
-            "step_parts": parts,
+            "step_parts": parts, "host_feed": host_feed,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define URSN_ABI_VERSION 2
+#define URSN_ABI_VERSION 3
 
 typedef struct ursn_net ursn_net; /* opaque */
 
@@ -67,6 +67,20 @@ const char* ursn_last_error(void);
 /* Size query; no device access. */
 int ursn_query(const ursn_config* cfg, ursn_sizes* out);
 
+/* The plan a configuration compiles to, without device access: conv-like layer `index` in TF variable order
+ * (lib/uresnet.py:37-121, lib/resnet_module.py:25-66) and the operand order of decoder step `step`'s tf.concat
+ * (lib/uresnet.py:81: [deconv_i, skip]).  ssnet_base.construct checks what _build recorded against these. */
+typedef struct ursn_layer_info {
+  char name[96];       /* TF scope, e.g. "UResNet/resnet_module0/module1/shortcut"                 */
+  int32_t transposed;  /* 0 slim.conv{2,3}d, 1 slim.conv{2,3}d_transpose                            */
+  int32_t k, stride, cin, cout;
+  int32_t relu;        /* activation_fn: 1 = tf.nn.relu (conv0, deconv*, conv1), 0 = None            */
+  int64_t w_offset;    /* float offsets of `weights` and `BatchNorm/beta` in the flat buffers       */
+  int64_t beta_offset;
+} ursn_layer_info;
+int ursn_query_layer(const ursn_config* cfg, int64_t index, ursn_layer_info* out);
+int ursn_query_concat(const ursn_config* cfg, int32_t step, char* first, char* second, size_t cap);
+
 /* Replaces graph construction (lib/ssnet.py:20-89 + lib/uresnet.py:22-123).  The four flat
  * fp32 buffers (n_params floats each) and the workspace are caller-owned device memory;
  * `grads` is the accum_vars set (lib/ssnet.py:53-55), adam_m/adam_v the Adam slots.
@@ -103,8 +117,11 @@ int ursn_infer(ursn_net* net, const float* data, const float* label, int32_t n, 
                float* out2, void* stream);
 
 /* ana_step's label rule on the device (lib/ssnet_trainval.py:285-287): labels_out [N,*spatial] =
- * ((p[1] > p[2]) * 1 + (p[2] >= p[1]) * 2) * (data > 1.0); avoids returning the full softmax. Synchronises. */
-int ursn_infer_labels(ursn_net* net, const float* data, int32_t n, float* labels_out, void* stream);
+ * ((p[1] > p[2]) * 1 + (p[2] >= p[1]) * 2) * (data > 1.0), from the same forward pass as the optional softmax_out
+ * (NULL: the softmax never leaves the kernel) and, if label != NULL, out2 = {acc_all, acc_nonzero}
+ * (the reference prints acc_nonzero per entry, lib/ssnet_trainval.py:262).  Synchronises. */
+int ursn_infer_labels(ursn_net* net, const float* data, const float* label, int32_t n, float* labels_out,
+                      float* softmax_out, float* out2, void* stream);
 
 /* Metrics of the last accum/eval call: synchronises, writes {loss, acc_all, acc_nonzero}. */
 int ursn_read_metrics(ursn_net* net, float* out3, void* stream);

@@ -122,7 +122,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert set(_lib.EXPORTS) <= declared
-    assert lib.ursn_abi_version() == 2
+    assert lib.ursn_abi_version() == _lib.ABI_VERSION
 
 
 def test_query_sizes_and_errors():
@@ -178,3 +178,69 @@ def test_rank_sharding_of_entries():
         seen.append(io_.fetch_entries())
         io_.reset()
     assert seen == [[0, 2, 4], [1, 3, 5]]
+
+
+def test_num_strides_above_five_rejected():
+    """lib/uresnet.py:100 names the decoder units 'resnet_module%d' % (step + 5): a sixth stride would collide with
+    the encoder's variable scopes (TensorFlow raises there too), and 10 tensors would silently share checkpoint keys."""
+    with pytest.raises(ValueError, match="num_strides"):
+        uresnet(dims=[64, 64, 1], num_class=3, num_strides=6).construct(allocate=False)
+    lib = _lib.load()
+    net = uresnet(dims=[64, 64, 1], num_class=3, num_strides=5)
+    net.construct(allocate=False)
+    assert len(set(net.variable_names())) == len(net.variable_names()) == 116
+    cfg = net._native_config(1)
+    cfg.num_strides = 6
+    s = _lib.ursn_sizes()
+    assert lib.ursn_query(ctypes.byref(cfg), ctypes.byref(s)) != 0 and b"num_strides" in lib.ursn_last_error()
+
+
+def test_plan_check_reads_the_native_tables():
+    """construct() compares what _build recorded with the layer / concat tables of the compiled plan (ursn_query_layer,
+    ursn_query_concat): a subclass that changes an activation or swaps the tf.concat operands (lib/uresnet.py:81) is
+    refused instead of silently running the fixed native topology."""
+    U = sys.modules["uresnet_amd.uresnet"]
+    lib = _lib.load()
+    net = uresnet(dims=[64, 64, 64, 1], num_class=3, base_num_outputs=8)
+    net.construct(allocate=False)
+    info = _lib.ursn_layer_info()
+    relu_layers = []
+    for i in range(58):
+        assert lib.ursn_query_layer(ctypes.byref(net._cfg), i, ctypes.byref(info)) == 0
+        if info.relu:
+            relu_layers.append(info.name.decode())
+    assert relu_layers == ['UResNet/conv0'] + ['UResNet/deconv%d' % i for i in range(5)] + ['UResNet/conv1']
+    assert lib.ursn_query_layer(ctypes.byref(net._cfg), 58, ctypes.byref(info)) != 0
+    a, b = ctypes.create_string_buffer(128), ctypes.create_string_buffer(128)
+    cats = []
+    for i in range(5):
+        assert lib.ursn_query_concat(ctypes.byref(net._cfg), i, a, b, 128) == 0
+        cats.append((a.value.decode(), b.value.decode()))
+    assert cats[0] == ('UResNet/deconv0', 'UResNet/resnet_module3/module2')     # SURVEY Appendix C: concat0 <- module3
+    assert cats[4] == ('UResNet/deconv4', 'UResNet/conv0')
+    assert [(x, y) for _, x, y in net._graph.concats] == cats
+
+    class swapped(uresnet):
+        def _build(self, input_tensor):
+            orig = U.concat
+            U.concat = lambda ts, name: orig(ts[::-1], name)
+            try:
+                return uresnet._build(self, input_tensor)
+            finally:
+                U.concat = orig
+    with pytest.raises(NotImplementedError, match="concat"):
+        swapped(dims=[64, 64, 1], num_class=3).construct(allocate=False)
+
+    class relu_logits(uresnet):
+        def _build(self, input_tensor):
+            orig = U.conv
+
+            def conv(inputs, n, k, s, scope, activation_fn=None):
+                return orig(inputs, n, k, s, scope, activation_fn='relu' if scope == 'conv2' else activation_fn)
+            U.conv = conv
+            try:
+                return uresnet._build(self, input_tensor)
+            finally:
+                U.conv = orig
+    with pytest.raises(NotImplementedError, match="conv2"):
+        relu_logits(dims=[64, 64, 1], num_class=3).construct(allocate=False)

@@ -227,10 +227,112 @@ def test_ana_label_rule_on_device():
     net = build(dims, base, ncls, False, trainable=False)
     data, _, _ = make_inputs(dims, ncls, N, seed=4)
     sm = net.inference(None, data)[0]
-    got = net.inference_labels(None, data)
+    got = net.inference_labels(None, data)[0]
     want = np.stack([O.ana_label_rule(sm[i], data[i].reshape(dims[:-1])) for i in range(N)])
     assert got.shape == want.shape and np.array_equal(got, want)
     assert set(np.unique(got)) <= {0.0, 1.0, 2.0} and (got > 0).any()
+
+
+def test_ana_batch_mode_never_brings_the_softmax_to_the_host(tmp_path, capsys, monkeypatch):
+    """batch_process in ana mode with an output stream (lib/ssnet_trainval.py:241-314, rule :285-287): the label volumes
+    written per entry come from the device kernel (ursn_infer_labels) and equal the reference's numpy post-processing of
+    the softmax; `inference` (the call that returns the softmax) is never issued."""
+    from uresnet_amd.ssnet_trainval import ssnet_trainval
+    from uresnet_amd import uresnet as U
+    inp = tmp_path / "input.cfg"
+    inp.write_text("Dims [32, 32, 32, 1]\nNumClass 3\nGenerator 'lartpc_sparse'\nNumEntries 64\n"
+                   "Keys {'data': 'data', 'label': 'label', 'weight': 'weight'}\n")
+    out = tmp_path / "ssnet_out.npy"
+    cfg = tmp_path / "ana.cfg"
+    cfg.write_text("NUM_CLASS 3\nBASE_NUM_FILTERS 4\nMAIN_INPUT_CONFIG '%s'\nANA_OUTPUT_CONFIG '%s'\nLOGDIR ''\n"
+                   "SAVE_FILE ''\nITERATIONS 2\nMINIBATCH_SIZE 2\nTRAIN False\nUSE_WEIGHTS False\nSUMMARY_STEPS 0\n"
+                   "CHECKPOINT_STEPS 0\n" % (inp, out))
+    calls = []
+    orig = U.inference
+    monkeypatch.setattr(U, "inference", lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
+    a = ssnet_trainval()
+    a.override_config(str(cfg))
+    a.initialize()
+    a.batch_process()
+    assert not calls
+    net = a._net
+    printed = capsys.readouterr().out
+    assert printed.count("Entry ") == 4 and "Acc" in printed
+    from uresnet_amd import synthetic_io as sio
+    with open(str(out), "rb") as f:
+        for e in range(4):
+            got = np.load(f)
+            d = sio.lartpc_sparse([32, 32, 32, 1], 3, e)[0]
+            pair = np.stack([sio.lartpc_sparse([32, 32, 32, 1], 3, 2 * (e // 2) + j)[0] for j in range(2)])
+            sm = orig(net, None, pair)[0][e % 2]      # BatchNorm uses batch statistics: same minibatch as the driver's
+            want = O.ana_label_rule(sm, d.reshape(32, 32, 32))
+            assert got.shape == (32, 32, 32) and got.dtype == np.float32 and np.array_equal(got, want)
+    r = a.ana_step()                                   # interactive mode returns the softmax as the reference does
+    assert set(r) == {'entries', 'input', 'label', 'softmax', 'acc_all', 'acc_nonzero'} and r['softmax'].shape == (2, 32, 32, 32, 3)
+    a.reset()
+
+
+def test_host_feed_paths_agree_and_release_the_buffer():
+    """ssnet.py::_feed: pageable numpy (staged through pinned memory), page-locked numpy (copied directly on the copy
+    stream) and device tensors give bit-identical results, and the host buffer may be overwritten as soon as
+    accum_gradients(fetch=False) has returned (the IO contract of lib/ssnet_trainval.py:167-188)."""
+    dims, base, ncls, N, ns = (32, 32, 64, 1), 8, 3, 2, 2
+    data, label, weight = make_inputs(dims, ncls, N, seed=41)
+    net = uresnet(dims=list(dims), num_class=ncls, base_num_outputs=base, num_strides=ns)
+    net.construct(trainable=True, use_weight=True, learning_rate=1e-3, seed=3)
+    out = []
+    pinned = [torch.from_numpy(a.copy()).pin_memory().numpy() for a in (data, label, weight)]
+    devt = [torch.from_numpy(a).cuda() for a in (data, label, weight)]
+    for mode, feed in (("pageable", (data.copy(), label.copy(), weight.copy())), ("pinned", pinned), ("device", devt)):
+        for rep in range(3):        # three rounds: both device buffers of every role get reused
+            net.zero_gradients(None)
+            assert net.accum_gradients(None, *feed, fetch=False)[0] is None
+            if mode != "device":
+                for a in feed:
+                    a[...] = 7.0    # the buffer is the caller's again
+            m = net.read_metrics()
+            out.append((mode, m[0], net.get_gradients()))
+            if mode != "device":
+                for a, src in zip(feed, (data, label, weight)):
+                    a[...] = src
+    for mode, loss, g in out[1:]:
+        assert loss == out[0][1], mode
+        assert all(np.array_equal(g[k], out[0][2][k]) for k in g), mode
+    assert net.feed_stats['staged_bytes'] == 3 * sum(a.nbytes for a in (data, label, weight))
+    assert net.feed_stats['h2d_calls'] == 18
+
+
+def test_rccl_allreduce_of_the_flat_gradient_buffer_single_rank():
+    """The N > 1 path on real hardware as far as one GPU allows: a world-size-1 RCCL group, all_reduce of the
+    caller-owned flat gradient buffer directly behind accum_gradients(fetch=False) -- the buffer is written on the internal
+    weight-gradient stream and joined to the current stream by an event -- then Adam through the raw stream pointer;
+    result identical to the non-distributed step."""
+    import os
+    import torch.distributed as dist
+    dims, base, ncls, N, ns = (32, 32, 64, 1), 8, 3, 2, 2
+    data, label, weight = make_inputs(dims, ncls, N, seed=43)
+
+    def run(distributed):
+        net = uresnet(dims=list(dims), num_class=ncls, base_num_outputs=base, num_strides=ns)
+        net.construct(trainable=True, use_weight=True, learning_rate=1e-3, seed=5)
+        for _ in range(2):
+            net.zero_gradients(None)
+            net.accum_gradients(None, data, label, weight, fetch=False)
+            if distributed:
+                dist.all_reduce(net._grads, op=dist.ReduceOp.SUM)     # what allreduce_gradients issues when world > 1
+            net.apply_gradients(None)
+        torch.cuda.synchronize()
+        return net.get_gradients(), net.get_variables()
+    g0, v0 = run(False)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        g1, v1 = run(True)
+    finally:
+        dist.destroy_process_group()
+    for k in g0:
+        assert np.array_equal(g0[k], g1[k]) and np.array_equal(v0[k], v1[k]), k
 
 
 def test_split_concat_matches_materialised_concat(monkeypatch):

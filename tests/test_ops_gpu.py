@@ -722,3 +722,70 @@ def test_igemm_dgrad_with_fused_shortcut_term(ndim, N, S, ci, co):
         base = torch.full(x.shape, 1.0 if acc else float("nan"), dtype=torch.float32, device="cuda")
         got = conv_backward_data(d, dyg, wg, x.shape, accumulate=acc, dx_init=base).cpu().numpy()
         assert rel_err(got, dx + acc) < TOL
+
+
+# ---- numerics hardening: fused one-pass statistics under |mean| >> std ------------------------------------------------
+# TensorFlow's moments are two-pass; the conv epilogues accumulate sum / sum of squares in one
+# pass.  A conv whose output carries a large per-channel offset (z = offset + N(0,1)) is the regime where a naive
+# one-pass variance cancels catastrophically; every kernel family with fused statistics is driven through it here
+# against the two-pass fp64 oracle.
+OFFSET_CASES = [
+    # tag, ndim, S, cin, cout, k, stride, transposed, algo
+    ("tconv8", 3, (32, 32, 64), 8, 8, 3, 1, 0, 3),
+    ("tconv16", 3, (16, 32, 64), 16, 16, 3, 1, 0, 3),
+    ("tconv2d16", 2, (64, 512), 16, 16, 3, 1, 0, 3),
+    ("igemm32", 3, (16, 24, 48), 32, 32, 3, 1, 0, 4),
+    ("igemm64", 3, (12, 12, 24), 64, 64, 3, 1, 0, 4),
+    ("igemm2d64", 2, (64, 128), 64, 64, 3, 1, 0, 4),
+    ("pconv16_8", 3, (16, 32, 64), 16, 8, 1, 1, 0, 5),
+    ("pconv_s2", 3, (16, 32, 64), 8, 16, 1, 2, 0, 5),
+    ("s2conv", 3, (16, 32, 64), 8, 16, 3, 2, 0, 6),
+    ("tdeconv16_8", 3, (8, 16, 32), 16, 8, 3, 2, 1, 3),
+    ("s2scatter32_16", 3, (8, 16, 32), 32, 16, 3, 2, 1, 7),
+    ("generic", 3, (8, 16, 32), 12, 20, 3, 1, 0, 2),
+]
+
+
+@pytest.mark.parametrize("ratio", [1e2, 1e3])
+@pytest.mark.parametrize("case", OFFSET_CASES, ids=[c[0] for c in OFFSET_CASES])
+def test_fused_statistics_with_large_mean_to_std_ratio(case, ratio):
+    tag, ndim, S, ci, co, k, st, tr, algo = case
+    rng = np.random.default_rng(len(tag) + int(ratio))
+    N = 2
+    x = _rand(rng, (N,) + S + (ci,))
+    # weights that copy input channel (co % ci) of ONE tap (conv) / of the 2^d taps that tile the output (transposed conv):
+    # z is exactly an input sample, so z = offset + N(0,1) at every output voxel (no border effect)
+    if tr:
+        w = np.zeros((k,) * ndim + (co, ci))
+        for t in np.ndindex(*((2,) * ndim)):
+            for c in range(co):
+                w[t + (c, c % ci)] = 1.0
+    else:
+        w = np.zeros((k,) * ndim + (ci, co))
+        tap = (0,) * ndim if st == 2 or k == 1 else (1,) * ndim
+        for c in range(co):
+            w[tap + (c % ci, c)] = 1.0
+    off = ratio * (1.0 + 0.25 * np.arange(ci) / ci) * np.where(np.arange(ci) % 2, -1.0, 1.0)
+    x = (x + off).astype(np.float32).astype(np.float64)
+    y = O.deconv_fwd(x, w) if tr else O.conv_fwd(x, w, st)
+    ax = tuple(range(y.ndim - 1))
+    mu = y.mean(axis=ax)
+    var = ((y - mu) ** 2).mean(axis=ax)          # two-pass
+    assert np.all(np.abs(mu) / np.sqrt(var) > 0.9 * ratio)
+    d = desc(ndim, N, S, ci, co, k, st, transposed=tr, algo=algo)
+    lib = _lib.load()
+    xg, wg = dev(x), dev(w)
+    yg = torch.empty(y.shape, dtype=torch.float32, device="cuda")
+    mg, rg = torch.empty(co, device="cuda"), torch.empty(co, device="cuda")
+    nb = 1 << 24
+    scratch = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.ursn_conv_forward_stats(ctypes.byref(d), P(xg), P(wg), P(yg), P(mg), P(rg), 1e-3, P(scratch), nb,
+                                           stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(yg.cpu().numpy(), y.astype(np.float32))
+    e_mu = float((np.abs(mg.cpu().numpy() - mu) / np.sqrt(var)).max())
+    e_rs = rel_err(rg.cpu().numpy(), 1 / np.sqrt(var + 1e-3))
+    print("%s |mean|/std %g: mean error %.2e std, rstd rel error %.2e" % (tag, ratio, e_mu, e_rs))
+    # the fp32 output itself is exact here; what is left is the rounding of the fp32 mean (ulp(mean)/std)
+    assert e_mu < 1e-7 * ratio + 1e-5
+    assert e_rs < 1e-4

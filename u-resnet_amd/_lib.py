@@ -23,6 +23,12 @@ class ursn_param_info(C.Structure):
                 ("rank", C.c_int32), ("shape", C.c_int32 * 5)]
 
 
+class ursn_layer_info(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("transposed", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("relu", C.c_int32), ("w_offset", C.c_int64),
+                ("beta_offset", C.c_int64)]
+
+
 class ursn_conv_desc(C.Structure):
     _fields_ = [("ndim", C.c_int32), ("n", C.c_int32), ("in_sp", C.c_int32 * 3), ("cin", C.c_int32),
                 ("cout", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("transposed", C.c_int32),
@@ -42,6 +48,8 @@ _SIGS = {
     "ursn_abi_version": (C.c_int, []),
     "ursn_last_error": (C.c_char_p, []),
     "ursn_query": (C.c_int, [C.POINTER(ursn_config), C.POINTER(ursn_sizes)]),
+    "ursn_query_layer": (C.c_int, [C.POINTER(ursn_config), C.c_int64, C.POINTER(ursn_layer_info)]),
+    "ursn_query_concat": (C.c_int, [C.POINTER(ursn_config), C.c_int32, C.c_char_p, C.c_char_p, C.c_size_t]),
     "ursn_create": (C.c_int, [C.POINTER(ursn_config), _P, _P, _P, _P, _P, C.c_size_t, C.POINTER(_P)]),
     "ursn_destroy": (C.c_int, [_P]),
     "ursn_get_sizes": (C.c_int, [_P, C.POINTER(ursn_sizes)]),
@@ -51,7 +59,7 @@ _SIGS = {
     "ursn_apply_adam": (C.c_int, [_P, C.c_float, _P]),
     "ursn_eval": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(C.c_float), _P]),
     "ursn_infer": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.POINTER(C.c_float), _P]),
-    "ursn_infer_labels": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "ursn_infer_labels": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.POINTER(C.c_float), _P]),
     "ursn_read_metrics": (C.c_int, [_P, C.POINTER(C.c_float), _P]),
     "ursn_get_adam_step": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "ursn_set_adam_step": (C.c_int, [_P, C.c_int64]),
@@ -78,6 +86,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS.keys())
 
+ABI_VERSION = 3
 _lib = None
 
 
@@ -96,7 +105,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.ursn_abi_version() != 2:
+    if lib.ursn_abi_version() != ABI_VERSION:
         raise ImportError("liburesnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

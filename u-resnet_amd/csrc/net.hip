@@ -44,6 +44,7 @@ struct Layer {
   std::string name;
   int kind = 0;  // 0 conv, 1 deconv
   int k = 3, stride = 1, cin = 0, cout = 0, lin = 0, lout = 0;
+  int relu = 0;  // activation_fn of the slim layer call (conv0 / deconv / conv1: ReLU; all others None)
   int64_t w_off = 0, b_off = 0, w_n = 0;
   ursn_conv_desc desc;
   float *z = nullptr, *dz = nullptr, *mean = nullptr, *rstd = nullptr;
@@ -99,6 +100,7 @@ struct ursn_net {
   std::vector<hipEvent_t> fwd_pool;   // forward: fork / join events of the side-stream shortcut convs
   size_t fwd_used = 0;
   hipEvent_t s2_done = nullptr;
+  std::vector<std::pair<std::string, std::string>> cat_names;   // per decoder step: producers of [first | second] channel halves
   std::map<std::string, Act> named;       // debug lookup: activations
   std::map<std::string, int> named_z;     // layer name -> layer index
 };
@@ -131,9 +133,10 @@ Act sub_act(const Act& full, int c0, int C) {
 }
 
 int add_layer(ursn_net* n, Arena& A, const std::string& name, int kind, int k, int s, int ci, int co, int lin, int lout,
-              int64_t& poff) {
+              int64_t& poff, int relu = 0) {
   Layer L;
   L.name = "UResNet/" + name;
+  L.relu = relu;
   L.kind = kind; L.k = k; L.stride = s; L.cin = ci; L.cout = co; L.lin = lin; L.lout = lout;
   int64_t taps = 1;
   for (int j = 0; j < n->cfg.ndim; ++j) taps *= k;
@@ -161,7 +164,9 @@ int add_layer(ursn_net* n, Arena& A, const std::string& name, int kind, int k, i
 int plan(ursn_net* n, Arena& A) {
   const ursn_config& c = n->cfg;
   URSN_REQUIRE(c.ndim == 2 || c.ndim == 3, "len(dims) must be 3 (H,W,C) or 4 (H,W,D,C)");
-  URSN_REQUIRE(c.num_strides >= 1 && c.num_strides <= 6, "num_strides %d out of range", c.num_strides);
+  // the decoder scopes are the reference's literal 'resnet_module%d' % (step + 5) (lib/uresnet.py:100): with more than 5
+  // strides they collide with the encoder's names (TensorFlow raises on the duplicate variable scope as well)
+  URSN_REQUIRE(c.num_strides >= 1 && c.num_strides <= 5, "num_strides %d out of range [1,5]", c.num_strides);
   URSN_REQUIRE(c.cin >= 1 && c.base_filters >= 1 && c.num_class >= 1 && c.num_class <= 8 && c.max_batch >= 1,
                "bad channel / class / batch configuration");
   const int ns = c.num_strides;
@@ -181,7 +186,7 @@ int plan(ursn_net* n, Arena& A) {
   const int F = c.base_filters;
   int64_t poff = 0;
   n->layers.clear(); n->units.clear(); n->deconv.clear(); n->cat.clear(); n->deconv_in.clear(); n->deconv_out.clear();
-  n->ginit.clear(); n->named.clear(); n->named_z.clear();
+  n->ginit.clear(); n->named.clear(); n->named_z.clear(); n->cat_names.clear();
 
   // concat buffers first (decoder step i lives at level ns-1-i with F*2^(ns-i) channels).  Where a half is narrower
   // than a 64-byte line (<= 8 channels) and the tiled / pointwise kernels take the two halves as separate tensors,
@@ -216,7 +221,7 @@ int plan(ursn_net* n, Arena& A) {
   n->a_data = Act();
   n->a_data.C = c.cin; n->a_data.cs = c.cin; n->a_data.lvl = 0;
 
-  n->conv0 = add_layer(n, A, "conv0", 0, 3, 1, c.cin, F, 0, 0, poff);
+  n->conv0 = add_layer(n, A, "conv0", 0, 3, 1, c.cin, F, 0, 0, poff, 1);
   n->a_conv0 = fmap_view(0);
   n->named["UResNet/conv0"] = n->a_conv0;
 
@@ -261,6 +266,8 @@ int plan(ursn_net* n, Arena& A) {
   };
 
   Act net = n->a_conv0;
+  std::vector<std::string> skip_name(ns + 1);   // producer of the encoder feature map at each level
+  skip_name[0] = "UResNet/conv0";
   for (int step = 0; step < ns; ++step) {
     char sc[64];
     int co = net.C * 2;
@@ -273,25 +280,27 @@ int plan(ursn_net* n, Arena& A) {
     } else {
       net = add_unit(sc, u1, co, 1, step + 1, nullptr);
     }
+    skip_name[step + 1] = std::string("UResNet/") + sc;
   }
   for (int i = 0; i < ns; ++i) {
     char sc[64];
     int co = net.C / 2;
     int lvl = ns - 1 - i;
     snprintf(sc, sizeof(sc), "deconv%d", i);
-    int li = add_layer(n, A, sc, 1, 3, 2, net.C, co, net.lvl, lvl, poff);
+    int li = add_layer(n, A, sc, 1, 3, 2, net.C, co, net.lvl, lvl, poff, 1);
     n->deconv.push_back(li);
     n->deconv_in.push_back(net);
     Act dout = split[i] ? make_act(n, A, lvl, co, tr) : sub_act(n->cat[i], 0, co);
     n->deconv_out.push_back(dout);
     n->named[n->layers[li].name] = dout;
+    n->cat_names.push_back({n->layers[li].name, skip_name[lvl]});   // tf.concat([deconv_i, skip]) (lib/uresnet.py:81)
     snprintf(sc, sizeof(sc), "resnet_module%d/module1", i + 5);
     Act u1 = split[i] ? add_unit(sc, dout, co, 1, lvl, nullptr, &lone_fmap[i]) : add_unit(sc, n->cat[i], co, 1, lvl, nullptr);
     snprintf(sc, sizeof(sc), "resnet_module%d/module2", i + 5);
     net = add_unit(sc, u1, co, 1, lvl, nullptr);
   }
   n->a_pre1 = net;
-  n->conv1 = add_layer(n, A, "conv1", 0, 3, 1, net.C, F, 0, 0, poff);
+  n->conv1 = add_layer(n, A, "conv1", 0, 3, 1, net.C, F, 0, 0, poff, 1);
   n->a_conv1 = make_act(n, A, 0, F, tr);
   n->named["UResNet/conv1"] = n->a_conv1;
   n->conv2 = add_layer(n, A, "conv2", 0, 3, 1, F, c.num_class, 0, 0, poff);
@@ -745,6 +754,35 @@ extern "C" int ursn_query(const ursn_config* cfg, ursn_sizes* out) {
   return 0;
 }
 
+// Layer / concat tables of the plan a configuration compiles to (no device access): what ssnet_base.construct checks
+// the topology recorded by _build against.
+extern "C" int ursn_query_layer(const ursn_config* cfg, int64_t index, ursn_layer_info* out) {
+  URSN_REQUIRE(cfg && out, "query_layer: null argument");
+  ursn_net tmp;
+  tmp.cfg = *cfg;
+  Arena A;
+  URSN_TRY(plan(&tmp, A));
+  URSN_REQUIRE(index >= 0 && index < (int64_t)tmp.layers.size(), "query_layer: index %lld out of range", (long long)index);
+  const Layer& L = tmp.layers[index];
+  memset(out, 0, sizeof(*out));
+  snprintf(out->name, sizeof(out->name), "%s", L.name.c_str());
+  out->transposed = L.kind; out->k = L.k; out->stride = L.stride; out->cin = L.cin; out->cout = L.cout; out->relu = L.relu;
+  out->w_offset = L.w_off; out->beta_offset = L.b_off;
+  return 0;
+}
+
+extern "C" int ursn_query_concat(const ursn_config* cfg, int32_t step, char* first, char* second, size_t cap) {
+  URSN_REQUIRE(cfg && first && second && cap > 0, "query_concat: null argument");
+  ursn_net tmp;
+  tmp.cfg = *cfg;
+  Arena A;
+  URSN_TRY(plan(&tmp, A));
+  URSN_REQUIRE(step >= 0 && step < (int)tmp.cat_names.size(), "query_concat: step %d out of range", step);
+  snprintf(first, cap, "%s", tmp.cat_names[step].first.c_str());
+  snprintf(second, cap, "%s", tmp.cat_names[step].second.c_str());
+  return 0;
+}
+
 extern "C" int ursn_create(const ursn_config* cfg, float* params, float* grads, float* adam_m, float* adam_v,
                            void* workspace, size_t workspace_bytes, ursn_net** out) {
   URSN_REQUIRE(cfg && params && workspace && out, "create: null argument");
@@ -893,15 +931,17 @@ extern "C" int ursn_infer(ursn_net* net, const float* data, const float* label, 
   return 0;
 }
 
-extern "C" int ursn_infer_labels(ursn_net* net, const float* data, int32_t n, float* labels_out, void* stream) {
+extern "C" int ursn_infer_labels(ursn_net* net, const float* data, const float* label, int32_t n, float* labels_out,
+                                 float* softmax_out, float* out2, void* stream) {
   URSN_TRY(check_call(net, data, n));
   URSN_REQUIRE(labels_out, "infer_labels: labels_out is null");
   URSN_REQUIRE(net->cfg.num_class >= 3 && net->cfg.cin == 1, "infer_labels: needs >= 3 classes and one input channel");
   hipStream_t s = (hipStream_t)stream;
   net->last_n = n;
   URSN_TRY(forward(net, data, n, s));
-  URSN_TRY(head(net, data, nullptr, nullptr, n, nullptr, false, s, labels_out));
-  URSN_HIP(hipStreamSynchronize(s));
+  URSN_TRY(head(net, data, label, nullptr, n, softmax_out, false, s, labels_out));
+  if (label && out2) URSN_TRY(read_metrics(net, out2, 2, s));
+  else URSN_HIP(hipStreamSynchronize(s));
   return 0;
 }
 

@@ -112,54 +112,55 @@ class ssnet_base(object):
 
     def _check_plan(self):
         """The native library implements the U-ResNet topology of lib/uresnet.py; a subclass whose
-        ``_build`` records anything else cannot be executed (there is no generic graph executor)."""
+        ``_build`` records anything else cannot be executed (there is no generic graph executor).
+        What ``_build`` recorded -- every conv-like layer's scope, kind, kernel, stride, channels and
+        activation, and the operand order of every tf.concat -- is compared with the layer / concat
+        tables of the plan the library compiles for this configuration (ursn_query_layer /
+        ursn_query_concat), not with a second Python copy of the formula."""
         lib = _lib.load()
+        if int(getattr(self, '_num_strides', 5)) > 5:
+            # lib/uresnet.py:100 names the decoder units 'resnet_module%d' % (step + 5): with more than 5 strides they
+            # collide with the encoder's scopes (TensorFlow raises on the duplicate variable scope as well)
+            raise ValueError('num_strides > 5: decoder scope names collide with the encoder (lib/uresnet.py:100)')
         sizes = _lib.ursn_sizes()
         _lib.check(lib.ursn_query(ctypes.byref(self._cfg), ctypes.byref(sizes)))
         self._n_params = int(sizes.n_params)
-        got = [(l['name'], l['kind'], l['k'], l['stride'], l['cin'], l['cout']) for l in self._graph.layers]
-        want = self._expected_layers()
+        native = []
+        info = _lib.ursn_layer_info()
+        for i in range(int(sizes.n_layers)):
+            _lib.check(lib.ursn_query_layer(ctypes.byref(self._cfg), i, ctypes.byref(info)))
+            native.append(dict(name=info.name.decode(), kind='deconv' if info.transposed else 'conv', k=int(info.k),
+                               stride=int(info.stride), cin=int(info.cin), cout=int(info.cout), relu=bool(info.relu),
+                               w_offset=int(info.w_offset), beta_offset=int(info.beta_offset)))
+        keys = ('name', 'kind', 'k', 'stride', 'cin', 'cout', 'relu')
+        got = [tuple(l[k] for k in keys) for l in self._graph.layers]
+        want = [tuple(l[k] for k in keys) for l in native]
         if got != want:
-            raise NotImplementedError('_build recorded a topology other than lib/uresnet.py:22-123; '
-                                      'only that hot path is implemented natively')
-        specs, off = [], 0
-        nd = len(self._dims) - 1
-        for (name, kind, k, s, ci, co) in want:
-            wshape = (k,) * nd + ((ci, co) if kind == 'conv' else (co, ci))
-            n = int(np.prod(wshape))
-            specs.append((name + '/weights', wshape, off, n)); off += n
-            specs.append((name + '/BatchNorm/beta', (co,), off, co)); off += co
-        if off != self._n_params:
-            raise RuntimeError('parameter count mismatch: python %d vs native %d' % (off, self._n_params))
-        self._specs = specs
-
-    def _expected_layers(self):
-        F = int(getattr(self, '_base_num_outputs', 16))
+            diff = [(g, w) for g, w in zip(got, want) if g != w][:1] or [(len(got), len(want))]
+            raise NotImplementedError('_build recorded a topology other than lib/uresnet.py:22-123 (first difference, '
+                                      'recorded vs native plan: %r); only that hot path is implemented natively' % (diff[0],))
+        a, b = ctypes.create_string_buffer(128), ctypes.create_string_buffer(128)
         ns = int(getattr(self, '_num_strides', 5))
-        cin = int(self._dims[-1])
-        L = []
-
-        def unit(scope, ci, co, s):
-            if not (ci == co and s == 1):
-                L.append((scope + '/shortcut', 'conv', 1, s, ci, co))
-            L.append((scope + '/resnet_conv1', 'conv', 3, s, ci, co))
-            L.append((scope + '/resnet_conv2', 'conv', 3, 1, co, co))
-
-        L.append(('UResNet/conv0', 'conv', 3, 1, cin, F))
-        c = F
+        native_cats = []
         for step in range(ns):
-            unit('UResNet/resnet_module%d/module1' % step, c, 2 * c, 2)
-            unit('UResNet/resnet_module%d/module2' % step, 2 * c, 2 * c, 1)
-            c *= 2
-        for step in range(ns):
-            co = c // 2
-            L.append(('UResNet/deconv%d' % step, 'deconv', 3, 2, c, co))
-            unit('UResNet/resnet_module%d/module1' % (step + 5), c, co, 1)
-            unit('UResNet/resnet_module%d/module2' % (step + 5), co, co, 1)
-            c = co
-        L.append(('UResNet/conv1', 'conv', 3, 1, c, F))
-        L.append(('UResNet/conv2', 'conv', 3, 1, F, self._num_class))
-        return L
+            _lib.check(lib.ursn_query_concat(ctypes.byref(self._cfg), step, a, b, 128))
+            native_cats.append((a.value.decode(), b.value.decode()))
+        if [(x, y) for (_, x, y) in self._graph.concats] != native_cats:
+            raise NotImplementedError('_build concatenates %r; the native plan implements tf.concat([deconv_i, skip]) = %r '
+                                      '(lib/uresnet.py:81)' % ([(x, y) for (_, x, y) in self._graph.concats], native_cats))
+        names = [l['name'] for l in native]
+        if len(set(names)) != len(names):
+            raise ValueError('duplicate variable scopes in the plan')
+        specs = []
+        nd = len(self._dims) - 1
+        for l in native:
+            wshape = (l['k'],) * nd + ((l['cin'], l['cout']) if l['kind'] == 'conv' else (l['cout'], l['cin']))
+            specs.append((l['name'] + '/weights', wshape, l['w_offset'], int(np.prod(wshape))))
+            specs.append((l['name'] + '/BatchNorm/beta', (l['cout'],), l['beta_offset'], l['cout']))
+        end = max(off + n for _, _, off, n in specs)
+        if end != self._n_params or sum(n for _, _, _, n in specs) != self._n_params:
+            raise RuntimeError('parameter table does not tile the flat buffer: %d vs native %d' % (end, self._n_params))
+        self._specs = specs
 
     # ------------------------------------------------------------------------------------------
     # device state
@@ -213,6 +214,15 @@ class ssnet_base(object):
         cfg = self._native_config(max_batch=batch)
         sizes = _lib.ursn_sizes()
         _lib.check(lib.ursn_query(ctypes.byref(cfg), ctypes.byref(sizes)))
+        # activations of every layer stay resident for the backward pass (sized for 288 GB of HBM, no recomputation): say
+        # so before the allocator raises something less readable
+        self._workspace = None
+        torch.cuda.empty_cache()
+        free_b, total_b = torch.cuda.mem_get_info(self._device)
+        if int(sizes.workspace_bytes) + (64 << 20) > free_b:
+            raise MemoryError('U-ResNet workspace for batch %d needs %.1f GB but only %.1f of %.1f GB of HBM are free; '
+                              'use a smaller MINIBATCH_SIZE with more NUM_MINIBATCHES (same gradient sum, '
+                              'lib/ssnet.py:77)' % (batch, sizes.workspace_bytes / 1e9, free_b / 1e9, total_b / 1e9))
         self._workspace = torch.empty(int(sizes.workspace_bytes) + 256, dtype=torch.uint8, device=self._device)
         wptr = (self._workspace.data_ptr() + 255) & ~255
         h = ctypes.c_void_p()
@@ -239,17 +249,91 @@ class ssnet_base(object):
         import torch
         return ctypes.c_void_p(torch.cuda.current_stream(self._device).cuda_stream)
 
+    # ------------------------------------------------------------------------------------------
+    # host feed (lib/ssnet.py:141-153 feed_dict; lib/ssnet_trainval.py:167-188 hands over IO buffers that are only
+    # valid until the next io.next() and are mutated in place at :173)
+    # ------------------------------------------------------------------------------------------
+    class _FeedSlot(object):
+        """One role's (data / label / weight) staging state: two device buffers used alternately, one pinned host
+        buffer for callers that hand over pageable memory, and the events that order copy and compute."""
+        __slots__ = ('dev', 'pinned', 'turn', 'consumed', 'copied')
+
+        def __init__(self):
+            self.dev, self.pinned, self.turn = [None, None], None, 0
+            self.consumed = [None, None]   # recorded on the compute stream after the last launch that reads dev[i]
+            self.copied = None
+
+    def _copy_stream(self):
+        import torch
+        if getattr(self, '_h2d_stream', None) is None:
+            self._h2d_stream = torch.cuda.Stream(device=self._device)
+            self._feed_slots = {}
+            self.feed_stats = {'h2d_bytes': 0, 'h2d_calls': 0, 'staged_bytes': 0}
+        return self._h2d_stream
+
     def _feed(self, x, cols, what):
-        """numpy / torch input [N, cols] -> contiguous fp32 device tensor (the H2D copy completes on the
-        current stream before the caller's buffer may be reused: torch copies from pageable memory
-        synchronously)."""
+        """numpy / torch input [N, cols] -> contiguous fp32 device tensor.
+
+        Host arrays travel on a dedicated copy stream from page-locked memory: directly from the caller's buffer when
+        it already is page-locked (synthetic_threadio produces into pinned buffers), else through a pinned staging
+        buffer.  The call returns once the COPY has completed (the caller may then reuse / mutate its buffer, as the
+        reference's IO does), but it never waits for compute: with ``accum_gradients(fetch=False)`` the copy of
+        minibatch k+1 overlaps the kernels of minibatch k.  Each role alternates between two device buffers; a buffer
+        is only overwritten after the launch that last read it has finished (event recorded by ``_mark_consumed``)."""
         import torch
         if isinstance(x, torch.Tensor):
-            t = x.to(device=self._device, dtype=torch.float32)
-        else:
-            t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self._device)
-        t = t.reshape(-1, cols).contiguous()
-        return t
+            if x.device == self._device and x.dtype == torch.float32 and x.is_contiguous():
+                return x.reshape(-1, cols)
+            if x.device.type != 'cpu':
+                return x.to(device=self._device, dtype=torch.float32).reshape(-1, cols).contiguous()
+            x = x.numpy()
+        host = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, cols)
+        n = host.shape[0]
+        cs = self._copy_stream()
+        slot = self._feed_slots.setdefault(what, ssnet_base._FeedSlot())
+        i = slot.turn
+        slot.turn ^= 1
+        if slot.dev[i] is None or slot.dev[i].shape[0] < n:
+            slot.dev[i] = torch.empty((n, cols), dtype=torch.float32, device=self._device)
+            slot.consumed[i] = None
+        dst = slot.dev[i][:n]
+        src = torch.from_numpy(host)
+        if not src.is_pinned():
+            if slot.pinned is None or slot.pinned.shape[0] < n:
+                slot.pinned = torch.empty((n, cols), dtype=torch.float32, pin_memory=True)
+            if slot.copied is not None:
+                slot.copied.synchronize()      # the previous copy out of the staging buffer
+            slot.pinned[:n].copy_(src)
+            src = slot.pinned[:n]
+            self.feed_stats['staged_bytes'] += host.nbytes
+        with torch.cuda.stream(cs):
+            if slot.consumed[i] is not None:
+                cs.wait_event(slot.consumed[i])
+            dst.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        slot.copied = ev
+        torch.cuda.current_stream(self._device).wait_event(ev)
+        ev.synchronize()                       # copy only; kernels of earlier minibatches keep running
+        self.feed_stats['h2d_bytes'] += host.nbytes
+        self.feed_stats['h2d_calls'] += 1
+        return dst
+
+    def _mark_consumed(self, fd):
+        """After the launches reading the fed tensors are queued: later copies into the same device buffers wait."""
+        import torch
+        slots = getattr(self, '_feed_slots', None)
+        if not slots:
+            return
+        ev = None
+        for t in fd.values():
+            for slot in slots.values():
+                for i in (0, 1):
+                    if slot.dev[i] is not None and t.data_ptr() == slot.dev[i].data_ptr():
+                        if ev is None:
+                            ev = torch.cuda.Event()
+                            ev.record(torch.cuda.current_stream(self._device))
+                        slot.consumed[i] = ev
 
     # ------------------------------------------------------------------------------------------
     # fetch-sets (lib/ssnet.py:91-153)
@@ -296,10 +380,16 @@ class ssnet_base(object):
         _lib.check(_lib.load().ursn_accum_step(self._handle, self._ptr(fd['input_data']), self._ptr(fd['input_label']),
                                                self._ptr(w), n, out if fetch else None, self._stream(sess)))
         self._last_feed = fd  # keep device inputs alive until the stream has consumed them
+        self._mark_consumed(fd)
         doc = ['', 'loss', 'acc. all', 'acc. nonzero']
         if not fetch:
             return None, doc
         return [None, float(out[0]), float(out[1]), float(out[2])], doc
+
+    def last_feed(self):
+        """Device-resident tensors of the most recent accum_gradients / inference_labels call (valid until two more
+        batches have been fed): lets a caller re-run them (summary) without another host copy."""
+        return dict(self._last_feed)
 
     def read_metrics(self, sess=None):
         out = (ctypes.c_float * 3)()
@@ -349,17 +439,30 @@ class ssnet_base(object):
             res += [float(out[0]), float(out[1])]
         return res
 
-    def inference_labels(self, sess, input_data, as_numpy=True):
-        """ana_step's shower/track label volume computed on the device (lib/ssnet_trainval.py:285-287);
-        returns [N, *spatial] float32 instead of the full softmax."""
+    def inference_labels(self, sess, input_data, input_label=None, as_numpy=True, with_softmax=False):
+        """ana_step's shower/track label volume computed on the device (lib/ssnet_trainval.py:285-287): returns
+        [labels [N, *spatial] float32 (, acc_all, acc_nonzero if input_label is given)]; the softmax only leaves the
+        kernel when ``with_softmax`` asks for it (appended last, same forward pass)."""
         import torch
-        d = self._feed(input_data, self._data_size, 'data')
-        n = int(d.shape[0])
+        fd = {'input_data': self._feed(input_data, self._data_size, 'data')}
+        if input_label is not None:
+            fd['input_label'] = self._feed(input_label, self._label_size, 'label')
+        n = int(fd['input_data'].shape[0])
         self._ensure_handle(n)
-        out = torch.empty((n,) + tuple(int(x) for x in self._dims[:-1]), dtype=torch.float32, device=self._device)
-        _lib.check(_lib.load().ursn_infer_labels(self._handle, self._ptr(d), n, self._ptr(out), self._stream(sess)))
-        self._last_feed = {'input_data': d}
-        return out.cpu().numpy() if as_numpy else out
+        sp = tuple(int(x) for x in self._dims[:-1])
+        out = torch.empty((n,) + sp, dtype=torch.float32, device=self._device)
+        sm = torch.empty((n,) + sp + (self._num_class,), dtype=torch.float32, device=self._device) if with_softmax else None
+        acc = (ctypes.c_float * 2)()
+        _lib.check(_lib.load().ursn_infer_labels(self._handle, self._ptr(fd['input_data']), self._ptr(fd.get('input_label')),
+                                                 n, self._ptr(out), self._ptr(sm), acc, self._stream(sess)))
+        self._last_feed = fd
+        self._mark_consumed(fd)
+        res = [out.cpu().numpy() if as_numpy else out]
+        if input_label is not None:
+            res += [float(acc[0]), float(acc[1])]
+        if with_softmax:
+            res.append(sm.cpu().numpy() if as_numpy else sm)
+        return res
 
     # ------------------------------------------------------------------------------------------
     # variables (checkpoint / weight injection)

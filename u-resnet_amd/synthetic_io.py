@@ -9,7 +9,10 @@ by this class, which keeps the call protocol the reference uses:
     io.fetch_data(key).dim()   -> [N, *dims]         io.fetch_data(key).data() -> float32 [N, prod(dims)]
     io.fetch_entries(); io.fetch_event_ids(); io.reset()
 
-Batches are produced by a background thread one step ahead (like larcv's filler threads) from two
+Batches are produced by a background thread one step ahead (like larcv's filler threads), into two
+alternating sets of PAGE-LOCKED host buffers when a HIP device is present (the network's feed then copies
+straight out of them on its copy stream, ssnet.py::_feed; a buffer is refilled only after the ``next()`` that
+follows its use, which is the validity contract of larcv's buffers, lib/ssnet_trainval.py:167-188), from two
 generators: ``dense_uniform`` (random pixels) and ``lartpc_sparse`` (a few straight
 "tracks" and blob "showers" on an empty background, values 1..500, inverse-frequency weights).
 Samples are seeded ``1234 + entry`` (1234 = TF_RANDOM_SEED, lib/config.py:22) so any rank/any run
@@ -127,16 +130,35 @@ class synthetic_threadio(object):
         self._stride = int(c.get('EntryStride', 1))   # data parallel: rank r reads entries r, r+W, ...
         self._cfg = c
 
+    def shard(self, rank, world_size):
+        """Data parallelism: this reader serves entries rank, rank + W, rank + 2W, ... (call before start_manager)."""
+        self._offset, self._stride = int(rank), int(world_size)
+
     def start_manager(self, batch_size):
         self._batch = int(batch_size)
+        self._sets = [self._alloc_set(), self._alloc_set()]
+        self._fill = 0
         self._spawn()
 
-    def _make(self, first):
+    @staticmethod
+    def _host_buffer(shape):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                return torch.empty(shape, dtype=torch.float32, pin_memory=True).numpy()
+        except Exception:
+            pass
+        return np.empty(shape, np.float32)
+
+    def _alloc_set(self):
         n = self._batch
         dsz, lsz = int(np.prod(self._dims)), int(np.prod(self._dims[:-1]))
-        data = np.empty((n, dsz), np.float32)
-        label = np.empty((n, lsz), np.float32)
-        weight = np.empty((n, lsz), np.float32)
+        return dict(data=self._host_buffer((n, dsz)), label=self._host_buffer((n, lsz)),
+                    weight=self._host_buffer((n, lsz)))
+
+    def _make(self, first, bufs):
+        n = self._batch
+        data, label, weight = bufs['data'], bufs['label'], bufs['weight']
         entries = []
         for i in range(n):
             e = (self._offset + (first + i) * self._stride) % self._num_entries
@@ -149,9 +171,11 @@ class synthetic_threadio(object):
         first = self._cursor
         self._cursor += self._batch
         box = {}
+        bufs = self._sets[self._fill]   # the set published two next() calls ago: its batch is no longer valid
+        self._fill ^= 1
 
         def work():
-            box['b'] = self._make(first)
+            box['b'] = self._make(first, bufs)
         self._thread = threading.Thread(target=work)
         self._thread.daemon = True
         self._thread.start()
