@@ -244,3 +244,35 @@ def test_plan_check_reads_the_native_tables():
                 U.conv = orig
     with pytest.raises(NotImplementedError, match="conv2"):
         relu_logits(dims=[64, 64, 1], num_class=3).construct(allocate=False)
+
+
+def test_native_plan_against_reference_graph():
+    """The layer / concat tables compiled into liburesnet_hip.so (ursn_query_layer / ursn_query_concat) against the
+    reference's saved GraphDef (tests/golden/ref_graph.json): scope order, conv vs transposed conv, strides, channel
+    counts, [deconv_i, skip] operand order.  (conv0 / conv1 were 7x7 in that older revision: kernel size excluded.)"""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "ref_graph.json")) as f:
+        G = json.load(f)
+    lib = _lib.load()
+    net = uresnet(dims=[512, 512, 1], num_class=3, base_num_outputs=16)
+    net.construct(allocate=False)
+    info = _lib.ursn_layer_info()
+    for i, c in enumerate(G["forward_convs"]):
+        assert lib.ursn_query_layer(ctypes.byref(net._cfg), i, ctypes.byref(info)) == 0
+        assert info.name.decode() == c["scope"]
+        assert bool(info.transposed) == (c["op"] == "Conv2DBackpropInput")
+        assert c["strides"] == [1, info.stride, info.stride, 1]
+        fs = c["filter_shape"]
+        assert (fs[2], fs[3]) == ((info.cout, info.cin) if info.transposed else (info.cin, info.cout))
+        if c["scope"] not in ("UResNet/conv0", "UResNet/conv1"):
+            assert fs[0] == fs[1] == info.k
+    a, b = ctypes.create_string_buffer(128), ctypes.create_string_buffer(128)
+    for i, c in enumerate(G["concats"]):
+        assert lib.ursn_query_concat(ctypes.byref(net._cfg), i, a, b, 128) == 0
+        assert [a.value.decode(), b.value.decode()] == c["inputs"]
+    # initialize_variables draws inside the graph's Xavier bounds
+    for name, shape, off, n in net._specs:
+        if name.endswith("/weights") and name.rsplit("/", 1)[0] not in ("UResNet/conv0", "UResNet/conv1"):
+            lim = G["xavier_limits"][name.rsplit("/", 1)[0]]["limit"]
+            fan = int(np.prod(shape[:2]))
+            assert abs(np.sqrt(6.0 / (fan * (shape[-1] + shape[-2]))) - lim) < 1e-8

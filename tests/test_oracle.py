@@ -161,3 +161,59 @@ def test_gradient_accumulation_is_a_sum_not_a_mean():
     _, acc = O.train_step(P2, O.Adam(P2), dims, base, mbs, num_strides=ns)
     for k in P:
         assert np.allclose(acc[k], g0[k] + g1[k])
+
+
+# ---- the one reference-held artefact: the saved GraphDef (tests/golden/ref_graph.json, made by make_ref_graph.py) ----
+def _ref_graph():
+    import json
+    with open(os.path.join(GOLD, "ref_graph.json")) as f:
+        return json.load(f)
+
+
+def test_oracle_topology_against_reference_graph():
+    """What the reference's saved graph (an older revision: 2-D 512x512, F=16, 3 classes) pins for
+    the current code: 53 convs + 5 transposed convs in this order with these strides / SAME / NHWC, the filter shapes
+    (k and channels; NOT conv0/conv1's 7x7 kernel), deconv filters stored [k,k,Cout,Cin], tf.concat([deconv_i, skip])
+    with skip = conv0 / resnet_module{0..3}/module2, Xavier-uniform bounds, BatchNorm = beta + moving averages (no
+    gamma), two-pass moments over [N,H,W].  Numerical parity stays UNPINNED: a GraphDef holds no activations."""
+    G = _ref_graph()
+    h = G["op_histogram"]
+    assert (h["Conv2D"], h["Conv2DBackpropInput"], h["Conv2DBackpropFilter"]) == (58, 58, 58)
+    assert G["graph_producer_version"] == 24 and G["num_nodes"] == 10303
+    L = O.layer_table(2, 1, 16, 3)
+    assert len(L) == len(G["forward_convs"]) == 58
+    old_kernel7 = {"UResNet/conv0", "UResNet/conv1"}          # the saved revision used 7x7 there (lib/uresnet.py:39,106 now 3)
+    for l, c in zip(L, G["forward_convs"]):
+        assert l["name"] == c["scope"]
+        assert (l["kind"] == "deconv") == (c["op"] == "Conv2DBackpropInput"), l["name"]
+        assert c["padding"] == "SAME" and c["data_format"] == "NHWC"
+        assert c["strides"] == [1, l["stride"], l["stride"], 1], l["name"]
+        if l["name"] in old_kernel7:
+            assert c["filter_shape"][:2] == [7, 7] and c["filter_shape"][2:] == l["wshape"][2:]
+        else:
+            assert c["filter_shape"] == l["wshape"], l["name"]    # deconv: [k,k,Cout,Cin]
+    d0 = [c for c in G["forward_convs"] if c["scope"] == "UResNet/deconv0"][0]
+    assert d0["filter_shape"] == [3, 3, 256, 512]
+    # the input gradient of a transposed conv is a plain stride-2 Conv2D with the same filter (Appendix B-2)
+    assert G["deconv0_input_gradient_ops"] == ["Conv2D", "Conv2DBackpropFilter"]
+    want_skip = ["UResNet/resnet_module3/module2", "UResNet/resnet_module2/module2", "UResNet/resnet_module1/module2",
+                 "UResNet/resnet_module0/module2", "UResNet/conv0"]
+    assert [c["inputs"] for c in G["concats"]] == [["UResNet/deconv%d" % i, want_skip[i]] for i in range(5)]
+    # Xavier uniform: limit = sqrt(6 / (fan_in + fan_out)), fan = k^d * C  (Appendix B-6)
+    for scope, x in G["xavier_limits"].items():
+        sh = x["shape"]
+        fan = sh[0] * sh[1]
+        assert abs(x["limit"] - np.sqrt(6.0 / (fan * (sh[2] + sh[3])))) < 1e-8, scope
+    P = O.init_params(2, 1, 16, 3, seed=7)
+    for l in L:
+        if l["name"] in old_kernel7:
+            continue
+        w, lim = P[l["name"] + "/weights"], G["xavier_limits"][l["name"]]["limit"]
+        assert np.abs(w).max() <= lim * (1 + 1e-7), l["name"]
+        if w.size >= 4096:
+            assert np.abs(w).max() > 0.99 * lim, l["name"]
+        assert np.all(P[l["name"] + "/BatchNorm/beta"] == 0)
+    assert G["batchnorm_variable_sets"] == [["beta", "moving_mean", "moving_variance"]]      # no gamma (B-3a)
+    assert G["moments"] == {"has_squared_difference": True, "has_stop_gradient_on_mean": True, "mean_reduction_axes": [0, 1, 2]}
+    assert G["moving_average_decay_constants"] == [0.001]                                    # 1 - 0.999 (B-3)
+    assert [p["shape"] for p in G["placeholders"]] == [[-1, 262144]] * 3                      # flat [N, 512*512] feeds
