@@ -86,17 +86,27 @@ def test_baseline_config_model_against_oracle(case):
     worst_b = sorted(((k, e) for k, e in errs.items() if k.endswith("/beta")), key=lambda kv: -kv[1])[:3]
     print("%s: worst gradient relative L2: weights %s, beta %s" % (tag, [(k, "%.2e" % e) for k, e in worst_w],
                                                                      [(k, "%.2e" % e) for k, e in worst_b]))
+    g32, _ = fp32_noise_floor(P, dims, base, data, label, w)
+    floor = {k: l2_rel(g32[k], g_ref[k]) for k in errs}
     if tight is not None:
-        # every filter gradient at full depth within 2e-3.  d(beta) = sum(g) is held to 1e-2: a constant added to a
-        # BatchNorm output is removed again by the next BatchNorm except through zero-padded borders and ReLU kinks, so
-        # these sums cancel to ~1e-3 of sum|g| (measured on the fp64 oracle: |sum g| / sum|g| = 1e-3..4e-3 for
-        # resnet_conv1's beta) and carry the fp32 rounding of the large terms
-        assert worst_w[0][1] <= tight, worst_w
+        # Full depth, 64 samples per channel at the bottleneck BatchNorm.  Measured (profiles/r02_gputest.log): the
+        # filter gradients of levels 0-2 (8^3 voxels and up per image at the BatchNorm) sit at 1e-4..2e-3; the two deepest
+        # levels reach 3.6e-3 -- and so does an INDEPENDENT fp32 evaluation of the oracle (numpy float32, other summation
+        # order): that is the conditioning of this 58-layer batch-statistics network in fp32, not a kernel property.
+        # Asserted: every filter gradient within max(2e-3, 1.5 x the fp32 floor of that tensor), three quarters of them
+        # within 2e-3 outright.  d(beta) = sum(g) is held to 1e-2: a constant added to a BatchNorm output is removed again
+        # by the next BatchNorm except through zero-padded borders and ReLU kinks, so these sums cancel to ~1e-3 of
+        # sum|g| (fp64 oracle: |sum g| / sum|g| = 1e-3..4e-3 for resnet_conv1's beta) and carry the rounding of the terms.
+        wk = [k for k in errs if k.endswith("/weights")]
+        print("%s: filter gradients: median error %.2e (fp32 floor %.2e), within 2e-3: %d of %d; worst error / floor %.2f"
+              % (tag, np.median([errs[k] for k in wk]), np.median([floor[k] for k in wk]),
+                 sum(errs[k] <= tight for k in wk), len(wk), max(errs[k] / max(floor[k], 1e-9) for k in wk)))
+        bad = [(k, errs[k], floor[k]) for k in wk if errs[k] > max(tight, 1.5 * floor[k])]
+        assert not bad, bad
+        assert sum(errs[k] <= tight for k in wk) >= 0.75 * len(wk)
         assert worst_b[0][1] <= 1e-2, worst_b
     else:
-        g32, _ = fp32_noise_floor(P, dims, base, data, label, w)
-        bad = [(k, e, l2_rel(g32[k], g_ref[k])) for k, e in errs.items()
-               if e > min(max(2e-3, 4 * l2_rel(g32[k], g_ref[k])), 5e-2)]
+        bad = [(k, e, floor[k]) for k, e in errs.items() if e > min(max(2e-3, 4 * floor[k]), 5e-2)]
         assert not bad, bad
 
 
@@ -164,5 +174,6 @@ def test_full_size_properties_and_dispatch_consistency(tag, tmp_path):
     errs = sorted(((l2_rel(b[k], a[k]), k) for k in a.files if np.linalg.norm(a[k]) > 0), reverse=True)
     print("%s: loss %.6f, worst specialised-vs-generic gradient relative L2 %s" % (tag, fast["loss"][0], errs[:3]))
     # two fp32 evaluations with different summation orders: deep-level gradients carry 0.1-1 % conditioning noise
+    # (batch 1 at 128^3 / 512^2 leaves 64 / 256 samples per channel at the bottleneck BatchNorm: median 4e-3 measured)
     assert errs[0][0] < 2e-2, errs[:3]
-    assert np.median([e for e, _ in errs]) < 2e-3
+    assert np.median([e for e, _ in errs]) < (2e-3 if case[3] > 1 else 8e-3)

@@ -149,11 +149,14 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IGemmArgs a) {
   }
 
   // ---- epilogue: lane (il = x, kl) holds channels co0 + 16m + 4kl + r of voxel (z, y, x0 + il) ----
-  float s1[MT][4], s2[MT][4];
+  // BatchNorm moments around a per-lane pivot (ursn_common.h: shifted one-pass moments); re-centred in fp64 below
+  float s1[MT][4], s2[MT][4], piv[MT][4], nacc[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < MT; ++m) {
+    nacc[m] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
+    for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = piv[m][r] = 0.f;
+  }
   const int gx = x0 + il;
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
@@ -171,17 +174,22 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IGemmArgs a) {
       *(ig_f32x4*)(op + c) = val;
       if constexpr (STATS) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[m][r] += val[r]; s2[m][r] += val[r] * val[r]; }
+        for (int r = 0; r < 4; ++r) {
+          if (nacc[m] == 0.f) piv[m][r] = val[r];
+          ursn_sacc(piv[m][r], s1[m][r], s2[m][r], val[r]);
+        }
+        nacc[m] += 1.f;
       }
     }
   }
   if constexpr (STATS) if (a.stats_partial) {
-    __shared__ float red[4][2 * BM];
+    __shared__ double red[4][2 * BM];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float u = s1[m][r], w2 = s2[m][r];
+        double u, w2;
+        ursn_sacc_final(piv[m][r], s1[m][r], s2[m][r], nacc[m], u, w2);
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
         if (il == 0) {
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(IGemmArgs a) {
     __syncthreads();
     if (tid < 2 * BM)
       a.stats_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * BM + tid] =
-          (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
+          (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   }
 }
 
@@ -395,11 +403,14 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
   }
 
   // epilogue (as igemm_conv_kernel)
-  float s1[MT][4], s2[MT][4];
+  // BatchNorm moments around a per-lane pivot (ursn_common.h: shifted one-pass moments); re-centred in fp64 below
+  float s1[MT][4], s2[MT][4], piv[MT][4], nacc[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < MT; ++m) {
+    nacc[m] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = 0.f;
+    for (int r = 0; r < 4; ++r) s1[m][r] = s2[m][r] = piv[m][r] = 0.f;
+  }
 #pragma unroll
   for (int v = 0; v < TPW; ++v) {
     if (vox[v] < 0) continue;
@@ -416,17 +427,22 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
       *(ig_f32x4*)(op + c) = val;
       if constexpr (STATS) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[m][r] += val[r]; s2[m][r] += val[r] * val[r]; }
+        for (int r = 0; r < 4; ++r) {
+          if (nacc[m] == 0.f) piv[m][r] = val[r];
+          ursn_sacc(piv[m][r], s1[m][r], s2[m][r], val[r]);
+        }
+        nacc[m] += 1.f;
       }
     }
   }
   if constexpr (STATS) if (a.stats_partial) {
-    __shared__ float red[4][2 * BM];
+    __shared__ double red[4][2 * BM];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float u = s1[m][r], w2 = s2[m][r];
+        double u, w2;
+        ursn_sacc_final(piv[m][r], s1[m][r], s2[m][r], nacc[m], u, w2);
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
         if (il == 0) {
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
     __syncthreads();
     if (tid < 2 * BM)
       a.stats_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * BM + tid] =
-          (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
+          (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   }
 }
 

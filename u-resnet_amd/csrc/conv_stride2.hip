@@ -181,7 +181,8 @@ __global__ __launch_bounds__(512, 4) void s2conv_kernel(S2Args a) {
   const int nitems = (box_end - box_begin) * nchunks;
 
   s2_f32x4 acc[NR];
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  // BatchNorm moments around a per-lane pivot (ursn_common.h: shifted one-pass moments); re-centred in fp64 below
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, piv[4] = {0.f, 0.f, 0.f, 0.f}, nacc = 0.f;
   s2_f32x4 hv[NH], wv[NWL];
   BoxPos cur = s2_box(g, box_begin, BZ, BY, BX);
   s2_load_halo<MODE, NTHR>(a.in, a.in_cs, 0, g, cur, goff, tid, hv);
@@ -232,17 +233,22 @@ __global__ __launch_bounds__(512, 4) void s2conv_kernel(S2Args a) {
         *(s2_f32x4*)op = val;
         if constexpr (STATS) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { s1[r] += val[r]; s2[r] += val[r] * val[r]; }
+          for (int r = 0; r < 4; ++r) {
+            if (nacc == 0.f) piv[r] = val[r];
+            ursn_sacc(piv[r], s1[r], s2[r], val[r]);
+          }
+          nacc += 1.f;
         }
       }
     }
     box = nbox; ch = nch; cur = nxt;
   }
   if constexpr (STATS) {
-    __shared__ float red[NWAVE][32];
+    __shared__ double red[NWAVE][32];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float u = s1[r], w2 = s2[r];
+      double u, w2;
+      ursn_sacc_final(piv[r], s1[r], s2[r], nacc, u, w2);
 #pragma unroll
       for (int o = 8; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
       if (il == 0) {
@@ -253,8 +259,8 @@ __global__ __launch_bounds__(512, 4) void s2conv_kernel(S2Args a) {
     __syncthreads();
     if (tid < 32)
       a.stats_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + tid] =
-          ((double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid]) +
-          ((double)red[4][tid] + (double)red[5][tid] + (double)red[6][tid] + (double)red[7][tid]);
+          ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) +
+          ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
   }
 }
 

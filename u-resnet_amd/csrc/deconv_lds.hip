@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256, 2) void s2scatter_kernel(ScArgs a) {
   }
 
   // epilogue: lane (il, kl) holds channels m0 + 4kl + j of the hi-res voxels 2*(lo voxel) + class offset
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  // BatchNorm moments around a per-lane pivot (ursn_common.h: shifted one-pass moments); re-centred in fp64 below
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, piv[4] = {0.f, 0.f, 0.f, 0.f}, nacc = 0.f;
   const int OZ = (KZ == 3) ? 2 * a.IZ : 1, OY = 2 * a.IY, OX = 2 * a.IX;
   const int lx = x0 + il;
 #pragma unroll
@@ -178,15 +179,20 @@ __global__ __launch_bounds__(256, 2) void s2scatter_kernel(ScArgs a) {
       *(sc_f32x4*)op = val;
       if constexpr (STATS) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[j] += val[j]; s2[j] += val[j] * val[j]; }
+        for (int j = 0; j < 4; ++j) {
+          if (nacc == 0.f) piv[j] = val[j];
+          ursn_sacc(piv[j], s1[j], s2[j], val[j]);
+        }
+        nacc += 1.f;
       }
     }
   }
   if constexpr (STATS) {
-    __shared__ float red[4][32];
+    __shared__ double red[4][32];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float u = s1[j], w2 = s2[j];
+      double u, w2;
+      ursn_sacc_final(piv[j], s1[j], s2[j], nacc, u, w2);
 #pragma unroll
       for (int o = 8; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
       if (il == 0) {
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void s2scatter_kernel(ScArgs a) {
     __syncthreads();
     if (tid < 32)
       a.stats_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + tid] =
-          (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
+          (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   }
 }
 

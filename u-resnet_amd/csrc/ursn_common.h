@@ -24,6 +24,28 @@ __device__ __forceinline__ int ursn_xcd_block(int b, int G) {
   return b;
 #endif
 }
+
+// ---- shifted one-pass moments ---------------------------------------------------------------------------------------
+// BatchNorm statistics ride in the conv epilogues as one-pass sums.  TensorFlow's moments are two-pass (SURVEY.md
+// Appendix B-3d); a plain one-pass  E[z^2] - E[z]^2  on fp32 partial sums loses var/mean^2 digits (measured: rstd off by
+// 1e-2 at |mean|/std = 1e3).  So every lane accumulates  sum(z - K), sum((z - K)^2)  around a pivot K (a sample of the
+// same channel: the first value the lane / wave sees), which keeps the fp32 partials at the scale of the variance, and
+// the partials are re-centred to K = 0 in fp64 BEFORE they are added to partials with another pivot:
+//     sum z = s1 + n K        sum z^2 = s2 + 2 K s1 + n K^2
+__device__ __forceinline__ void ursn_sacc(float piv, float& s1, float& s2, float v) {
+  const float d = v - piv;
+  s1 += d;
+  s2 = fmaf(d, d, s2);
+}
+__device__ __forceinline__ void ursn_sacc_final(float piv, float s1, float s2, float n, double& S1, double& S2) {
+  const double K = (double)piv, a = (double)s1, m = (double)n;
+  S1 = a + m * K;
+  S2 = (double)s2 + 2.0 * K * a + m * K * K;
+}
+// value of lane `src` (wave-uniform index) as a wave-uniform float: stays in an SGPR
+__device__ __forceinline__ float ursn_readlane(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
 #endif   // rename the last dispatch without counting a launch
 long ursn_kernel_launch_count();
 
