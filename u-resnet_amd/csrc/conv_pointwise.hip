@@ -64,14 +64,9 @@ __global__ __launch_bounds__(256) void pconv_kernel(PConvArgs a) {
         wreg[cq][r] = v;
       }
   }
-  // BatchNorm moments of the output, shifted by a per-wave pivot per channel kept in LDS (ursn_common.h: shifted
-  // one-pass moments): written by lane 0 in the wave's first iteration (always a real voxel), re-read by the same wave
   float s1[STATS ? CP : 1], s2[STATS ? CP : 1];
 #pragma unroll
   for (int c = 0; c < (STATS ? CP : 1); ++c) s1[c] = s2[c] = 0.f;
-  __shared__ __attribute__((aligned(16))) float spiv[STATS ? 4 : 1][STATS ? CP : 4];
-  float nacc = 0.f;       // voxels this lane summed
-  bool first = true;      // wave-uniform
 
   const int64_t hi_z = (int64_t)a.lo[0] * a.sm[0], hi_y = (int64_t)a.lo[1] * a.sm[1], hi_x = (int64_t)a.lo[2] * a.sm[2];
   // The loop is wave-uniform: v_mfma with the cbsz/abid A-broadcast must run with all 64 lanes active (a masked-off
@@ -108,7 +103,7 @@ __global__ __launch_bounds__(256) void pconv_kernel(PConvArgs a) {
         acc[cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[cq][k / 16], xv[k / 4][k % 4], acc[cq], 4, k % 16, 0);
       });
     });
-    if (!ok) { first = false; continue; }
+    if (!ok) continue;
 #pragma unroll
     for (int cq = 0; cq < CQ; ++cq) {
       pw_f32x4 val = acc[cq];
@@ -116,31 +111,24 @@ __global__ __launch_bounds__(256) void pconv_kernel(PConvArgs a) {
       if (a.accumulate) val += *(pw_f32x4*)o;
       *(pw_f32x4*)o = val;
       if constexpr (STATS) {
-        if (first && lane == 0) { volatile float* sp = &spiv[tid >> 6][4 * cq]; sp[0] = val[0]; sp[1] = val[1]; sp[2] = val[2]; sp[3] = val[3]; }
-        const volatile float* spl = &spiv[tid >> 6][4 * cq];   // volatile: another lane of this wave wrote it
-          const float pv[4] = {spl[0], spl[1], spl[2], spl[3]};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ursn_sacc(pv[j], s1[4 * cq + j], s2[4 * cq + j], val[j]);
+        for (int j = 0; j < 4; ++j) { s1[4 * cq + j] += val[j]; s2[4 * cq + j] += val[j] * val[j]; }
       }
     }
-    nacc += 1.f;
-    first = false;
   }
   if constexpr (STATS) if (a.stats_partial) {
-    __shared__ double red[4][2 * CP];
-    float cnt = nacc;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+    __shared__ float red[4][2 * CP];
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
       float u = s1[c], w2 = s2[c];
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
-      if (lane == 0) ursn_sacc_final(cnt > 0.f ? ((const volatile float*)spiv[tid >> 6])[c] : 0.f, u, w2, cnt, red[tid >> 6][c], red[tid >> 6][CP + c]);
+      if (lane == 0) { red[tid >> 6][c] = u; red[tid >> 6][CP + c] = w2; }
     }
     __syncthreads();
     if (tid < 2 * CP)
-      a.stats_partial[(size_t)blockIdx.x * 2 * CP + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      a.stats_partial[(size_t)blockIdx.x * 2 * CP + tid] =
+          (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
   }
 }
 
@@ -348,7 +336,7 @@ int launch_pointwise_conv(const ursn_conv_desc& d, ConvPass pass, const float* i
   else if (ck == 64 && cp == 32) rc = pconv_launch<64, 32>(a, flip, grid, s);
   else ursn_set_error("pointwise conv: no instantiation for %d->%d", ck, cp);
   if (rc) return rc;
-  if (stats_partial) return launch_bn_stats_final(stats_partial, grid, cp, cp, a.nvox, eps, mean, rstd, s);
+  if (stats_partial) return launch_bn_stats_final(stats_partial, grid, cp, cp, a.nvox, eps, mean, rstd, s, a.out, a.out_cs);
   return 0;
 }
 

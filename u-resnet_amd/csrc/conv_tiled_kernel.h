@@ -182,15 +182,9 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
     }
   };
 
-  // BatchNorm moments of the output, shifted by a per-wave pivot per channel (ursn_common.h: shifted one-pass moments).
-  // The pivots live in LDS (one row per wave, written by the wave's first valid lane on its first plane and re-read
-  // by the same wave: program order, no barrier): the 16-channel kernels have no registers to spare.
   float s1[STATS ? COUT : 1], s2[STATS ? COUT : 1];
 #pragma unroll
   for (int c = 0; c < (STATS ? COUT : 1); ++c) s1[c] = s2[c] = 0.f;
-  __shared__ __attribute__((aligned(16))) float spiv[STATS ? 4 : 1][STATS ? COUT : 4];
-  const unsigned long long ok_mask = __ballot(vox_ok);
-  const int piv_lane = ok_mask ? __ffsll((long long)ok_mask) - 1 : 0;
 
   // prologue: planes z0-1, z0, z0+1
   for (int p = -1; p <= 1; ++p) {
@@ -270,11 +264,11 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
         *(f32x4*)(op + 4 * cq) = v;
 #endif
         if constexpr (STATS) {
-          if (z == z0 && lane == piv_lane) { volatile float* sp = &spiv[tid >> 6][4 * cq]; sp[0] = v[0]; sp[1] = v[1]; sp[2] = v[2]; sp[3] = v[3]; }
-          const volatile float* spl = &spiv[tid >> 6][4 * cq];   // volatile: another lane of this wave wrote it
-          const float pv[4] = {spl[0], spl[1], spl[2], spl[3]};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) ursn_sacc(pv[j], s1[4 * cq + j], s2[4 * cq + j], v[j]);
+          for (int j = 0; j < 4; ++j) {
+            s1[4 * cq + j] += v[j];
+            s2[4 * cq + j] += v[j] * v[j];
+          }
         }
       }
     }
@@ -283,8 +277,7 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
   }
 
   if constexpr (STATS) if (a.stats_partial) {  // workgroup partial sums (double) -> finalised by bn_stats_final_kernel
-    __shared__ double red[4][2 * COUT];
-    const float cnt = (float)(__popcll(ok_mask) * (z1 > z0 ? z1 - z0 : 0));   // values each channel of this wave summed
+    __shared__ float red[4][2 * COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) {
       float u = s1[c], v = s2[c];
@@ -293,10 +286,16 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
         u += __shfl_xor(u, o);
         v += __shfl_xor(v, o);
       }
-      if (lane == 0) ursn_sacc_final(cnt > 0.f ? ((const volatile float*)spiv[tid >> 6])[c] : 0.f, u, v, cnt, red[tid >> 6][c], red[tid >> 6][COUT + c]);
+      if (lane == 0) {
+        red[tid >> 6][c] = u;
+        red[tid >> 6][COUT + c] = v;
+      }
     }
     __syncthreads();
-    if (tid < 2 * COUT) a.stats_partial[(size_t)blockIdx.x * 2 * COUT + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid < 2 * COUT) {
+      double t = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
+      a.stats_partial[(size_t)blockIdx.x * 2 * COUT + tid] = t;
+    }
   }
 }
 

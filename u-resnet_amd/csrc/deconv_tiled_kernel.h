@@ -93,13 +93,9 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
     }
   };
 
-  // BatchNorm moments of the output, shifted by a per-wave pivot per channel kept in LDS (conv_tiled_kernel.h)
   float s1[STATS ? CP : 1], s2[STATS ? CP : 1];
 #pragma unroll
   for (int c = 0; c < (STATS ? CP : 1); ++c) s1[c] = s2[c] = 0.f;
-  __shared__ __attribute__((aligned(16))) float spiv[STATS ? 4 : 1][STATS ? CP : 4];
-  const unsigned long long ok_mask = __ballot(vox_ok);
-  const int piv_lane = ok_mask ? __ffsll((long long)ok_mask) - 1 : 0;
 
   // prologue: planes z0-1, z0  (ring slot of plane z = (z + 3) % 3)
   stage_load(z0 - 1);
@@ -162,11 +158,11 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
           if (a.accumulate) v += *(f32x4*)(op + 4 * cq);
           *(f32x4*)(op + 4 * cq) = v;
           if constexpr (STATS) {
-            if (z == z0 && c == 0 && lane == piv_lane) { volatile float* sp = &spiv[tid >> 6][4 * cq]; sp[0] = v[0]; sp[1] = v[1]; sp[2] = v[2]; sp[3] = v[3]; }
-            const volatile float* spl = &spiv[tid >> 6][4 * cq];   // volatile: another lane of this wave wrote it
-          const float pv[4] = {spl[0], spl[1], spl[2], spl[3]};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ursn_sacc(pv[j], s1[4 * cq + j], s2[4 * cq + j], v[j]);
+            for (int j = 0; j < 4; ++j) {
+              s1[4 * cq + j] += v[j];
+              s2[4 * cq + j] += v[j] * v[j];
+            }
           }
         }
       }
@@ -176,8 +172,7 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
   }
 
   if constexpr (STATS) if (a.stats_partial) {
-    __shared__ double red[4][2 * CP];
-    const float cnt = (float)(__popcll(ok_mask) * (z1 > z0 ? z1 - z0 : 0) * NCLS);   // values per channel this wave summed
+    __shared__ float red[4][2 * CP];
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
       float u = s1[c], v = s2[c];
@@ -186,10 +181,16 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
         u += __shfl_xor(u, o);
         v += __shfl_xor(v, o);
       }
-      if (lane == 0) ursn_sacc_final(cnt > 0.f ? ((const volatile float*)spiv[tid >> 6])[c] : 0.f, u, v, cnt, red[tid >> 6][c], red[tid >> 6][CP + c]);
+      if (lane == 0) {
+        red[tid >> 6][c] = u;
+        red[tid >> 6][CP + c] = v;
+      }
     }
     __syncthreads();
-    if (tid < 2 * CP) a.stats_partial[(size_t)blockIdx.x * 2 * CP + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid < 2 * CP) {
+      double t = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
+      a.stats_partial[(size_t)blockIdx.x * 2 * CP + tid] = t;
+    }
   }
 }
 

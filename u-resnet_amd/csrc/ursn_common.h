@@ -28,10 +28,13 @@ __device__ __forceinline__ int ursn_xcd_block(int b, int G) {
 // ---- shifted one-pass moments ---------------------------------------------------------------------------------------
 // BatchNorm statistics ride in the conv epilogues as one-pass sums.  TensorFlow's moments are two-pass (SURVEY.md
 // Appendix B-3d); a plain one-pass  E[z^2] - E[z]^2  on fp32 partial sums loses var/mean^2 digits (measured: rstd off by
-// 1e-2 at |mean|/std = 1e3).  So every lane accumulates  sum(z - K), sum((z - K)^2)  around a pivot K (a sample of the
-// same channel: the first value the lane / wave sees), which keeps the fp32 partials at the scale of the variance, and
-// the partials are re-centred to K = 0 in fp64 BEFORE they are added to partials with another pivot:
+// 1e-2 at |mean|/std = 1e3).  In the implicit-GEMM / stride-2 kernels every lane accumulates  sum(z - K),
+// sum((z - K)^2)  around a pivot K (the first value the lane sees of that channel), which keeps the fp32 partials at the
+// scale of the variance, and the partials are re-centred to K = 0 in fp64 BEFORE they meet partials with another pivot:
 //     sum z = s1 + n K        sum z^2 = s2 + 2 K s1 + n K^2
+// The lane-per-voxel kernels (tconv, tdeconv, pconv) have no registers for pivots (measured: +17..36 VGPRs, spills in
+// the 16-channel shapes, +2 ms per cfg3 step): they keep plain sums and bn_stats_final_kernel recomputes an
+// ill-conditioned channel two-pass from z (elementwise.hip).
 __device__ __forceinline__ void ursn_sacc(float piv, float& s1, float& s2, float v) {
   const float d = v - piv;
   s1 += d;
@@ -41,10 +44,6 @@ __device__ __forceinline__ void ursn_sacc_final(float piv, float s1, float s2, f
   const double K = (double)piv, a = (double)s1, m = (double)n;
   S1 = a + m * K;
   S2 = (double)s2 + 2.0 * K * a + m * K * K;
-}
-// value of lane `src` (wave-uniform index) as a wave-uniform float: stays in an SGPR
-__device__ __forceinline__ float ursn_readlane(float v, int src) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 #endif   // rename the last dispatch without counting a launch
 long ursn_kernel_launch_count();
@@ -139,8 +138,10 @@ int reduce_nblocks(int64_t voxels, int channels);
 int launch_bn_stats(const float* z, int zcs, int64_t V, int C, float eps, float* mean, float* rstd,
                     void* scratch, hipStream_t s);
 // finalise [nblocks][2][C] double partials (as written by the conv epilogue) into mean/rstd
+// PC = channel stride of the partials (C padded to 4).  z != nullptr (producers with plain fp32 partial sums): channels
+// whose one-pass variance is ill-conditioned (mean^2 > 1e3 var) are recomputed two-pass from z (channel stride zcs)
 int launch_bn_stats_final(const double* partial, int nblocks, int C, int PC, int64_t V, float eps, float* mean,
-                          float* rstd, hipStream_t s);  // PC = channel stride of the partials (C padded to 4)
+                          float* rstd, hipStream_t s, const float* z = nullptr, int zcs = 0);
 // tiled small-channel conv (conv_tiled.hip): forward with fused BN-statistics partials
 int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass);
 size_t tiled_conv_stats_scratch_doubles(const ursn_conv_desc& d);
