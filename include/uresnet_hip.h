@@ -181,7 +181,9 @@ typedef struct ursn_conv_desc {
   const float* pw_dy;  /* [voxels][cout] gradient at the shortcut conv's output                                       */
   const float* pw_w;   /* [cin][cout] shortcut weights                                                                 */
   int32_t pw_dy_cstride; /* 0 = compact (= cout)                                                                       */
-  int32_t reserved_;
+  int32_t dtype;         /* 0: fp32 tensors.  1: x / y / dx / dy are bf16 (uint16 bit patterns), channel counts and strides
+                          * multiples of 8, weights and dw stay fp32 (BASELINE configs[4] mixed precision); in_split, pw_dy and
+                          * in_mean are fp32-only                                                                                */
   /* Normalise-on-load (forward and weight gradient): x is the RAW output z of the preceding conv whose BatchNorm has no
    * activation (resnet_conv1 inside a residual unit, lib/resnet_module.py:43-51); the kernel stages
    * (z - in_mean) * in_rstd + in_beta per input channel (zero padding stays zero), so that activation is never

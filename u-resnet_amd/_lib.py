@@ -34,7 +34,7 @@ class ursn_conv_desc(C.Structure):
                 ("cout", C.c_int32), ("k", C.c_int32), ("stride", C.c_int32), ("transposed", C.c_int32),
                 ("in_cstride", C.c_int32), ("out_cstride", C.c_int32), ("algo", C.c_int32),
                 ("in_split", C.c_int32), ("in2_cstride", C.c_int32), ("x2", C.c_void_p), ("dx2", C.c_void_p),
-                ("pw_dy", C.c_void_p), ("pw_w", C.c_void_p), ("pw_dy_cstride", C.c_int32), ("reserved_", C.c_int32),
+                ("pw_dy", C.c_void_p), ("pw_w", C.c_void_p), ("pw_dy_cstride", C.c_int32), ("dtype", C.c_int32),
                 ("in_mean", C.c_void_p), ("in_rstd", C.c_void_p), ("in_beta", C.c_void_p)]
 
 

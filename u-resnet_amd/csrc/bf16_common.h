@@ -1,0 +1,87 @@
+// bf16 mixed-precision path (BASELINE.json configs[4]: 3-D 256^3 bf16 with MFMA channel-block tiles) -- shared
+// declarations.  Activations, raw conv outputs z, and every gradient tensor live in HBM as bf16 (channel counts padded to
+// multiples of 8, so a voxel is a whole number of 16-byte pieces); weights stay fp32 masters and are re-packed into bf16
+// MFMA operand order at the start of every pass; all accumulation (conv, BatchNorm moments, weight gradients, Adam) is
+// fp32 / fp64.  gfx950 only.
+#pragma once
+#include "ursn_common.h"
+
+typedef unsigned short bf16_t;   // storage type (bit pattern)
+typedef __bf16 bfx8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float bf_f32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+// round-to-nearest-even, NaN stays NaN (plain cast: v_cvt_pk_bf16_f32, MI355X_MICROARCH.md correctness boundaries)
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+// 8 bf16 (one 16-byte piece) <-> 8 floats
+__device__ __forceinline__ void unpack8(const u32x4& p, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(p[i] << 16);
+    f[2 * i + 1] = __uint_as_float(p[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  u32x4 p;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+  return p;
+}
+#endif
+
+// ---- conv-like ops on bf16 tensors (bf16_conv.hip): every layer type runs through two kernels driven by the GatherGeom of
+// conv_api.hip::build_geoms ------------------------------------------------------------------------------------------
+// packed-weight elements (bf16) one geometry needs; the pack kernel re-orders the fp32 master weights into MFMA A-operand
+// order [co block][ci chunk][k step][co tile][lane][8]
+size_t bconv_pack_elems(const GatherGeom& g);
+// out[n, q*so+po, :] (=|+=) sum_t in[n, q*si+d_t, :] . W_t ; stats_partial != nullptr: BatchNorm moment partials of the
+// produced tensor (forward only), finalised into mean / rstd.  wpack: scratch of bconv_pack_elems(g) bf16.
+int launch_bconv(const GatherGeom& g, const bf16_t* in, const float* w, bf16_t* wpack, bf16_t* out, double* stats_partial,
+                 float eps, float* mean, float* rstd, int64_t stats_V, hipStream_t s);
+size_t bconv_stats_scratch_doubles(const GatherGeom& g);
+// dW[t][m][n] += sum_q S[q*si+d_t][m] * C[q][n]   (fp32 accumulation, fp32 dW)
+size_t bwgrad_scratch_bytes(const GatherGeom& g);
+int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, void* scratch, size_t scratch_bytes,
+                  hipStream_t s);
+
+// ---- elementwise (bf16_elementwise.hip) ----------------------------------------------------------------------------------
+struct BBnActArgs {   // y = act(bn(z) [+ bn(z2) | + res]); all tensors bf16, channel counts multiples of 8
+  const bf16_t* z; int zcs; const float* mean; const float* rstd; const float* beta;
+  const bf16_t* z2; int z2cs; const float* mean2; const float* rstd2; const float* beta2;
+  const bf16_t* res; int rescs;
+  bf16_t* y; int ycs;
+  int64_t V; int C; int relu;
+};
+int launch_bbn_act(const BBnActArgs& a, hipStream_t s);
+struct BBnBwdArgs {   // as BnBwdArgs (ursn_common.h) on bf16 tensors; the relu mask is y > 0 (y given) or bn(z) > 0 (beta given)
+  const bf16_t* dy; int dycs; const bf16_t* y; int ycs;
+  const bf16_t* z; int zcs; const float* mean; const float* rstd; bf16_t* dz; int dzcs; float* dbeta;
+  const float* beta;
+  const bf16_t* z2; int z2cs; const float* mean2; const float* rstd2; bf16_t* dz2; int dz2cs; float* dbeta2;
+  bf16_t* dres; int drescs; int dres_accumulate;
+  int64_t V; int C; int relu;
+  void* scratch;
+  int Cw;
+};
+int launch_bbn_bwd(const BBnBwdArgs& a, hipStream_t s);
+size_t bbn_scratch_bytes(int64_t V, int C);
+struct BHeadArgs {    // logits = bn(z); z, dlogits bf16 with channel stride 8
+  const bf16_t* z; int z_cs; const float* mean; const float* rstd; const float* beta;
+  const float* data; int data_cs; const float* label; const float* weight;
+  int n; int64_t pix; int ncls;
+  float* softmax_out; bf16_t* dlogits; int dl_cs;
+  float* ana_out;
+  float* metrics; void* scratch;
+};
+int launch_bhead(const BHeadArgs& a, hipStream_t s);
+// data [V] fp32 (one input channel) -> [V][8] bf16, channels 1..7 zero
+int launch_bf16_input(const float* data, bf16_t* out, int64_t V, hipStream_t s);
+int launch_f32_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t s);
+int launch_bf16_to_f32(const bf16_t* src, float* dst, int64_t n, hipStream_t s);

@@ -1,0 +1,582 @@
+// bf16 convolution kernels (gfx950): ONE LDS-tiled implicit-GEMM kernel for every conv-like forward / data-gradient
+// pass of the path and ONE weight-gradient kernel, both driven by the GatherGeom of conv_api.hip::build_geoms
+//     out[n, q*so + po, :] (=|+=) sum_t in[n, q*si + d_t, :] . W_t            dW_t += sum_q S[q*si + d_t]^T C[q]
+// (k3 s1, k3 s2, 1x1 s1|s2, transposed conv and scatter-type data gradients by output-parity class: lib/uresnet.py:37-121,
+// lib/resnet_module.py:25-66).  bf16 operands, fp32 accumulation on v_mfma_f32_16x16x32_bf16.
+//
+// bconv: a workgroup (4 waves) owns a box of q points (BZ x BY x BX, BX a multiple of 16) and one block of <= 32 produced
+// channels.  Per chunk of <= 32 contraction channels the input halo box is staged ONCE in LDS as [voxel][channel] (NDHWC
+// order: a lane's MFMA B operand = 8 consecutive channels of one tap of one voxel = one ds_read_b128) together with the
+// chunk's weights in A-operand order; every tap re-reads the box from LDS, never from HBM.  D = W^T (M = produced
+// channels) x X (N = 16 voxels along x): a lane ends with 4 consecutive channels of one voxel -> 8-byte bf16 stores.
+// k index inside a chunk: slot s = tap * (chunk channels / 8) + channel block, four slots per MFMA.
+// BatchNorm moment partials (per-lane pivots, fp64 re-centring: ursn_common.h) ride in the forward epilogue.
+//
+// bwgrad: contraction over voxels.  The S halo box and the C box are staged in the same [voxel][channel] order and read
+// with ds_read_b64_tr_b16 (hardware transpose: a 16-lane group gets, per lane, one channel of 4 consecutive voxels), so no
+// transposed copy of either tensor ever exists.  M rows = (tap, contraction channel), taps split over the 4 waves (no
+// cross-wave sum); a workgroup walks many boxes and leaves ONE fp32 slab, slabs are summed in fixed order.
+#include <stdlib.h>
+
+#include "bf16_common.h"
+
+#define BCONV_MAX_SLOTS 112
+
+struct BConvArgs {
+  const bf16_t* in;
+  const bf16_t* wp;
+  bf16_t* out;
+  double* stats_partial;   // [grid.y][grid.x][2][cob] or null
+  int N;
+  int in_d[3], out_d[3], q_d[3], so[3], po[3], si[3];
+  int Cin, Cout, in_cs, out_cs, accumulate;
+  int bq[3], nb[3], hb[3], dmin[3];
+  int cinc, nchunks, nj, cob;
+  int toff[BCONV_MAX_SLOTS];
+};
+
+template <int VT, int COT>
+__global__ __launch_bounds__(256) void bconv_kernel(BConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, g = lane >> 4;
+  const int cpb = a.cinc >> 3;                                   // 16-byte pieces per staged voxel
+  const int hbvox = a.hb[0] * a.hb[1] * a.hb[2];
+  unsigned char* xin = smem;
+  unsigned char* wl = smem + (((size_t)hbvox * cpb * 16 + 15) & ~(size_t)15);
+
+  int b = ursn_xcd_block(blockIdx.x, gridDim.x);
+  const int bx = b % a.nb[2]; b /= a.nb[2];
+  const int by = b % a.nb[1]; b /= a.nb[1];
+  const int bz = b % a.nb[0];
+  const int n = b / a.nb[0];
+  const int q0[3] = {bz * a.bq[0], by * a.bq[1], bx * a.bq[2]};
+  const int co0 = blockIdx.y * a.cob;
+  const int xr = a.bq[2] >> 4;
+
+  __shared__ int toff_s[BCONV_MAX_SLOTS];   // tap / channel-block offsets of the k slots, read per lane (slot 4 j + g)
+  if (tid < BCONV_MAX_SLOTS) toff_s[tid] = tid < 4 * a.nj ? a.toff[tid] : 0;
+  int vbase[VT];   // LDS byte offset of the input voxel under this lane's q point (tap offsets are added per k step)
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    const int tl = wave * VT + vt, row = tl / xr, qx = (tl % xr) * 16 + m;
+    const int qz = row / a.bq[1], qy = row % a.bq[1];
+    vbase[vt] = (((qz * a.si[0]) * a.hb[1] + qy * a.si[1]) * a.hb[2] + qx * a.si[2]) * cpb * 16;
+  }
+  bf_f32x4 acc[VT][COT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt)
+#pragma unroll
+    for (int c = 0; c < COT; ++c) acc[vt][c] = (bf_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int g0 = q0[0] * a.si[0] + a.dmin[0], g1 = q0[1] * a.si[1] + a.dmin[1], g2 = q0[2] * a.si[2] + a.dmin[2];
+  const int wpieces = a.nj * COT * 64;
+  for (int ch = 0; ch < a.nchunks; ++ch) {
+    if (ch) __syncthreads();
+    for (int idx = tid; idx < hbvox * cpb; idx += 256) {
+      const int vox = idx / cpb, cb = idx - vox * cpb;
+      const int hx = vox % a.hb[2], t2 = vox / a.hb[2], hy = t2 % a.hb[1], hz = t2 / a.hb[1];
+      const int z = g0 + hz, y = g1 + hy, x = g2 + hx;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (z >= 0 && z < a.in_d[0] && y >= 0 && y < a.in_d[1] && x >= 0 && x < a.in_d[2])
+        v = *(const u32x4*)(a.in + ((((size_t)n * a.in_d[0] + z) * a.in_d[1] + y) * a.in_d[2] + x) * a.in_cs + ch * a.cinc + cb * 8);
+      *(u32x4*)(xin + (size_t)idx * 16) = v;
+    }
+    const u32x4* wsrc = (const u32x4*)a.wp + ((size_t)blockIdx.y * a.nchunks + ch) * wpieces;
+    for (int idx = tid; idx < wpieces; idx += 256) ((u32x4*)wl)[idx] = wsrc[idx];
+    __syncthreads();
+    for (int j = 0; j < a.nj; ++j) {
+      const int to = toff_s[4 * j + g];
+      bfx8 A[COT];
+#pragma unroll
+      for (int c = 0; c < COT; ++c) A[c] = *(const bfx8*)(wl + ((size_t)(j * COT + c) * 64 + lane) * 16);
+#pragma unroll
+      for (int vt = 0; vt < VT; ++vt) {
+        const bfx8 B = *(const bfx8*)(xin + vbase[vt] + to);
+#pragma unroll
+        for (int c = 0; c < COT; ++c) acc[vt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[c], B, acc[vt][c], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane (m, g) holds channels co0 + 16c + 4g + r of the voxel under q point (tile vt, m) ----
+  float s1[COT][4], s2[COT][4], piv[COT][4], nacc = 0.f;
+#pragma unroll
+  for (int c = 0; c < COT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1[c][r] = s2[c][r] = piv[c][r] = 0.f;
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    const int tl = wave * VT + vt, row = tl / xr, qx = q0[2] + (tl % xr) * 16 + m;
+    const int qz = q0[0] + row / a.bq[1], qy = q0[1] + row % a.bq[1];
+    if (!(qz < a.q_d[0] && qy < a.q_d[1] && qx < a.q_d[2])) continue;
+    bf16_t* op = a.out + ((((size_t)n * a.out_d[0] + qz * a.so[0] + a.po[0]) * a.out_d[1] + qy * a.so[1] + a.po[1]) * a.out_d[2] +
+                          qx * a.so[2] + a.po[2]) * a.out_cs + co0 + 4 * g;
+#pragma unroll
+    for (int c = 0; c < COT; ++c) {
+      if (co0 + 16 * c + 4 * g >= a.Cout) continue;
+      bf_f32x4 v = acc[vt][c];
+      u32x2* o = (u32x2*)(op + 16 * c);
+      if (a.accumulate) {
+        const u32x2 e = *o;
+        v[0] += __uint_as_float(e[0] << 16); v[1] += __uint_as_float(e[0] & 0xffff0000u);
+        v[2] += __uint_as_float(e[1] << 16); v[3] += __uint_as_float(e[1] & 0xffff0000u);
+      }
+      u32x2 pk;
+      pk[0] = pack_bf2(v[0], v[1]);
+      pk[1] = pack_bf2(v[2], v[3]);
+      *o = pk;
+      if (a.stats_partial) {   // moments of the STORED (rounded) tensor: that is what BatchNorm will normalise
+        const float rv[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
+                             __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (nacc == 0.f) piv[c][r] = rv[r];
+          ursn_sacc(piv[c][r], s1[c][r], s2[c][r], rv[r]);
+        }
+      }
+    }
+    nacc += 1.f;
+  }
+  if (a.stats_partial) {
+    __shared__ double red[4][2 * 16 * COT];
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double u, w2;
+        ursn_sacc_final(piv[c][r], s1[c][r], s2[c][r], nacc, u, w2);
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
+        if (m == 0) {
+          red[wave][16 * c + 4 * g + r] = u;
+          red[wave][16 * COT + 16 * c + 4 * g + r] = w2;
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * 16 * COT)
+      a.stats_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * 16 * COT + tid] =
+          (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  }
+}
+
+// ---- weight packing: fp32 master W_t[k][n] -> bf16 A-operand order [co block][chunk][j][co tile][lane = 16 g + m][8] -------
+struct BPackArgs {
+  const float* w;
+  bf16_t* wp;
+  int ntaps, K, Nn, w_tap_stride, w_sk, w_sn;
+  int tap_w[URSN_MAX_TAPS];
+  int cinc, nchunks, nj, cot, ncob;
+};
+__global__ __launch_bounds__(256) void bconv_pack_kernel(BPackArgs a) {
+  const int cpb = a.cinc >> 3;
+  const int64_t total = (int64_t)a.ncob * a.nchunks * a.nj * a.cot * 64 * 8;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e & 7);
+    int64_t r = e >> 3;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int c = (int)(r % a.cot); r /= a.cot;
+    const int j = (int)(r % a.nj); r /= a.nj;
+    const int ch = (int)(r % a.nchunks);
+    const int cb_ = (int)(r / a.nchunks);
+    const int m = lane & 15, g = lane >> 4;
+    const int s = 4 * j + g, t = s / cpb, cb = s - t * cpb;
+    const int k = ch * a.cinc + cb * 8 + i, nn = (cb_ * a.cot + c) * 16 + m;
+    float v = 0.f;
+    if (t < a.ntaps && k < a.K && nn < a.Nn) v = a.w[(int64_t)a.tap_w[t] * a.w_tap_stride + (int64_t)k * a.w_sk + (int64_t)nn * a.w_sn];
+    a.wp[e] = f2bf(v);
+  }
+}
+
+// ---- host side: box / chunk choice ----------------------------------------------------------------------------------
+struct BPlan {
+  int bq[3], nb[3], hb[3], dmin[3];
+  int cinc, nchunks, nj, cot, ncob, vt;
+  size_t lds;
+  int gridx;
+};
+
+static bool bconv_plan(const GatherGeom& g, BPlan& p) {
+  if ((g.K & 7) || (g.Nn & 7) || (g.in_cs & 7) || (g.out_cs & 3) || g.ntaps < 1) return false;
+  int dmax[3];
+  for (int j = 0; j < 3; ++j) {
+    p.dmin[j] = g.tap_d[0][j]; dmax[j] = g.tap_d[0][j];
+    for (int t = 1; t < g.ntaps; ++t) {
+      if (g.tap_d[t][j] < p.dmin[j]) p.dmin[j] = g.tap_d[t][j];
+      if (g.tap_d[t][j] > dmax[j]) dmax[j] = g.tap_d[t][j];
+    }
+  }
+  p.cinc = g.K >= 32 ? 32 : g.K;           // 8 | 16 | 24 | 32 contraction channels per staged chunk
+  if (g.K > 32 && (g.K % 32)) p.cinc = (g.K % 16) ? 8 : 16;
+  p.nchunks = g.K / p.cinc;
+  const int slots = g.ntaps * (p.cinc / 8);
+  p.nj = (slots + 3) / 4;
+  if (p.nj * 4 > BCONV_MAX_SLOTS) return false;
+  p.cot = g.Nn > 16 ? 2 : 1;
+  p.ncob = (g.Nn + 16 * p.cot - 1) / (16 * p.cot);
+  // largest box whose halo + weights fit the LDS budget (two workgroups per CU) AND that still fills the chip; small
+  // problems fall through to the smallest box that fits
+  static const int cand[][3] = {{2, 8, 32}, {1, 8, 32}, {1, 4, 32}, {1, 2, 32}, {1, 4, 16}};
+  const int ncand = (int)(sizeof(cand) / sizeof(cand[0]));
+  const size_t wbytes = (size_t)p.nj * p.cot * 64 * 16;
+  const size_t limits[2] = {76 * 1024, 156 * 1024};
+  for (size_t limit : limits) {
+    BPlan fit;
+    bool have = false;
+    for (int ci = 0; ci < ncand; ++ci) {
+      BPlan c = p;
+      int bq[3] = {cand[ci][0], cand[ci][1], cand[ci][2]};
+      if (g.q_d[0] == 1) { bq[1] *= bq[0]; bq[0] = 1; }          // 2-D problems: all rows in y
+      for (int j = 0; j < 3; ++j) {
+        c.bq[j] = bq[j];
+        c.hb[j] = (bq[j] - 1) * g.si[j] + (dmax[j] - p.dmin[j]) + 1;
+        c.nb[j] = (g.q_d[j] + bq[j] - 1) / bq[j];
+      }
+      const int nq = c.bq[0] * c.bq[1] * c.bq[2];
+      c.vt = nq / 64;
+      c.lds = ((((size_t)c.hb[0] * c.hb[1] * c.hb[2] * c.cinc * 2) + 15) & ~(size_t)15) + wbytes;
+      const int64_t boxes = (int64_t)g.N * c.nb[0] * c.nb[1] * c.nb[2];
+      if (c.lds > limit || boxes <= 0 || boxes >= (1ll << 31)) continue;
+      c.gridx = (int)boxes;
+      fit = c;
+      have = true;
+      if (boxes * c.ncob >= 512) { p = c; return true; }
+    }
+    if (have) { p = fit; return true; }
+  }
+  return false;
+}
+
+size_t bconv_pack_elems(const GatherGeom& g) {
+  BPlan p;
+  if (!bconv_plan(g, p)) return 0;
+  return (size_t)p.ncob * p.nchunks * p.nj * p.cot * 64 * 8;
+}
+
+size_t bconv_stats_scratch_doubles(const GatherGeom& g) {
+  BPlan p;
+  if (!bconv_plan(g, p)) return 0;
+  return (size_t)p.ncob * p.gridx * 2 * 16 * p.cot;
+}
+
+template <int VT, int COT>
+static int bconv_launch(const BPlan& p, const BConvArgs& a, hipStream_t s) {
+  auto kern = bconv_kernel<VT, COT>;
+  static size_t attr = 48 * 1024;
+  if (p.lds > attr) {
+    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    attr = p.lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.gridx, p.ncob), dim3(256), p.lds, s, a);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_bconv(const GatherGeom& g, const bf16_t* in, const float* w, bf16_t* wpack, bf16_t* out, double* stats_partial,
+                 float eps, float* mean, float* rstd, int64_t stats_V, hipStream_t s) {
+  BPlan p;
+  URSN_REQUIRE(bconv_plan(g, p), "bf16 conv: unsupported geometry (channels %d -> %d, strides %d / %d)", g.K, g.Nn, g.in_cs, g.out_cs);
+  {
+    BPackArgs k;
+    k.w = w; k.wp = wpack; k.ntaps = g.ntaps; k.K = g.K; k.Nn = g.Nn;
+    k.w_tap_stride = g.w_tap_stride; k.w_sk = g.w_sk; k.w_sn = g.w_sn;
+    for (int t = 0; t < g.ntaps; ++t) k.tap_w[t] = g.tap_w[t];
+    k.cinc = p.cinc; k.nchunks = p.nchunks; k.nj = p.nj; k.cot = p.cot; k.ncob = p.ncob;
+    const int64_t total = (int64_t)p.ncob * p.nchunks * p.nj * p.cot * 64 * 8;
+    int blocks = (int)(cdiv64(total, 256) < 2048 ? cdiv64(total, 256) : 2048);
+    hipLaunchKernelGGL(bconv_pack_kernel, dim3(blocks), dim3(256), 0, s, k);
+    URSN_HIP(hipGetLastError());
+  }
+  BConvArgs a;
+  a.in = in; a.wp = wpack; a.out = out; a.stats_partial = stats_partial;
+  a.N = g.N;
+  for (int j = 0; j < 3; ++j) {
+    a.in_d[j] = g.in_d[j]; a.out_d[j] = g.out_d[j]; a.q_d[j] = g.q_d[j]; a.so[j] = g.so[j]; a.po[j] = g.po[j]; a.si[j] = g.si[j];
+    a.bq[j] = p.bq[j]; a.nb[j] = p.nb[j]; a.hb[j] = p.hb[j]; a.dmin[j] = p.dmin[j];
+  }
+  a.Cin = g.K; a.Cout = g.Nn; a.in_cs = g.in_cs; a.out_cs = g.out_cs; a.accumulate = g.accumulate;
+  a.cinc = p.cinc; a.nchunks = p.nchunks; a.nj = p.nj; a.cob = 16 * p.cot;
+  const int cpb = p.cinc / 8;
+  for (int sl = 0; sl < p.nj * 4; ++sl) {
+    const int t = sl / cpb, cb = sl - t * cpb;
+    a.toff[sl] = 0;
+    if (t < g.ntaps)
+      a.toff[sl] = ((((g.tap_d[t][0] - p.dmin[0]) * p.hb[1] + (g.tap_d[t][1] - p.dmin[1])) * p.hb[2] + (g.tap_d[t][2] - p.dmin[2])) * cpb + cb) * 16;
+  }
+  ursn_note_kernel("bconv_bf16");
+  int rc = 3;
+#define BC(vt_, cot_) if (p.vt == vt_ && p.cot == cot_) rc = bconv_launch<vt_, cot_>(p, a, s);
+  BC(8, 1) BC(8, 2) BC(4, 1) BC(4, 2) BC(2, 1) BC(2, 2) BC(1, 1) BC(1, 2)
+#undef BC
+  if (rc) return rc;
+  if (stats_partial) {
+    for (int cb = 0; cb < p.ncob; ++cb) {
+      const int c0 = cb * 16 * p.cot;
+      const int cn = g.Nn - c0 < 16 * p.cot ? g.Nn - c0 : 16 * p.cot;
+      URSN_TRY(launch_bn_stats_final(stats_partial + (size_t)cb * p.gridx * 2 * 16 * p.cot, p.gridx, cn, 16 * p.cot, stats_V, eps,
+                                     mean + c0, rstd + c0, s));
+    }
+  }
+  return 0;
+}
+
+// =========================================================================================================================
+// weight gradient
+// =========================================================================================================================
+struct BWgradArgs {
+  const bf16_t* S;      // gathered tensor (in_d, in_cs), contraction channels K
+  const bf16_t* C;      // q-grid tensor (q_d, out_cs), produced channels Nn
+  float* slab;          // [grid.y][grid.x][U*16][16*COT] fp32
+  int N;
+  int in_d[3], q_d[3], si[3];
+  int K, Nn, in_cs, out_cs;
+  int bq[3], nb[3], hb[3], dmin[3];
+  int cinc, nchunks, ncob, U;     // U: 16-row tiles of (tap, channel) rows per chunk
+  int nboxes;
+  int toff[BCONV_MAX_SLOTS];      // LDS byte offset of k slot s = tap * (cinc/8) + channel block (as in bconv)
+};
+
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+}
+__device__ __forceinline__ bfx8 tr_pair(const unsigned char* p0, const unsigned char* p1) {
+  const s16x4 lo = lds_tr16(p0), hi = lds_tr16(p1);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bfx8, v);
+}
+
+// MTW: 16-row tiles per wave (tile u = wave + 4 i), COT: 16-column tiles of produced channels
+template <int MTW, int COT>
+__global__ __launch_bounds__(256) void bwgrad_kernel(BWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;   // transposed read: lane (row tq, column piece tp) of group G
+  const int cpb = a.cinc >> 3;                    // 16-byte pieces per staged S voxel
+  const int ccn = 16 * COT;                       // staged C channels per voxel
+  const int hbvox = a.hb[0] * a.hb[1] * a.hb[2];
+  const int nq = a.bq[0] * a.bq[1] * a.bq[2];
+  unsigned char* sbox = smem;
+  unsigned char* cbox = smem + (((size_t)hbvox * cpb * 16 + 64 + 15) & ~(size_t)15);
+  const int pair = blockIdx.y, ch = pair % a.nchunks, cb_ = pair / a.nchunks;
+  const int co0 = cb_ * ccn;
+
+  bf_f32x4 acc[MTW][COT];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int c = 0; c < COT; ++c) acc[i][c] = (bf_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per M tile of this wave: LDS byte offset of (k slot of this lane's column piece) relative to the voxel position
+  __shared__ int toff_s[BCONV_MAX_SLOTS];
+  if (tid < BCONV_MAX_SLOTS) toff_s[tid] = a.toff[tid];
+  __syncthreads();
+  int aoff[MTW];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    const int u = wave + 4 * i, slot = 2 * u + (tp >> 1);
+    aoff[i] = ((u < a.U && slot < BCONV_MAX_SLOTS) ? toff_s[slot] : 0) + (tp & 1) * 8;
+  }
+  const int xruns = a.bq[2] >> 5, nsteps = a.bq[0] * a.bq[1] * xruns;
+
+  for (int box = blockIdx.x; box < a.nboxes; box += gridDim.x) {
+    int b = box;
+    const int bx = b % a.nb[2]; b /= a.nb[2];
+    const int by = b % a.nb[1]; b /= a.nb[1];
+    const int bz = b % a.nb[0];
+    const int n = b / a.nb[0];
+    const int q0[3] = {bz * a.bq[0], by * a.bq[1], bx * a.bq[2]};
+    const int g0 = q0[0] * a.si[0] + a.dmin[0], g1 = q0[1] * a.si[1] + a.dmin[1], g2 = q0[2] * a.si[2] + a.dmin[2];
+    __syncthreads();   // the previous box's reads are done
+    for (int idx = tid; idx < hbvox * cpb; idx += 256) {
+      const int vox = idx / cpb, cb = idx - vox * cpb;
+      const int hx = vox % a.hb[2], t2 = vox / a.hb[2], hy = t2 % a.hb[1], hz = t2 / a.hb[1];
+      const int z = g0 + hz, y = g1 + hy, x = g2 + hx;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (z >= 0 && z < a.in_d[0] && y >= 0 && y < a.in_d[1] && x >= 0 && x < a.in_d[2])
+        v = *(const u32x4*)(a.S + ((((size_t)n * a.in_d[0] + z) * a.in_d[1] + y) * a.in_d[2] + x) * a.in_cs + ch * a.cinc + cb * 8);
+      *(u32x4*)(sbox + (size_t)idx * 16) = v;
+    }
+    for (int idx = tid; idx < nq * (ccn >> 3); idx += 256) {
+      const int vox = idx / (ccn >> 3), cb = idx - vox * (ccn >> 3);
+      const int qx = vox % a.bq[2], t2 = vox / a.bq[2], qy = t2 % a.bq[1], qz = t2 / a.bq[1];
+      const int z = q0[0] + qz, y = q0[1] + qy, x = q0[2] + qx;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (z < a.q_d[0] && y < a.q_d[1] && x < a.q_d[2] && co0 + cb * 8 < a.Nn)
+        v = *(const u32x4*)(a.C + ((((size_t)n * a.q_d[0] + z) * a.q_d[1] + y) * a.q_d[2] + x) * a.out_cs + co0 + cb * 8);
+      *(u32x4*)(cbox + (size_t)idx * 16) = v;
+    }
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+      const int row = st / xruns, xq = (st - row * xruns) * 32 + 8 * G + tq;   // this lane's voxel row of the first 4x16 block
+      const int qz = row / a.bq[1], qy = row - qz * a.bq[1];
+      // B operand: C[k = voxel][n = channel]; lane supplies row tq, columns 4 tp .. 4 tp + 3
+      bfx8 B[COT];
+      {
+        const unsigned char* cp = cbox + ((size_t)((qz * a.bq[1] + qy) * a.bq[2] + xq) * ccn + tp * 4) * 2;
+#pragma unroll
+        for (int c = 0; c < COT; ++c) B[c] = tr_pair(cp + c * 32, cp + c * 32 + (size_t)4 * ccn * 2);
+      }
+      const int sp = (((qz * a.si[0]) * a.hb[1] + qy * a.si[1]) * a.hb[2] + xq * a.si[2]) * cpb * 16;   // S position under voxel row tq
+      const int sp4 = 4 * a.si[2] * cpb * 16;                                                          // + 4 voxels along x
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) {
+        const bfx8 A = tr_pair(sbox + sp + aoff[i], sbox + sp + sp4 + aoff[i]);
+#pragma unroll
+        for (int c = 0; c < COT; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B[c], acc[i][c], 0, 0, 0);
+      }
+    }
+  }
+  // slab: rows 16 u + 4 G + r, columns 16 c + li
+  float* sl = a.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ((size_t)a.U * 16 * ccn);
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    const int u = wave + 4 * i;
+    if (u >= a.U) continue;
+#pragma unroll
+    for (int c = 0; c < COT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sl[(size_t)(16 * u + 4 * G + r) * ccn + 16 * c + li] = acc[i][c][r];
+  }
+}
+
+// dw[tap_w[t]][ci][co] += sum over workgroup slabs (fixed order); one thread per (pair, row, column)
+struct BWReduceArgs {
+  const float* slab; float* dw;
+  int nslabs, U, ccn, cinc, nchunks, ncob, ntaps, K, Nn;
+  int tap_w[URSN_MAX_TAPS];
+};
+__global__ __launch_bounds__(256) void bwgrad_reduce_kernel(BWReduceArgs a) {
+  const int cpb = a.cinc >> 3;
+  const int64_t per = (int64_t)a.U * 16 * a.ccn, total = per * a.nchunks * a.ncob;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int pair = (int)(e / per);
+    const int64_t rc = e - (int64_t)pair * per;
+    const int row = (int)(rc / a.ccn), col = (int)(rc - (int64_t)row * a.ccn);
+    const int ch = pair % a.nchunks, cb_ = pair / a.nchunks;
+    const int slot = row >> 3, t = slot / cpb, cb = slot - t * cpb;
+    const int ci = ch * a.cinc + cb * 8 + (row & 7), co = cb_ * a.ccn + col;
+    if (t >= a.ntaps || ci >= a.K || co >= a.Nn) continue;
+    const float* p = a.slab + (size_t)pair * a.nslabs * per + rc;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < a.nslabs; k += 4) {
+      s0 += p[(size_t)k * per]; s1 += p[(size_t)(k + 1) * per]; s2 += p[(size_t)(k + 2) * per]; s3 += p[(size_t)(k + 3) * per];
+    }
+    for (; k < a.nslabs; ++k) s0 += p[(size_t)k * per];
+    a.dw[(size_t)a.tap_w[t] * a.K * a.Nn + (size_t)ci * a.Nn + co] += (s0 + s1) + (s2 + s3);
+  }
+}
+
+struct BWPlan {
+  int bq[3], nb[3], hb[3], dmin[3];
+  int cinc, nchunks, cot, ncob, U, mtw, nboxes, gridx;
+  size_t lds;
+};
+
+static bool bwgrad_plan(const GatherGeom& g, BWPlan& p) {
+  if ((g.K & 7) || (g.Nn & 7) || (g.in_cs & 7) || (g.out_cs & 7) || g.ntaps < 1) return false;
+  int dmax[3];
+  for (int j = 0; j < 3; ++j) {
+    p.dmin[j] = g.tap_d[0][j]; dmax[j] = g.tap_d[0][j];
+    for (int t = 1; t < g.ntaps; ++t) {
+      if (g.tap_d[t][j] < p.dmin[j]) p.dmin[j] = g.tap_d[t][j];
+      if (g.tap_d[t][j] > dmax[j]) dmax[j] = g.tap_d[t][j];
+    }
+  }
+  p.cinc = g.K >= 32 ? 32 : g.K;
+  if (g.K > 32 && (g.K % 32)) p.cinc = (g.K % 16) ? 8 : 16;
+  p.nchunks = g.K / p.cinc;
+  const int slots = g.ntaps * (p.cinc / 8);
+  if (slots + 2 > BCONV_MAX_SLOTS) return false;
+  p.U = (slots + 1) / 2;
+  const int per_wave = (p.U + 3) / 4;
+  p.mtw = per_wave <= 1 ? 1 : per_wave <= 2 ? 2 : per_wave <= 4 ? 4 : per_wave <= 7 ? 7 : 14;
+  if (per_wave > 14) return false;
+  p.cot = g.Nn > 16 ? 2 : 1;
+  p.ncob = (g.Nn + 16 * p.cot - 1) / (16 * p.cot);
+  static const int cand[][3] = {{2, 8, 32}, {1, 8, 32}, {1, 4, 32}, {1, 2, 32}, {1, 1, 32}};
+  const int ncand = (int)(sizeof(cand) / sizeof(cand[0]));
+  const size_t limits[2] = {76 * 1024, 156 * 1024};
+  for (size_t limit : limits)
+    for (int ci = 0; ci < ncand; ++ci) {
+      int bq[3] = {cand[ci][0], cand[ci][1], cand[ci][2]};
+      if (g.q_d[0] == 1) { bq[1] *= bq[0]; bq[0] = 1; }
+      for (int j = 0; j < 3; ++j) {
+        p.bq[j] = bq[j];
+        p.hb[j] = (bq[j] - 1) * g.si[j] + (dmax[j] - p.dmin[j]) + 1;
+        p.nb[j] = (g.q_d[j] + bq[j] - 1) / bq[j];
+      }
+      const size_t sbytes = (((size_t)p.hb[0] * p.hb[1] * p.hb[2] * p.cinc * 2) + 64 + 15) & ~(size_t)15;
+      const size_t cbytes = (size_t)p.bq[0] * p.bq[1] * p.bq[2] * 16 * p.cot * 2 + 64;
+      p.lds = sbytes + cbytes;
+      const int64_t boxes = (int64_t)g.N * p.nb[0] * p.nb[1] * p.nb[2];
+      if (p.lds > limit || boxes <= 0 || boxes >= (1ll << 31)) continue;
+      // smaller boxes when the problem is small, so that more than a handful of workgroups take part
+      if (boxes * p.nchunks * p.ncob < 256 && ci + 1 < ncand) continue;
+      p.nboxes = (int)boxes;
+      int64_t gx = 1024 / ((int64_t)p.nchunks * p.ncob);
+      if (gx < 1) gx = 1;
+      if (gx > boxes) gx = boxes;
+      p.gridx = (int)gx;
+      return true;
+    }
+  return false;
+}
+
+size_t bwgrad_scratch_bytes(const GatherGeom& g) {
+  BWPlan p;
+  if (!bwgrad_plan(g, p)) return 0;
+  return (size_t)p.nchunks * p.ncob * p.gridx * p.U * 16 * 16 * p.cot * sizeof(float) + 256;
+}
+
+template <int MTW, int COT>
+static int bwgrad_launch(const BWPlan& p, const BWgradArgs& a, hipStream_t s) {
+  auto kern = bwgrad_kernel<MTW, COT>;
+  static size_t attr = 48 * 1024;
+  if (p.lds > attr) {
+    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    attr = p.lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.gridx, p.nchunks * p.ncob), dim3(256), p.lds, s, a);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, void* scratch, size_t scratch_bytes,
+                  hipStream_t s) {
+  BWPlan p;
+  URSN_REQUIRE(bwgrad_plan(g, p), "bf16 wgrad: unsupported geometry (channels %d x %d)", g.K, g.Nn);
+  URSN_REQUIRE(scratch && scratch_bytes >= bwgrad_scratch_bytes(g), "bf16 wgrad: scratch too small");
+  BWgradArgs a;
+  a.S = S; a.C = C; a.slab = (float*)scratch; a.N = g.N;
+  for (int j = 0; j < 3; ++j) {
+    a.in_d[j] = g.in_d[j]; a.q_d[j] = g.q_d[j]; a.si[j] = g.si[j];
+    a.bq[j] = p.bq[j]; a.nb[j] = p.nb[j]; a.hb[j] = p.hb[j]; a.dmin[j] = p.dmin[j];
+  }
+  a.K = g.K; a.Nn = g.Nn; a.in_cs = g.in_cs; a.out_cs = g.out_cs;
+  a.cinc = p.cinc; a.nchunks = p.nchunks; a.ncob = p.ncob; a.U = p.U; a.nboxes = p.nboxes;
+  const int cpb = p.cinc / 8, slots = g.ntaps * cpb;
+  for (int sl = 0; sl < BCONV_MAX_SLOTS; ++sl) {
+    const int t = sl / cpb, cb = sl - t * cpb;
+    a.toff[sl] = 0;
+    if (sl < slots)
+      a.toff[sl] = ((((g.tap_d[t][0] - p.dmin[0]) * p.hb[1] + (g.tap_d[t][1] - p.dmin[1])) * p.hb[2] + (g.tap_d[t][2] - p.dmin[2])) * cpb + cb) * 16;
+  }
+  ursn_note_kernel("bwgrad_bf16");
+  int rc = 3;
+#define BW(m_, c_) if (p.mtw == m_ && p.cot == c_) rc = bwgrad_launch<m_, c_>(p, a, s);
+  BW(1, 1) BW(1, 2) BW(2, 1) BW(2, 2) BW(4, 1) BW(4, 2) BW(7, 1) BW(7, 2) BW(14, 1) BW(14, 2)
+#undef BW
+  if (rc) return rc;
+  BWReduceArgs r;
+  r.slab = (const float*)scratch; r.dw = dw; r.nslabs = p.gridx; r.U = p.U; r.ccn = 16 * p.cot; r.cinc = p.cinc;
+  r.nchunks = p.nchunks; r.ncob = p.ncob; r.ntaps = g.ntaps; r.K = g.K; r.Nn = g.Nn;
+  for (int t = 0; t < g.ntaps; ++t) r.tap_w[t] = g.tap_w[t];
+  const int64_t total = (int64_t)p.U * 16 * 16 * p.cot * p.nchunks * p.ncob;
+  int blocks = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+  hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, r);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}

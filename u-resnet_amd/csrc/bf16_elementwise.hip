@@ -1,0 +1,326 @@
+// HBM-bound kernels of the bf16 path: BatchNorm apply / join / backward, the softmax-CE head and the input / dtype
+// conversions.  Same arithmetic as elementwise.hip (fp32 per element, fp64 per-channel sums); tensors are bf16 with channel
+// counts that are multiples of 8, so a thread moves one 16-byte piece (8 channels of one voxel) per access.
+// Thread mapping: CP = next_pow2(C / 8) channel pieces per voxel, 256 / CP voxels per block iteration, a thread keeps its
+// channel piece for the whole kernel (per-channel parameters and sums live in registers).
+#include "bf16_common.h"
+
+namespace {
+
+int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+struct BMap { int shift, grid; };
+BMap make_bmap(int64_t V, int C) {
+  BMap m;
+  const int cp = next_pow2(C / 8);
+  m.shift = 0;
+  while ((1 << m.shift) < cp) ++m.shift;
+  const int vpb = 256 >> m.shift;
+  int64_t blocks = cdiv64(V, (int64_t)vpb * 8);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  m.grid = (int)blocks;
+  return m;
+}
+
+__device__ __forceinline__ u32x4 ld16(const bf16_t* p) { return __builtin_nontemporal_load((const u32x4*)p); }
+
+// NS sums x 8 channels per thread -> partial[block][NS][C] doubles
+template <int NS>
+__device__ inline void block_reduce_store8(double (&acc)[NS][8], int CP, int C, double* partial_blk) {
+  __shared__ double sm[NS * 8][257];
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sm[s * 8 + j][tid] = acc[s][j];
+  __syncthreads();
+  for (int st = 128; st >= CP; st >>= 1) {
+    if (tid < st) {
+#pragma unroll
+      for (int k = 0; k < NS * 8; ++k) sm[k][tid] += sm[k][tid + st];
+    }
+    __syncthreads();
+  }
+  if (tid < CP && tid * 8 < C) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) partial_blk[s * C + tid * 8 + j] = sm[s * 8 + j][tid];
+  }
+}
+
+// ---- BN apply / join ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bbn_act_kernel(BBnActArgs a, int shift) {
+  const int CP = 1 << shift, VPB = 256 >> shift;
+  const int c = (threadIdx.x & (CP - 1)) * 8, vr = threadIdx.x >> shift;
+  if (c >= a.C) return;
+  float sc[8], sh[8], sc2[8], sh2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = a.rstd[c + j];
+    sh[j] = a.beta[c + j] - a.mean[c + j] * sc[j];
+    sc2[j] = a.z2 ? a.rstd2[c + j] : 0.f;
+    sh2[j] = a.z2 ? a.beta2[c + j] - a.mean2[c + j] * sc2[j] : 0.f;
+  }
+  const int64_t stride = (int64_t)gridDim.x * VPB;
+  for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += 2 * stride) {
+    u32x4 x[2], x2[2], r[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t v = v0 + u * stride;
+      if (v < a.V) {
+        x[u] = ld16(a.z + v * a.zcs + c);
+        if (a.z2) x2[u] = ld16(a.z2 + v * a.z2cs + c);
+        if (a.res) r[u] = ld16(a.res + v * a.rescs + c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t v = v0 + u * stride;
+      if (v >= a.V) continue;
+      float f[8], f2[8], fr[8], y[8];
+      unpack8(x[u], f);
+      if (a.z2) unpack8(x2[u], f2);
+      if (a.res) unpack8(r[u], fr);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = fmaf(f[j], sc[j], sh[j]);
+        if (a.z2) t += fmaf(f2[j], sc2[j], sh2[j]);
+        if (a.res) t += fr[j];
+        if (a.relu) t = fmaxf(t, 0.f);
+        y[j] = t;
+      }
+      *(u32x4*)(a.y + v * a.ycs + c) = pack8(y);
+    }
+  }
+}
+
+// ---- BN backward ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bbn_bwd_reduce_kernel(BBnBwdArgs a, int shift, double* __restrict__ partial) {
+  const int CP = 1 << shift, VPB = 256 >> shift;
+  const int c = (threadIdx.x & (CP - 1)) * 8, vr = threadIdx.x >> shift;
+  double acc[3][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.0;
+  if (c < a.C) {
+    float mu[8], rs[8], mu2[8], rs2[8], be[8];
+    const bool ymask = a.relu && a.y != nullptr, zmask = a.relu && a.y == nullptr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mu[j] = a.mean[c + j]; rs[j] = a.rstd[c + j];
+      mu2[j] = a.z2 ? a.mean2[c + j] : 0.f; rs2[j] = a.z2 ? a.rstd2[c + j] : 0.f;
+      be[j] = zmask ? a.beta[c + j] - mu[j] * rs[j] : 0.f;
+    }
+    const int64_t stride = (int64_t)gridDim.x * VPB;
+    for (int64_t v = (int64_t)blockIdx.x * VPB + vr; v < a.V; v += stride) {
+      const u32x4 gp = ld16(a.dy + v * a.dycs + c), zp = ld16(a.z + v * a.zcs + c);
+      u32x4 yp, z2p;
+      if (ymask) yp = ld16(a.y + v * a.ycs + c);
+      if (a.z2) z2p = ld16(a.z2 + v * a.z2cs + c);
+      float g[8], z[8], y[8], z2[8];
+      unpack8(gp, g); unpack8(zp, z);
+      if (ymask) unpack8(yp, y);
+      if (a.z2) unpack8(z2p, z2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float gj = g[j];
+        if (ymask && !(y[j] > 0.f)) gj = 0.f;
+        if (zmask && !(fmaf(z[j], rs[j], be[j]) > 0.f)) gj = 0.f;
+        const double gd = (double)gj;
+        acc[0][j] += gd;
+        acc[1][j] += gd * (double)((z[j] - mu[j]) * rs[j]);
+        if (a.z2) acc[2][j] += gd * (double)((z2[j] - mu2[j]) * rs2[j]);
+      }
+    }
+  }
+  block_reduce_store8<3>(acc, CP, a.C, partial + (size_t)blockIdx.x * 3 * a.C);
+}
+
+__global__ __launch_bounds__(256) void bbn_bwd_apply_kernel(BBnBwdArgs a, int shift, const double* __restrict__ finals) {
+  const int CP = 1 << shift, VPB = 256 >> shift;
+  const int c = (threadIdx.x & (CP - 1)) * 8, vr = threadIdx.x >> shift;
+  if (c >= a.C) return;
+  float mu[8], rs[8], mu2[8], rs2[8], mg[8], mgx[8], mgx2[8], be[8];
+  const bool ymask = a.relu && a.y != nullptr, zmask = a.relu && a.y == nullptr;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu[j] = a.mean[c + j]; rs[j] = a.rstd[c + j];
+    be[j] = zmask ? a.beta[c + j] - mu[j] * rs[j] : 0.f;
+    mu2[j] = a.z2 ? a.mean2[c + j] : 0.f; rs2[j] = a.z2 ? a.rstd2[c + j] : 0.f;
+    mg[j] = (float)finals[c + j]; mgx[j] = (float)finals[a.C + c + j]; mgx2[j] = (float)finals[2 * a.C + c + j];
+  }
+  const int64_t stride = (int64_t)gridDim.x * VPB;
+  for (int64_t v = (int64_t)blockIdx.x * VPB + vr; v < a.V; v += stride) {
+    const u32x4 gp = ld16(a.dy + v * a.dycs + c), zp = ld16(a.z + v * a.zcs + c);
+    u32x4 yp, z2p, drp;
+    if (ymask) yp = ld16(a.y + v * a.ycs + c);
+    if (a.z2) z2p = ld16(a.z2 + v * a.z2cs + c);
+    if (a.dres && a.dres_accumulate) drp = ld16(a.dres + v * a.drescs + c);
+    float g[8], z[8], y[8], z2[8], dr[8], dz[8], dz2[8];
+    unpack8(gp, g); unpack8(zp, z);
+    if (ymask) unpack8(yp, y);
+    if (a.z2) unpack8(z2p, z2);
+    if (a.dres && a.dres_accumulate) unpack8(drp, dr);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float gj = g[j];
+      if (ymask && !(y[j] > 0.f)) gj = 0.f;
+      if (zmask && !(fmaf(z[j], rs[j], be[j]) > 0.f)) gj = 0.f;
+      dz[j] = rs[j] * (gj - mg[j] - (z[j] - mu[j]) * rs[j] * mgx[j]);
+      if (a.z2) dz2[j] = rs2[j] * (gj - mg[j] - (z2[j] - mu2[j]) * rs2[j] * mgx2[j]);
+      if (a.dres) dr[j] = a.dres_accumulate ? dr[j] + gj : gj;
+    }
+    *(u32x4*)(a.dz + v * a.dzcs + c) = pack8(dz);
+    if (a.z2) *(u32x4*)(a.dz2 + v * a.dz2cs + c) = pack8(dz2);
+    if (a.dres) *(u32x4*)(a.dres + v * a.drescs + c) = pack8(dr);
+  }
+}
+
+// ---- head (lib/ssnet.py:57-71): logits = bn(z), 8-channel bf16 pieces ----------------------------------------------------------
+__global__ __launch_bounds__(256) void bhead_kernel(BHeadArgs a, double* __restrict__ partial) {
+  const int64_t P = (int64_t)a.n * a.pix;
+  double loss = 0.0;
+  unsigned n_ok = 0, n_nz = 0, n_ok_nz = 0;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sc[k] = k < a.ncls ? a.rstd[k] : 0.f;
+    sh[k] = k < a.ncls ? a.beta[k] - a.mean[k] * sc[k] : 0.f;
+  }
+  const float invn = 1.0f / (float)a.n;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    float raw[8], z[8], e[8];
+    unpack8(ld16(a.z + p * a.z_cs), raw);
+    float m = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < a.ncls) {
+        z[k] = fmaf(raw[k], sc[k], sh[k]);
+        if (z[k] > m) { m = z[k]; arg = k; }   // strict '>' keeps the lowest index on ties
+      }
+    float ssum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < a.ncls) { e[k] = expf(z[k] - m); ssum += e[k]; }
+    const float inv = 1.0f / ssum;
+    if (a.softmax_out)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < a.ncls) a.softmax_out[p * a.ncls + k] = e[k] * inv;
+    if (a.ana_out) {   // lib/ssnet_trainval.py:285-287
+      const float shower = e[1] * inv, track = e[2] * inv;
+      const float lab = (shower > track ? 1.f : 0.f) + (track >= shower ? 2.f : 0.f);
+      a.ana_out[p] = (a.data && a.data[p * a.data_cs] > 1.0f) ? lab : 0.f;
+    }
+    if (a.label) {
+      const int lab = (int)a.label[p];
+      const bool lab_ok = lab >= 0 && lab < a.ncls;
+      const int labc = lab_ok ? lab : 0;
+      const float w = a.weight ? a.weight[p] : 1.0f;
+      float zl = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k == labc) zl = z[k];
+      const float ce = (m + logf(ssum)) - zl;
+      loss += lab_ok ? (double)(w * ce) : (double)NAN;
+      const bool okp = (arg == lab), nz = a.data ? (a.data[p * a.data_cs] > 0.f) : false;
+      n_ok += okp; n_nz += nz; n_ok_nz += (okp && nz);
+      if (a.dlogits) {
+        float d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = k < a.ncls ? w * invn * (e[k] * inv - (k == labc ? 1.f : 0.f)) : 0.f;
+        *(u32x4*)(a.dlogits + p * a.dl_cs) = pack8(d);
+      }
+    }
+  }
+  __shared__ double sm[4][256];
+  sm[0][threadIdx.x] = loss; sm[1][threadIdx.x] = (double)n_ok; sm[2][threadIdx.x] = (double)n_nz; sm[3][threadIdx.x] = (double)n_ok_nz;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (threadIdx.x < st)
+      for (int k = 0; k < 4; ++k) sm[k][threadIdx.x] += sm[k][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] = sm[threadIdx.x][0];
+}
+
+__global__ void bf16_input_kernel(const float* __restrict__ data, bf16_t* __restrict__ out, int64_t V) {
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += (int64_t)gridDim.x * blockDim.x) {
+    u32x4 p = {(unsigned)f2bf(data[v]), 0u, 0u, 0u};
+    *(u32x4*)(out + v * 8) = p;
+  }
+}
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = f2bf(src[i]);
+}
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = bf2f(src[i]);
+}
+
+bool piece_ok(int C, std::initializer_list<int> strides, std::initializer_list<const void*> ptrs) {
+  if (C % 8 || C / 8 > 256) return false;
+  for (int s : strides) if (s % 8) return false;
+  for (const void* p : ptrs) if (p && (((uintptr_t)p) & 15)) return false;
+  return true;
+}
+
+}  // namespace
+
+size_t bbn_scratch_bytes(int64_t V, int C) {
+  return ((size_t)make_bmap(V, C).grid * 3 * C + (size_t)3 * C) * sizeof(double) + 256;
+}
+
+int launch_bbn_act(const BBnActArgs& a, hipStream_t s) {
+  URSN_REQUIRE(piece_ok(a.C, {a.zcs, a.ycs, a.z2 ? a.z2cs : 0, a.res ? a.rescs : 0}, {a.z, a.y, a.z2, a.res}),
+               "bf16 bn_act: channels / strides must be multiples of 8 and pointers 16-byte aligned (C = %d)", a.C);
+  const BMap m = make_bmap(a.V, a.C);
+  hipLaunchKernelGGL(bbn_act_kernel, dim3(m.grid), dim3(256), 0, s, a, m.shift);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_bbn_bwd(const BBnBwdArgs& a, hipStream_t s) {
+  URSN_REQUIRE(!a.relu || a.y || a.beta, "bf16 bn_bwd: relu mask needs y or beta");
+  URSN_REQUIRE(piece_ok(a.C, {a.dycs, (a.relu && a.y) ? a.ycs : 0, a.zcs, a.dzcs, a.z2 ? a.z2cs : 0, a.z2 ? a.dz2cs : 0, a.dres ? a.drescs : 0},
+                        {a.dy, a.relu ? a.y : nullptr, a.z, a.dz, a.z2, a.dz2, a.dres}),
+               "bf16 bn_bwd: channels / strides must be multiples of 8 and pointers 16-byte aligned (C = %d)", a.C);
+  const BMap m = make_bmap(a.V, a.C);
+  double* partial = (double*)a.scratch;
+  double* finals = partial + (size_t)m.grid * 3 * a.C;
+  hipLaunchKernelGGL(bbn_bwd_reduce_kernel, dim3(m.grid), dim3(256), 0, s, a, m.shift, partial);
+  URSN_HIP(hipGetLastError());
+  URSN_TRY(launch_bn_bwd_final(partial, m.grid, a.C, a.V, finals, a.dbeta, a.z2 ? a.dbeta2 : nullptr, a.Cw > 0 ? a.Cw : a.C, s));
+  hipLaunchKernelGGL(bbn_bwd_apply_kernel, dim3(m.grid), dim3(256), 0, s, a, m.shift, (const double*)finals);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_bhead(const BHeadArgs& a, hipStream_t s) {
+  URSN_REQUIRE(a.ncls >= 1 && a.ncls <= 8 && a.z_cs == 8 && (!a.dlogits || a.dl_cs == 8), "bf16 head: needs <= 8 classes in 8-channel pieces");
+  const int nb = head_blocks(a.n, a.pix);
+  double* partial = (double*)a.scratch;
+  hipLaunchKernelGGL(bhead_kernel, dim3(nb), dim3(256), 0, s, a, partial);
+  URSN_HIP(hipGetLastError());
+  return launch_head_final(partial, nb, a.n, a.pix, a.metrics, s);
+}
+
+static int ew_blocks(int64_t n) { int64_t b = cdiv64(n, 256); return (int)(b < 4096 ? (b < 1 ? 1 : b) : 4096); }
+int launch_bf16_input(const float* data, bf16_t* out, int64_t V, hipStream_t s) {
+  hipLaunchKernelGGL(bf16_input_kernel, dim3(ew_blocks(V)), dim3(256), 0, s, data, out, V);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+int launch_f32_to_bf16(const float* src, bf16_t* dst, int64_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, src, dst, n);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+int launch_bf16_to_f32(const bf16_t* src, float* dst, int64_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, src, dst, n);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}

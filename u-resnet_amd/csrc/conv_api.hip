@@ -3,7 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "ursn_common.h"
+#include "bf16_common.h"
 
 static thread_local char g_err[1024] = "";
 void ursn_set_error(const char* fmt, ...) {
@@ -279,8 +279,53 @@ int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const
   return run_gather(d, pass, in, w, out, accumulate, s);
 }
 
+// ---- bf16 tensors at op level (desc.dtype == 1): the two kernels of bf16_conv.hip, one launch per output-parity class.
+// The packed-weight scratch of these test entry points is a small library-owned device buffer (net-level calls pack into
+// the caller's workspace instead).
+static bf16_t* op_wpack(size_t elems) {
+  static bf16_t* buf = nullptr;
+  static size_t cap = 0;
+  if (elems > cap) {
+    if (buf) (void)hipFree(buf);
+    buf = nullptr; cap = 0;
+    if (hipMalloc((void**)&buf, elems * sizeof(bf16_t)) != hipSuccess) return nullptr;
+    cap = elems;
+  }
+  return buf;
+}
+static int bf16_conv_op(const ursn_conv_desc& d, ConvPass pass, const void* in, const float* w, void* out, int accumulate,
+                        double* stats_partial, size_t stats_bytes, float eps, float* mean, float* rstd, hipStream_t s) {
+  URSN_REQUIRE(!d.in_split && !d.pw_dy && !d.in_mean, "bf16 conv: split inputs / fused shortcut term / normalise-on-load are fp32-only");
+  GatherGeom g[8];
+  const int n = build_geoms(d, pass, g);
+  URSN_REQUIRE(n >= 1, "bf16 conv: bad descriptor");
+  int64_t V = (int64_t)d.n;
+  for (int j = 0; j < 3; ++j) V *= g[0].out_d[j];
+  URSN_REQUIRE(!stats_partial || n == 1 || pass == PASS_FWD, "bf16 conv: statistics only on forward passes");
+  bool empty = false;
+  for (int i = 0; i < n; ++i) empty = empty || g[i].ntaps == 0;
+  if (empty && !accumulate) {   // 1x1 stride-2 data gradient: the voxels no output reads get a zero gradient
+    URSN_REQUIRE(g[0].out_cs == g[0].Nn, "bf16 conv: overwrite with empty parity classes needs a compact output tensor");
+    int64_t e = (int64_t)d.n * g[0].Nn;
+    for (int j = 0; j < 3; ++j) e *= g[0].out_d[j];
+    URSN_HIP(hipMemsetAsync(out, 0, (size_t)e * sizeof(bf16_t), s));
+  }
+  for (int i = 0; i < n; ++i) {
+    g[i].accumulate = accumulate;
+    if (g[i].ntaps == 0) continue;
+    bf16_t* wp = op_wpack(bconv_pack_elems(g[i]));
+    URSN_REQUIRE(wp, "bf16 conv: unsupported geometry or no memory for the packed weights");
+    // transposed forward: each parity class writes its own voxels; statistics partials are summed over the classes below
+    URSN_REQUIRE(!stats_partial || bconv_stats_scratch_doubles(g[i]) * sizeof(double) * n <= stats_bytes, "bf16 conv: statistics scratch too small");
+    URSN_TRY(launch_bconv(g[i], (const bf16_t*)in, w, wp, (bf16_t*)out, (stats_partial && n == 1) ? stats_partial : nullptr, eps, mean,
+                          rstd, V, s));
+  }
+  return 0;
+}
+
 extern "C" int ursn_conv_forward(const ursn_conv_desc* d, const float* x, const float* w, float* y, void* stream) {
   URSN_REQUIRE(d && x && w && y, "conv_forward: null argument");
+  if (d->dtype == 1) return bf16_conv_op(*d, PASS_FWD, x, w, y, 0, nullptr, 0, 0.f, nullptr, nullptr, (hipStream_t)stream);
   return conv_dispatch(*d, PASS_FWD, x, w, y, 0, (hipStream_t)stream);
 }
 
@@ -290,6 +335,10 @@ extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, 
                                        float* rstd, float eps, void* scratch, size_t scratch_bytes, void* stream) {
   URSN_REQUIRE(d && x && w && y && mean && rstd && scratch, "conv_forward_stats: null argument");
   hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == 1) {
+    URSN_REQUIRE(!d->transposed, "conv_forward_stats: bf16 transposed convs take their statistics at net level");
+    return bf16_conv_op(*d, PASS_FWD, x, w, y, 0, (double*)scratch, scratch_bytes, eps, mean, rstd, s);
+  }
   GatherGeom g[8];
   URSN_REQUIRE(build_geoms(*d, PASS_FWD, g) >= 1, "conv_forward_stats: bad descriptor");
   int64_t V = (int64_t)d->n;
@@ -339,6 +388,7 @@ extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, 
 extern "C" int ursn_conv_backward_data(const ursn_conv_desc* d, const float* dy, const float* w, float* dx,
                                        int32_t accumulate, void* stream) {
   URSN_REQUIRE(d && dy && w && dx, "conv_backward_data: null argument");
+  if (d->dtype == 1) return bf16_conv_op(*d, PASS_DGRAD, dy, w, dx, accumulate, nullptr, 0, 0.f, nullptr, nullptr, (hipStream_t)stream);
   return conv_dispatch(*d, PASS_DGRAD, dy, w, dx, accumulate, (hipStream_t)stream);
 }
 
@@ -351,6 +401,7 @@ extern "C" size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d) {
   if (!d) return 0;
   GatherGeom g[8];
   if (build_geoms(*d, PASS_WGRAD, g) != 1) return 0;
+  if (d->dtype == 1) return bwgrad_scratch_bytes(g[0]) + 256;
   size_t a = wgrad_plan(g[0]).scratch_bytes;
   size_t b = tiled_wgrad_supported(*d) ? tiled_wgrad_scratch_bytes(*d) : 0;
   size_t c = igemm_wgrad_scratch_bytes(*d);
@@ -397,6 +448,13 @@ int wgrad_dispatch(const ursn_conv_desc& d, const float* x, const float* dy, flo
 extern "C" int ursn_conv_backward_weight(const ursn_conv_desc* d, const float* x, const float* dy, float* dw,
                                          void* scratch, size_t scratch_bytes, void* stream) {
   URSN_REQUIRE(d && x && dy && dw, "conv_backward_weight: null argument");
+  if (d->dtype == 1) {
+    GatherGeom g[8];
+    URSN_REQUIRE(build_geoms(*d, PASS_WGRAD, g) == 1, "conv_backward_weight: bad descriptor");
+    const void* S = d->transposed ? (const void*)dy : (const void*)x;
+    const void* Cq = d->transposed ? (const void*)x : (const void*)dy;
+    return launch_bwgrad(g[0], (const bf16_t*)S, (const bf16_t*)Cq, dw, scratch, scratch_bytes, (hipStream_t)stream);
+  }
   return wgrad_dispatch(*d, x, dy, dw, scratch, scratch_bytes, (hipStream_t)stream);
 }
 

@@ -456,6 +456,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int shif
   }
 }
 
+int launch_bn_bwd_final(const double* partial, int nblocks, int C, int64_t V, double* finals, float* dbeta, float* dbeta2,
+                        int Cw, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, partial, nblocks, C, V, finals, dbeta, dbeta2, Cw);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
   URSN_REQUIRE(!a.relu || a.y || a.beta || a.mask, "bn_bwd: relu mask needs y, beta or the bit mask");
   bool v4 = vec4_ok(a.C, {a.dycs, (a.relu && a.y && !a.mask) ? a.ycs : 0, a.zcs, a.dzcs, a.z2 ? a.z2cs : 0, a.z2 ? a.dz2cs : 0,
@@ -595,7 +602,13 @@ __global__ __launch_bounds__(256) void head_final_kernel(const double* __restric
   metrics[3] = (float)sm[2][0];
 }
 
-static int head_blocks(int n, int64_t pix) {
+int launch_head_final(const double* partial, int nblocks, int n, int64_t pix, float* metrics, hipStream_t s) {
+  hipLaunchKernelGGL(head_final_kernel, dim3(1), dim3(256), 0, s, partial, nblocks, n, pix, metrics);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+int head_blocks(int n, int64_t pix) {
   static const int cap = getenv("URSN_HEAD_GRID") ? atoi(getenv("URSN_HEAD_GRID")) : 4096;
   int64_t b = cdiv64((int64_t)n * pix, 256 * 4);
   if (b > cap) b = cap;

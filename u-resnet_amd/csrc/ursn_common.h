@@ -240,6 +240,11 @@ struct HeadArgs {
   void* scratch;
 };
 size_t head_scratch_bytes(int n, int64_t pix);
+int head_blocks(int n, int64_t pix);
+int launch_head_final(const double* partial, int nblocks, int n, int64_t pix, float* metrics, hipStream_t s);
+// finals [3][C] = mean(g), mean(g xhat), mean(g xhat2) from [nblocks][3][C] partials; dbeta(2)[c < Cw] += sum g
+int launch_bn_bwd_final(const double* partial, int nblocks, int C, int64_t V, double* finals, float* dbeta, float* dbeta2,
+                        int Cw, hipStream_t s);
 int launch_head(const HeadArgs& a, hipStream_t s);
 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
