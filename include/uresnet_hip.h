@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define URSN_ABI_VERSION 3
+#define URSN_ABI_VERSION 4
 
 typedef struct ursn_net ursn_net; /* opaque */
 
@@ -43,6 +43,11 @@ typedef struct ursn_config {
   int32_t trainable;     /* construct(trainable=...): allocate the backward workspace             */
   int32_t use_weight;    /* construct(use_weight=...), lib/ssnet.py:68-69                         */
   float bn_eps;          /* slim.batch_norm epsilon (default 1e-3)                                */
+  int32_t act_dtype;     /* 0: fp32 everywhere (the reference's precision).  1: bf16 mixed precision
+                          * (BASELINE.json configs[4]): activations, raw conv outputs and gradient tensors
+                          * live in HBM as bf16, convolutions run on bf16 MFMA with fp32 accumulation;
+                          * parameters, BatchNorm statistics, accumulated gradients and Adam stay fp32.
+                          * Needs cin == 1 and base_filters % 8 == 0.                               */
 } ursn_config;
 
 typedef struct ursn_sizes {

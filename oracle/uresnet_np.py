@@ -19,6 +19,26 @@ import numpy as np
 
 BN_EPS = 1e-3  # slim.batch_norm default epsilon
 
+# Mixed-precision leg (BASELINE.json configs[4]): QUANT, when set, is applied to every tensor the bf16 plan of the
+# product stores in HBM as bf16 -- the input data, the weights as the conv kernels read them, every raw conv output z,
+# every MATERIALISED activation (conv0 / deconv / conv1 / resnet_conv1 outputs and the residual-unit outputs; the two
+# BatchNorm'd branches of a join are summed in fp32 and rounded once), the logits gradient, every BatchNorm input gradient
+# dz and every activation gradient.  Arithmetic between those points stays in the oracle's dtype (fp64), standing in for
+# the product's fp32 accumulation.  QUANT = None (default): the reference's fp32/fp64 semantics, unchanged.
+QUANT = None
+
+
+def bf16_round(a):
+    """Round-to-nearest-even to bfloat16 (8 significant bits), returned in the input dtype."""
+    a32 = np.ascontiguousarray(a, dtype=np.float32)
+    u = a32.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return (r.astype(np.uint32)).view(np.float32).reshape(a32.shape).astype(np.asarray(a).dtype)
+
+
+def _q(a):
+    return a if QUANT is None else QUANT(a)
+
 
 # ----------------------------------------------------------------------------
 # Topology: lib/uresnet.py:22-123, lib/resnet_module.py:10-87
@@ -192,12 +212,14 @@ class _Tape:
         self.acts = OrderedDict() if keep_acts else None
 
 
-def _cbn(P, tape, name, x, kind="conv", stride=1, relu=False, eps=BN_EPS):
-    w = P[name + "/weights"]
-    z = conv_fwd(x, w, stride) if kind == "conv" else deconv_fwd(x, w)
+def _cbn(P, tape, name, x, kind="conv", stride=1, relu=False, eps=BN_EPS, store=True):
+    w = _q(P[name + "/weights"])
+    z = _q(conv_fwd(x, w, stride) if kind == "conv" else deconv_fwd(x, w))
     y, bc = bn_fwd(z, P[name + "/BatchNorm/beta"], eps)
     if relu:
         y = np.maximum(y, 0.0)
+    if store:   # the activation exists as a tensor of its own (not only inside a residual join)
+        y = _q(y)
     tape.c[name] = (x, bc, y if relu else None, kind, stride)
     if tape.acts is not None:
         tape.acts[name + ":z"] = z
@@ -210,8 +232,10 @@ def _cbn_bwd(P, tape, G, name, dy):
     if yrelu is not None:
         dy = dy * (yrelu > 0)
     dz, dbeta = bn_bwd(bc, dy)
-    w = P[name + "/weights"]
+    dz = _q(dz)
+    w = _q(P[name + "/weights"])
     dx, dw = conv_bwd(x, w, stride, dz) if kind == "conv" else deconv_bwd(x, w, dz)
+    dx = _q(dx)
     G[name + "/weights"] = dw
     G[name + "/BatchNorm/beta"] = dbeta
     return dx
@@ -222,10 +246,10 @@ def _unit(P, tape, scope, x, cout, stride, eps):  # lib/resnet_module.py:10-68
     if cin == cout and stride == 1:
         sc = x
     else:
-        sc = _cbn(P, tape, scope + "/shortcut", x, stride=stride, eps=eps)
+        sc = _cbn(P, tape, scope + "/shortcut", x, stride=stride, eps=eps, store=False)
     r = _cbn(P, tape, scope + "/resnet_conv1", x, stride=stride, eps=eps)
-    r = _cbn(P, tape, scope + "/resnet_conv2", r, eps=eps)
-    out = np.maximum(sc + r, 0.0)
+    r = _cbn(P, tape, scope + "/resnet_conv2", r, eps=eps, store=False)
+    out = _q(np.maximum(sc + r, 0.0))
     tape.c[scope] = (out, cin == cout and stride == 1)
     if tape.acts is not None:
         tape.acts[scope] = out
@@ -238,9 +262,9 @@ def _unit_bwd(P, tape, G, scope, dout):
     d1 = _cbn_bwd(P, tape, G, scope + "/resnet_conv2", g)
     dx = _cbn_bwd(P, tape, G, scope + "/resnet_conv1", d1)
     if ident:
-        dx = dx + g
+        dx = _q(dx + g)
     else:
-        dx = dx + _cbn_bwd(P, tape, G, scope + "/shortcut", g)
+        dx = _q(dx + _cbn_bwd(P, tape, G, scope + "/shortcut", g))
     return dx
 
 
@@ -264,7 +288,7 @@ def forward(P, data, base, num_strides=5, eps=BN_EPS, keep_acts=False):
         net = _unit(P, tape, s + "/module1", net, co, 1, eps)
         net = _unit(P, tape, s + "/module2", net, co, 1, eps)
     net = _cbn(P, tape, U + "conv1", net, relu=True, eps=eps)
-    net = _cbn(P, tape, U + "conv2", net, relu=False, eps=eps)
+    net = _cbn(P, tape, U + "conv2", net, relu=False, eps=eps, store=False)   # the logits only exist inside the head
     tape.num_strides = num_strides
     return net, tape
 
@@ -288,11 +312,11 @@ def backward(P, tape, dlogits):
         s = U + "resnet_module%d" % step
         co = tape.c[s + "/module2"][0].shape[-1]
         if co in dskip:
-            d = d + dskip.pop(co)
+            d = _q(d + dskip.pop(co))
         d = _unit_bwd(P, tape, G, s + "/module2", d)
         d = _unit_bwd(P, tape, G, s + "/module1", d)
     base = d.shape[-1]
-    d = d + dskip.pop(base)
+    d = _q(d + dskip.pop(base))
     d = _cbn_bwd(P, tape, G, U + "conv0", d)
     grads = OrderedDict((k, G[k]) for k in P.keys())
     return grads, d
@@ -353,9 +377,9 @@ def step_gradients(P, dims, base, data, label, weight=None, eps=BN_EPS, keep_act
     dt = next(iter(P.values())).dtype
     d, l, w = reshape_inputs(dims, data, label, weight)
     d = d.astype(dt)
-    logits, tape = forward(P, d, base, num_strides=num_strides, eps=eps, keep_acts=keep_acts)
+    logits, tape = forward(P, _q(d), base, num_strides=num_strides, eps=eps, keep_acts=keep_acts)
     m = loss_and_metrics(logits, d, l, w)
-    grads, _ = backward(P, tape, m["dlogits"])
+    grads, _ = backward(P, tape, _q(m["dlogits"]))
     m["logits"] = logits
     if keep_acts:
         m["acts"] = tape.acts

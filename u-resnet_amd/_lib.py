@@ -10,7 +10,7 @@ class ursn_config(C.Structure):
     _fields_ = [("ndim", C.c_int32), ("spatial", C.c_int32 * 3), ("cin", C.c_int32),
                 ("base_filters", C.c_int32), ("num_class", C.c_int32), ("num_strides", C.c_int32),
                 ("max_batch", C.c_int32), ("trainable", C.c_int32), ("use_weight", C.c_int32),
-                ("bn_eps", C.c_float)]
+                ("bn_eps", C.c_float), ("act_dtype", C.c_int32)]
 
 
 class ursn_sizes(C.Structure):
@@ -86,7 +86,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS.keys())
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

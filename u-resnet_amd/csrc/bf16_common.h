@@ -41,15 +41,21 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
 // packed-weight elements (bf16) one geometry needs; the pack kernel re-orders the fp32 master weights into MFMA A-operand
 // order [co block][ci chunk][k step][co tile][lane][8]
 size_t bconv_pack_elems(const GatherGeom& g);
-// out[n, q*so+po, :] (=|+=) sum_t in[n, q*si+d_t, :] . W_t ; stats_partial != nullptr: BatchNorm moment partials of the
-// produced tensor (forward only), finalised into mean / rstd.  wpack: scratch of bconv_pack_elems(g) bf16.
-int launch_bconv(const GatherGeom& g, const bf16_t* in, const float* w, bf16_t* wpack, bf16_t* out, double* stats_partial,
-                 float eps, float* mean, float* rstd, int64_t stats_V, hipStream_t s);
-size_t bconv_stats_scratch_doubles(const GatherGeom& g);
-// dW[t][m][n] += sum_q S[q*si+d_t][m] * C[q][n]   (fp32 accumulation, fp32 dW)
+// out[n, q*so+po, :] (=|+=) sum_t in[n, q*si+d_t, :] . W_t.  Kw / Nw (0 = g.K / g.Nn): extents of the stored weight tensor when
+// the kernel-view channel counts are padded (conv0's single input channel, the 3|5-class logits layer); the weight strides in
+// g describe the STORED tensor.  wpack: scratch of bconv_pack_elems(g) bf16.
+// stats_partial != nullptr (forward): BatchNorm moment partials of the produced tensor, block stats_off + i of stats_total
+// (a transposed conv runs one launch per output-parity class into one partial array); finalise with bconv_stats_finalize.
+int launch_bconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
+                 double* stats_partial, int stats_off, int stats_total, hipStream_t s);
+int bconv_grid_blocks(const GatherGeom& g);
+size_t bconv_stats_scratch_doubles(const GatherGeom& g);   // for ONE launch; x classes for a transposed conv
+int bconv_stats_finalize(const GatherGeom& g, const double* partial, int total_blocks, int64_t V, float eps, float* mean,
+                         float* rstd, hipStream_t s);
+// dW[t][m][n] += sum_q S[q*si+d_t][m] * C[q][n]   (fp32 accumulation, fp32 dW [t][Kw][Nw])
 size_t bwgrad_scratch_bytes(const GatherGeom& g);
-int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, void* scratch, size_t scratch_bytes,
-                  hipStream_t s);
+int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,
+                  size_t scratch_bytes, hipStream_t s);
 
 // ---- elementwise (bf16_elementwise.hip) ----------------------------------------------------------------------------------
 struct BBnActArgs {   // y = act(bn(z) [+ bn(z2) | + res]); all tensors bf16, channel counts multiples of 8

@@ -26,7 +26,8 @@ struct BConvArgs {
   const bf16_t* in;
   const bf16_t* wp;
   bf16_t* out;
-  double* stats_partial;   // [grid.y][grid.x][2][cob] or null
+  double* stats_partial;   // [grid.y][stats_total][2][cob] or null; this launch writes blocks stats_off + blockIdx.x
+  int stats_off, stats_total;
   int N;
   int in_d[3], out_d[3], q_d[3], so[3], po[3], si[3];
   int Cin, Cout, in_cs, out_cs, accumulate;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void bconv_kernel(BConvArgs a) {
       }
     __syncthreads();
     if (tid < 2 * 16 * COT)
-      a.stats_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * 16 * COT + tid] =
+      a.stats_partial[((size_t)blockIdx.y * a.stats_total + a.stats_off + blockIdx.x) * 2 * 16 * COT + tid] =
           (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   }
 }
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void bconv_kernel(BConvArgs a) {
 struct BPackArgs {
   const float* w;
   bf16_t* wp;
-  int ntaps, K, Nn, w_tap_stride, w_sk, w_sn;
+  int ntaps, K, Nn, w_tap_stride, w_sk, w_sn;   // K, Nn: extents of the STORED weight tensor (rows / columns beyond are 0)
   int tap_w[URSN_MAX_TAPS];
   int cinc, nchunks, nj, cot, ncob;
 };
@@ -271,13 +272,31 @@ static int bconv_launch(const BPlan& p, const BConvArgs& a, hipStream_t s) {
   return 0;
 }
 
-int launch_bconv(const GatherGeom& g, const bf16_t* in, const float* w, bf16_t* wpack, bf16_t* out, double* stats_partial,
-                 float eps, float* mean, float* rstd, int64_t stats_V, hipStream_t s) {
+int bconv_grid_blocks(const GatherGeom& g) {
+  BPlan p;
+  return bconv_plan(g, p) ? p.gridx : 0;
+}
+
+int bconv_stats_finalize(const GatherGeom& g, const double* partial, int total_blocks, int64_t V, float eps, float* mean,
+                         float* rstd, hipStream_t s) {
+  BPlan p;
+  URSN_REQUIRE(bconv_plan(g, p), "bf16 conv: unsupported geometry");
+  for (int cb = 0; cb < p.ncob; ++cb) {
+    const int c0 = cb * 16 * p.cot;
+    const int cn = g.Nn - c0 < 16 * p.cot ? g.Nn - c0 : 16 * p.cot;
+    URSN_TRY(launch_bn_stats_final(partial + (size_t)cb * total_blocks * 2 * 16 * p.cot, total_blocks, cn, 16 * p.cot, V, eps,
+                                   mean + c0, rstd + c0, s));
+  }
+  return 0;
+}
+
+int launch_bconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
+                 double* stats_partial, int stats_off, int stats_total, hipStream_t s) {
   BPlan p;
   URSN_REQUIRE(bconv_plan(g, p), "bf16 conv: unsupported geometry (channels %d -> %d, strides %d / %d)", g.K, g.Nn, g.in_cs, g.out_cs);
   {
     BPackArgs k;
-    k.w = w; k.wp = wpack; k.ntaps = g.ntaps; k.K = g.K; k.Nn = g.Nn;
+    k.w = w; k.wp = wpack; k.ntaps = g.ntaps; k.K = Kw > 0 ? Kw : g.K; k.Nn = Nw > 0 ? Nw : g.Nn;
     k.w_tap_stride = g.w_tap_stride; k.w_sk = g.w_sk; k.w_sn = g.w_sn;
     for (int t = 0; t < g.ntaps; ++t) k.tap_w[t] = g.tap_w[t];
     k.cinc = p.cinc; k.nchunks = p.nchunks; k.nj = p.nj; k.cot = p.cot; k.ncob = p.ncob;
@@ -288,6 +307,7 @@ int launch_bconv(const GatherGeom& g, const bf16_t* in, const float* w, bf16_t* 
   }
   BConvArgs a;
   a.in = in; a.wp = wpack; a.out = out; a.stats_partial = stats_partial;
+  a.stats_off = stats_off; a.stats_total = stats_total > 0 ? stats_total : p.gridx;
   a.N = g.N;
   for (int j = 0; j < 3; ++j) {
     a.in_d[j] = g.in_d[j]; a.out_d[j] = g.out_d[j]; a.q_d[j] = g.q_d[j]; a.so[j] = g.so[j]; a.po[j] = g.po[j]; a.si[j] = g.si[j];
@@ -307,16 +327,7 @@ int launch_bconv(const GatherGeom& g, const bf16_t* in, const float* w, bf16_t* 
 #define BC(vt_, cot_) if (p.vt == vt_ && p.cot == cot_) rc = bconv_launch<vt_, cot_>(p, a, s);
   BC(8, 1) BC(8, 2) BC(4, 1) BC(4, 2) BC(2, 1) BC(2, 2) BC(1, 1) BC(1, 2)
 #undef BC
-  if (rc) return rc;
-  if (stats_partial) {
-    for (int cb = 0; cb < p.ncob; ++cb) {
-      const int c0 = cb * 16 * p.cot;
-      const int cn = g.Nn - c0 < 16 * p.cot ? g.Nn - c0 : 16 * p.cot;
-      URSN_TRY(launch_bn_stats_final(stats_partial + (size_t)cb * p.gridx * 2 * 16 * p.cot, p.gridx, cn, 16 * p.cot, stats_V, eps,
-                                     mean + c0, rstd + c0, s));
-    }
-  }
-  return 0;
+  return rc;
 }
 
 // =========================================================================================================================
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(256) void bwgrad_kernel(BWgradArgs a) {
 // dw[tap_w[t]][ci][co] += sum over workgroup slabs (fixed order); one thread per (pair, row, column)
 struct BWReduceArgs {
   const float* slab; float* dw;
-  int nslabs, U, ccn, cinc, nchunks, ncob, ntaps, K, Nn;
+  int nslabs, U, ccn, cinc, nchunks, ncob, ntaps, K, Nn;   // K, Nn: extents of the STORED gradient tensor [t][K][Nn]
   int tap_w[URSN_MAX_TAPS];
 };
 __global__ __launch_bounds__(256) void bwgrad_reduce_kernel(BWReduceArgs a) {
@@ -544,8 +555,8 @@ static int bwgrad_launch(const BWPlan& p, const BWgradArgs& a, hipStream_t s) {
   return 0;
 }
 
-int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, void* scratch, size_t scratch_bytes,
-                  hipStream_t s) {
+int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,
+                  size_t scratch_bytes, hipStream_t s) {
   BWPlan p;
   URSN_REQUIRE(bwgrad_plan(g, p), "bf16 wgrad: unsupported geometry (channels %d x %d)", g.K, g.Nn);
   URSN_REQUIRE(scratch && scratch_bytes >= bwgrad_scratch_bytes(g), "bf16 wgrad: scratch too small");
@@ -572,7 +583,7 @@ int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* 
   if (rc) return rc;
   BWReduceArgs r;
   r.slab = (const float*)scratch; r.dw = dw; r.nslabs = p.gridx; r.U = p.U; r.ccn = 16 * p.cot; r.cinc = p.cinc;
-  r.nchunks = p.nchunks; r.ncob = p.ncob; r.ntaps = g.ntaps; r.K = g.K; r.Nn = g.Nn;
+  r.nchunks = p.nchunks; r.ncob = p.ncob; r.ntaps = g.ntaps; r.K = Kw > 0 ? Kw : g.K; r.Nn = Nw > 0 ? Nw : g.Nn;
   for (int t = 0; t < g.ntaps; ++t) r.tap_w[t] = g.tap_w[t];
   const int64_t total = (int64_t)p.U * 16 * 16 * p.cot * p.nchunks * p.ncob;
   int blocks = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);

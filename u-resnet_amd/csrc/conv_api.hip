@@ -317,8 +317,8 @@ static int bf16_conv_op(const ursn_conv_desc& d, ConvPass pass, const void* in, 
     URSN_REQUIRE(wp, "bf16 conv: unsupported geometry or no memory for the packed weights");
     // transposed forward: each parity class writes its own voxels; statistics partials are summed over the classes below
     URSN_REQUIRE(!stats_partial || bconv_stats_scratch_doubles(g[i]) * sizeof(double) * n <= stats_bytes, "bf16 conv: statistics scratch too small");
-    URSN_TRY(launch_bconv(g[i], (const bf16_t*)in, w, wp, (bf16_t*)out, (stats_partial && n == 1) ? stats_partial : nullptr, eps, mean,
-                          rstd, V, s));
+    URSN_TRY(launch_bconv(g[i], (const bf16_t*)in, w, 0, 0, wp, (bf16_t*)out, (stats_partial && n == 1) ? stats_partial : nullptr, 0, 0, s));
+    if (stats_partial && n == 1) URSN_TRY(bconv_stats_finalize(g[i], stats_partial, bconv_grid_blocks(g[i]), V, eps, mean, rstd, s));
   }
   return 0;
 }
@@ -453,7 +453,7 @@ extern "C" int ursn_conv_backward_weight(const ursn_conv_desc* d, const float* x
     URSN_REQUIRE(build_geoms(*d, PASS_WGRAD, g) == 1, "conv_backward_weight: bad descriptor");
     const void* S = d->transposed ? (const void*)dy : (const void*)x;
     const void* Cq = d->transposed ? (const void*)x : (const void*)dy;
-    return launch_bwgrad(g[0], (const bf16_t*)S, (const bf16_t*)Cq, dw, scratch, scratch_bytes, (hipStream_t)stream);
+    return launch_bwgrad(g[0], (const bf16_t*)S, (const bf16_t*)Cq, dw, 0, 0, scratch, scratch_bytes, (hipStream_t)stream);
   }
   return wgrad_dispatch(*d, x, dy, dw, scratch, scratch_bytes, (hipStream_t)stream);
 }

@@ -150,7 +150,10 @@ int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass) {
   TPlan p;
   Blocking b;
   if (!make_plan(d, pass, p, b)) return 0;
-  if (d.pw_dy && !(pass == PASS_DGRAD && p.cin <= 16)) return 0;
+  // fused shortcut term: the kernel contracts ALL channels of the shortcut gradient in one pass (<= 16), so the
+  // contraction side must not be split into channel blocks (found with URSN_IGEMM=0: 32 -> 16 ran as two blocks and
+  // dropped half of the term)
+  if (d.pw_dy && !(pass == PASS_DGRAD && p.cin <= 16 && b.nbi == 1)) return 0;
   if (d.in_mean && pass == PASS_FWD && (b.nbi > 1 || b.nbo > 1 || p.cin != p.cout || !(p.cin == 8 || p.cin == 16))) return 0;   // normalise-on-load: 8->8 / 16->16
   return 1;
 }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "ursn_common.h"
+#include "net_bf16.h"
 
 int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out, int accumulate,
                   hipStream_t s);
@@ -63,6 +64,7 @@ struct Unit {
 }  // namespace
 
 struct ursn_net {
+  ursn_bnet* bf = nullptr;   // act_dtype == 1: the bf16 mixed-precision plan (net_bf16.hip) executes the fetch-sets
   ursn_config cfg;
   ursn_sizes sizes;
   int nlev = 0;
@@ -745,6 +747,8 @@ int check_call(ursn_net* n, const float* data, int N) {
 // ---- C-ABI ----------------------------------------------------------------------------------
 extern "C" int ursn_query(const ursn_config* cfg, ursn_sizes* out) {
   URSN_REQUIRE(cfg && out, "query: null argument");
+  URSN_REQUIRE(cfg->act_dtype == 0 || cfg->act_dtype == 1, "query: act_dtype %d not in {0 fp32, 1 bf16}", cfg->act_dtype);
+  if (cfg->act_dtype == 1) return bnet_query(cfg, out);
   ursn_net tmp;
   tmp.cfg = *cfg;
   if (tmp.cfg.bn_eps <= 0.f) tmp.cfg.bn_eps = 1e-3f;
@@ -758,6 +762,7 @@ extern "C" int ursn_query(const ursn_config* cfg, ursn_sizes* out) {
 // the topology recorded by _build against.
 extern "C" int ursn_query_layer(const ursn_config* cfg, int64_t index, ursn_layer_info* out) {
   URSN_REQUIRE(cfg && out, "query_layer: null argument");
+  if (cfg->act_dtype == 1) return bnet_layer(cfg, index, out, nullptr);
   ursn_net tmp;
   tmp.cfg = *cfg;
   Arena A;
@@ -775,6 +780,7 @@ extern "C" int ursn_query_concat(const ursn_config* cfg, int32_t step, char* fir
   URSN_REQUIRE(cfg && first && second && cap > 0, "query_concat: null argument");
   ursn_net tmp;
   tmp.cfg = *cfg;
+  tmp.cfg.act_dtype = 0;   // same topology and scope names in both precisions
   Arena A;
   URSN_TRY(plan(&tmp, A));
   URSN_REQUIRE(step >= 0 && step < (int)tmp.cat_names.size(), "query_concat: step %d out of range", step);
@@ -788,8 +794,18 @@ extern "C" int ursn_create(const ursn_config* cfg, float* params, float* grads, 
   URSN_REQUIRE(cfg && params && workspace && out, "create: null argument");
   URSN_REQUIRE(!cfg->trainable || (grads && adam_m && adam_v), "create: trainable net needs grads/adam buffers");
   URSN_REQUIRE((((uintptr_t)workspace) & 255) == 0, "create: workspace must be 256-byte aligned");
+  URSN_REQUIRE(cfg->act_dtype == 0 || cfg->act_dtype == 1, "create: act_dtype %d not in {0 fp32, 1 bf16}", cfg->act_dtype);
   ursn_net* n = new ursn_net();
   n->cfg = *cfg;
+  if (cfg->act_dtype == 1) {
+    int rc = bnet_create(cfg, params, grads, workspace, workspace_bytes, &n->bf);
+    if (rc) { delete n; return rc; }
+    n->sizes = *bnet_sizes(n->bf);
+    n->params = params; n->grads = grads; n->adam_m = adam_m; n->adam_v = adam_v;
+    n->metrics = bnet_metrics(n->bf);
+    *out = n;
+    return 0;
+  }
   if (n->cfg.bn_eps <= 0.f) n->cfg.bn_eps = 1e-3f;
   Arena A;
   A.base = (char*)workspace;
@@ -841,6 +857,7 @@ extern "C" int ursn_create(const ursn_config* cfg, float* params, float* grads, 
 
 extern "C" int ursn_destroy(ursn_net* net) {
   if (!net) return 0;
+  if (net->bf) { bnet_destroy(net->bf); delete net; return 0; }
   if (net->s2_owned) { (void)hipStreamSynchronize(net->s2_owned); (void)hipStreamDestroy(net->s2_owned); }
   if (net->s2_done) (void)hipEventDestroy(net->s2_done);
   for (hipEvent_t e : net->sync_pool) (void)hipEventDestroy(e);
@@ -858,6 +875,7 @@ extern "C" int ursn_get_sizes(const ursn_net* net, ursn_sizes* out) {
 
 extern "C" int ursn_param(const ursn_net* net, int64_t index, ursn_param_info* out) {
   URSN_REQUIRE(net && out, "param: null argument");
+  if (net->bf) return bnet_param(net->bf, index, out);
   URSN_REQUIRE(index >= 0 && index < net->sizes.n_tensors, "param: index %lld out of range", (long long)index);
   const Layer& L = net->layers[index / 2];
   memset(out, 0, sizeof(*out));
@@ -888,6 +906,11 @@ extern "C" int ursn_accum_step(ursn_net* net, const float* data, const float* la
   URSN_REQUIRE(!net->cfg.use_weight || weight, "Network configured to use loss pixel-weighting. Cannot run w/ input_weight=None");
   hipStream_t s = (hipStream_t)stream;
   net->last_n = n;
+  if (net->bf) {
+    URSN_TRY(bnet_step(net->bf, data, label, weight, n, 0, nullptr, nullptr, s));
+    if (out3) URSN_TRY(read_metrics(net, out3, 3, s));
+    return 0;
+  }
   URSN_TRY(forward(net, data, n, s));
   URSN_TRY(head(net, data, label, net->cfg.use_weight ? weight : nullptr, n, nullptr, true, s));
   URSN_TRY(backward(net, data, n, s));
@@ -912,8 +935,11 @@ extern "C" int ursn_eval(ursn_net* net, const float* data, const float* label, c
   URSN_REQUIRE(!net->cfg.use_weight || weight, "Network configured to use loss pixel-weighting. Cannot run w/ input_weight=None");
   hipStream_t s = (hipStream_t)stream;
   net->last_n = n;
-  URSN_TRY(forward(net, data, n, s));
-  URSN_TRY(head(net, data, label, net->cfg.use_weight ? weight : nullptr, n, nullptr, false, s));
+  if (net->bf) URSN_TRY(bnet_step(net->bf, data, label, weight, n, 1, nullptr, nullptr, s));
+  else {
+    URSN_TRY(forward(net, data, n, s));
+    URSN_TRY(head(net, data, label, net->cfg.use_weight ? weight : nullptr, n, nullptr, false, s));
+  }
   if (out3) URSN_TRY(read_metrics(net, out3, 3, s));
   return 0;
 }
@@ -924,8 +950,11 @@ extern "C" int ursn_infer(ursn_net* net, const float* data, const float* label, 
   URSN_REQUIRE(softmax_out, "infer: softmax_out is null");
   hipStream_t s = (hipStream_t)stream;
   net->last_n = n;
-  URSN_TRY(forward(net, data, n, s));
-  URSN_TRY(head(net, data, label, nullptr, n, softmax_out, false, s));
+  if (net->bf) URSN_TRY(bnet_step(net->bf, data, label, nullptr, n, 2, softmax_out, nullptr, s));
+  else {
+    URSN_TRY(forward(net, data, n, s));
+    URSN_TRY(head(net, data, label, nullptr, n, softmax_out, false, s));
+  }
   if (label && out2) URSN_TRY(read_metrics(net, out2, 2, s));
   else URSN_HIP(hipStreamSynchronize(s));
   return 0;
@@ -938,8 +967,11 @@ extern "C" int ursn_infer_labels(ursn_net* net, const float* data, const float* 
   URSN_REQUIRE(net->cfg.num_class >= 3 && net->cfg.cin == 1, "infer_labels: needs >= 3 classes and one input channel");
   hipStream_t s = (hipStream_t)stream;
   net->last_n = n;
-  URSN_TRY(forward(net, data, n, s));
-  URSN_TRY(head(net, data, label, nullptr, n, softmax_out, false, s, labels_out));
+  if (net->bf) URSN_TRY(bnet_step(net->bf, data, label, nullptr, n, 2, softmax_out, labels_out, s));
+  else {
+    URSN_TRY(forward(net, data, n, s));
+    URSN_TRY(head(net, data, label, nullptr, n, softmax_out, false, s, labels_out));
+  }
   if (label && out2) URSN_TRY(read_metrics(net, out2, 2, s));
   else URSN_HIP(hipStreamSynchronize(s));
   return 0;
@@ -964,6 +996,7 @@ extern "C" int ursn_set_adam_step(ursn_net* net, int64_t t) {
 extern "C" int ursn_tensor(const ursn_net* net, const char* name, float** ptr, int64_t* voxels, int32_t* channels,
                            int32_t* cstride) {
   URSN_REQUIRE(net && name && ptr && voxels && channels && cstride, "tensor: null argument");
+  if (net->bf) return bnet_tensor(net->bf, name, (void**)ptr, voxels, channels, cstride);
   std::string s(name);
   bool want_z = false, want_g = false, want_dz = false;
   auto strip = [&](const char* suf, bool& f) {
@@ -996,6 +1029,7 @@ extern "C" int ursn_tensor(const ursn_net* net, const char* name, float** ptr, i
 // ---- profiling C-ABI --------------------------------------------------------------------------
 extern "C" int ursn_profile_enable(ursn_net* net, int32_t on) {
   URSN_REQUIRE(net, "null handle");
+  if (net->bf) return 0;   // per-launch event records exist for the fp32 plan only
   net->profile = on != 0;
   net->prof.clear();
   net->ev_used = 0;
@@ -1025,6 +1059,7 @@ extern "C" int ursn_profile_read(ursn_net* net, ursn_prof_rec* out, int64_t max_
 
 extern "C" int ursn_set_wgrad_overlap(ursn_net* net, int32_t on) {
   URSN_REQUIRE(net, "null handle");
+  if (net->bf) return 0;
   if (net->s2_owned) (void)hipStreamSynchronize(net->s2_owned);
   net->s2 = on ? net->s2_owned : nullptr;
   return 0;

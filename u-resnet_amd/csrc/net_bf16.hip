@@ -1,0 +1,575 @@
+// bf16 mixed-precision plan of the U-ResNet of lib/uresnet.py:22-123 + lib/resnet_module.py:10-87 (BASELINE.json configs[4]):
+// activations, raw conv outputs z and all gradient tensors in HBM as bf16, fp32 master weights / BatchNorm statistics /
+// gradient accumulators / Adam.  Same topology, variable layout and fetch-set semantics as net.hip; every conv-like pass runs
+// on the two kernels of bf16_conv.hip, BatchNorm / join / head on bf16_elementwise.hip.
+//   * channel counts are padded to multiples of 8 in memory (one voxel = whole 16-byte pieces): the single input channel
+//     is expanded to 8 (7 zero channels) by launch_bf16_input, the 3|5-class logits live in 8-channel pieces; the padded
+//     rows / columns of those two layers' weights do not exist in the parameter buffer (Kw / Nw of launch_bconv);
+//   * tf.concat([deconv_i, skip]) is never executed: both producers write channel slices of one buffer;
+//   * weight gradients run on a second stream beside the data-gradient / BatchNorm chain (they only feed the optimiser).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "bf16_common.h"
+#include "net_bf16.h"
+
+namespace {
+
+struct Arena {
+  char* base = nullptr;
+  size_t off = 0;
+  void* take(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = base ? (void*)(base + off) : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+struct BAct {              // activation view + its gradient view (same layout)
+  bf16_t* p = nullptr;
+  bf16_t* g = nullptr;
+  int C = 0, cs = 0, lvl = 0, flag = -1;
+};
+
+struct BLayer {
+  std::string name;
+  int kind = 0, k = 3, stride = 1, cin = 0, cout = 0, lin = 0, lout = 0;   // real channel counts (parameter tensor)
+  int kin = 0, kout = 0;                                                   // channel counts in memory (multiples of 8)
+  int64_t w_off = 0, b_off = 0, w_n = 0;
+  ursn_conv_desc desc;                                                     // memory-view channels
+  bf16_t *z = nullptr, *dz = nullptr;
+  float *mean = nullptr, *rstd = nullptr;
+};
+
+struct BUnit {
+  int sc = -1, c1 = -1, c2 = -1;
+  BAct in, a1, out;
+};
+
+}  // namespace
+
+struct ursn_bnet {
+  ursn_config cfg;
+  ursn_sizes sizes;
+  int nlev = 0;
+  int ldim[8][3];
+  int64_t lvox[8];
+  std::vector<BLayer> layers;
+  std::vector<BUnit> units;
+  std::vector<int> deconv;
+  std::vector<BAct> deconv_in, deconv_out, cat;
+  int conv0 = -1, conv1 = -1, conv2 = -1;
+  BAct a_data, a_conv0, a_conv1, a_pre1;
+  std::vector<int> ginit;
+  float *params = nullptr, *grads = nullptr;
+  bf16_t* dlog = nullptr;
+  float* metrics = nullptr;
+  float* beta_pad = nullptr;     // conv2's beta padded to 8 (the head and the BatchNorm kernels index 8 channels)
+  bf16_t* wpack = nullptr; size_t wpack_elems = 0;
+  bf16_t* wpack2 = nullptr;      // packed weights of the launches on the second stream (none today: wgrad packs nothing)
+  double* stats = nullptr; size_t stats_doubles = 0;
+  void* bn_scratch = nullptr;
+  void* head_scratch = nullptr;
+  void* wg_scratch = nullptr; size_t wg_bytes = 0;
+  hipStream_t s2 = nullptr;
+  hipEvent_t s2_done = nullptr;
+  std::vector<hipEvent_t> evs;
+  size_t ev_used = 0;
+};
+
+namespace {
+
+int new_flag(ursn_bnet* n) { n->ginit.push_back(0); return (int)n->ginit.size() - 1; }
+
+BAct make_act(ursn_bnet* n, Arena& A, int lvl, int C, bool grad, bool value = true) {
+  BAct a;
+  a.C = C; a.cs = C; a.lvl = lvl;
+  const size_t bytes = (size_t)n->cfg.max_batch * n->lvox[lvl] * C * sizeof(bf16_t);
+  a.p = value ? (bf16_t*)A.take(bytes) : nullptr;
+  a.g = grad ? (bf16_t*)A.take(bytes) : nullptr;
+  a.flag = new_flag(n);
+  return a;
+}
+BAct sub_act(const BAct& full, int c0, int C) {
+  BAct a = full;
+  a.p = full.p ? full.p + c0 : nullptr;
+  a.g = full.g ? full.g + c0 : nullptr;
+  a.C = C;
+  return a;
+}
+int pad8(int c) { return (c + 7) & ~7; }
+
+int add_layer(ursn_bnet* n, Arena& A, const std::string& name, int kind, int k, int s, int ci, int co, int lin, int lout,
+              int64_t& poff) {
+  BLayer L;
+  L.name = "UResNet/" + name;
+  L.kind = kind; L.k = k; L.stride = s; L.cin = ci; L.cout = co; L.lin = lin; L.lout = lout;
+  L.kin = pad8(ci); L.kout = pad8(co);
+  int64_t taps = 1;
+  for (int j = 0; j < n->cfg.ndim; ++j) taps *= k;
+  L.w_n = taps * ci * co;
+  L.w_off = poff; poff += L.w_n;
+  L.b_off = poff; poff += co;
+  memset(&L.desc, 0, sizeof(L.desc));
+  L.desc.ndim = n->cfg.ndim;
+  L.desc.n = n->cfg.max_batch;
+  for (int j = 0; j < n->cfg.ndim; ++j) L.desc.in_sp[j] = n->ldim[lin][3 - n->cfg.ndim + j];
+  L.desc.cin = L.kin; L.desc.cout = L.kout; L.desc.k = k; L.desc.stride = s; L.desc.transposed = kind; L.desc.dtype = 1;
+  const size_t bytes = (size_t)n->cfg.max_batch * n->lvox[lout] * L.kout * sizeof(bf16_t);
+  L.z = (bf16_t*)A.take(bytes);
+  L.dz = n->cfg.trainable ? (bf16_t*)A.take(bytes) : nullptr;
+  L.mean = (float*)A.take(L.kout * sizeof(float));
+  L.rstd = (float*)A.take(L.kout * sizeof(float));
+  n->layers.push_back(L);
+  return (int)n->layers.size() - 1;
+}
+
+// geometry of one pass of a layer with the weight strides of the STORED (unpadded) parameter tensor
+int layer_geoms(const ursn_bnet* n, const BLayer& L, ConvPass pass, int N, int in_cs, int out_cs, GatherGeom* g8) {
+  ursn_conv_desc d = L.desc;
+  d.n = N; d.in_cstride = in_cs; d.out_cstride = out_cs;
+  const int cnt = build_geoms(d, pass, g8);
+  const bool gather = (!L.kind && pass == PASS_FWD) || (L.kind && pass == PASS_DGRAD);
+  for (int i = 0; i < cnt; ++i) {
+    GatherGeom& g = g8[i];
+    if (pass == PASS_WGRAD || gather) {   // [t][K][N] natural
+      const int Kr = pass == PASS_WGRAD ? (L.kind ? L.cout : L.cin) : (pass == PASS_FWD ? L.cin : L.cout);
+      const int Nr = pass == PASS_WGRAD ? (L.kind ? L.cin : L.cout) : (pass == PASS_FWD ? L.cout : L.cin);
+      g.w_tap_stride = Kr * Nr; g.w_sk = Nr; g.w_sn = 1;
+    } else {                              // contraction along the last stored axis
+      g.w_tap_stride = L.cin * L.cout; g.w_sk = 1;
+      g.w_sn = pass == PASS_DGRAD ? L.cout : L.cin;   // conv dgrad contracts cout, transposed forward contracts cin
+    }
+  }
+  return cnt;
+}
+void real_extents(const BLayer& L, ConvPass pass, int& Kw, int& Nw) {
+  if (pass == PASS_WGRAD) { Kw = L.kind ? L.cout : L.cin; Nw = L.kind ? L.cin : L.cout; }
+  else if (pass == PASS_FWD) { Kw = L.cin; Nw = L.cout; }
+  else { Kw = L.cout; Nw = L.cin; }
+}
+
+int plan(ursn_bnet* n, Arena& A) {
+  const ursn_config& c = n->cfg;
+  URSN_REQUIRE(c.ndim == 2 || c.ndim == 3, "len(dims) must be 3 (H,W,C) or 4 (H,W,D,C)");
+  URSN_REQUIRE(c.num_strides >= 1 && c.num_strides <= 5, "num_strides %d out of range [1,5]", c.num_strides);
+  URSN_REQUIRE(c.cin == 1, "bf16 path: one input channel (the reference's data), got %d", c.cin);
+  URSN_REQUIRE(c.base_filters >= 8 && c.base_filters % 8 == 0, "bf16 path: base_num_outputs must be a multiple of 8, got %d", c.base_filters);
+  URSN_REQUIRE(c.num_class >= 1 && c.num_class <= 8 && c.max_batch >= 1, "bad class / batch configuration");
+  const int ns = c.num_strides, F = c.base_filters;
+  const bool tr = c.trainable != 0;
+  n->nlev = ns + 1;
+  for (int l = 0; l <= ns; ++l) {
+    n->lvox[l] = 1;
+    for (int j = 0; j < 3; ++j) {
+      const int lead = 3 - c.ndim;
+      if (j < lead) { n->ldim[l][j] = 1; continue; }
+      const int s0 = c.spatial[j - lead];
+      URSN_REQUIRE(s0 > 0 && s0 % (1 << ns) == 0, "spatial size %d not divisible by 2^%d (deconv/skip shapes would differ)", s0, ns);
+      n->ldim[l][j] = s0 >> l;
+      n->lvox[l] *= n->ldim[l][j];
+    }
+  }
+  int64_t poff = 0;
+  n->layers.clear(); n->units.clear(); n->deconv.clear(); n->cat.clear(); n->deconv_in.clear(); n->deconv_out.clear();
+  n->ginit.clear();
+  n->cat.resize(ns);
+  for (int i = 0; i < ns; ++i) n->cat[i] = make_act(n, A, ns - 1 - i, 2 * (F << (ns - 1 - i)), tr);
+  auto fmap_view = [&](int lvl) { const BAct& full = n->cat[ns - 1 - lvl]; return sub_act(full, full.C / 2, full.C / 2); };
+
+  n->a_data = make_act(n, A, 0, 8, false);
+  n->conv0 = add_layer(n, A, "conv0", 0, 3, 1, c.cin, F, 0, 0, poff);
+  n->a_conv0 = fmap_view(0);
+  auto add_unit = [&](const std::string& scope, const BAct& in, int co, int s, int lout, const BAct* out_view) {
+    BUnit u;
+    u.in = in;
+    if (!(in.C == co && s == 1)) u.sc = add_layer(n, A, scope + "/shortcut", 0, 1, s, in.C, co, in.lvl, lout, poff);
+    u.c1 = add_layer(n, A, scope + "/resnet_conv1", 0, 3, s, in.C, co, in.lvl, lout, poff);
+    u.a1 = make_act(n, A, lout, co, tr);
+    u.c2 = add_layer(n, A, scope + "/resnet_conv2", 0, 3, 1, co, co, lout, lout, poff);
+    u.out = out_view ? *out_view : make_act(n, A, lout, co, tr);
+    n->units.push_back(u);
+    return u.out;
+  };
+  BAct net = n->a_conv0;
+  char sc[64];
+  for (int step = 0; step < ns; ++step) {
+    const int co = net.C * 2;
+    snprintf(sc, sizeof(sc), "resnet_module%d/module1", step);
+    BAct u1 = add_unit(sc, net, co, 2, step + 1, nullptr);
+    snprintf(sc, sizeof(sc), "resnet_module%d/module2", step);
+    if (step + 1 < ns) { BAct view = fmap_view(step + 1); net = add_unit(sc, u1, co, 1, step + 1, &view); }
+    else net = add_unit(sc, u1, co, 1, step + 1, nullptr);
+  }
+  for (int i = 0; i < ns; ++i) {
+    const int co = net.C / 2, lvl = ns - 1 - i;
+    snprintf(sc, sizeof(sc), "deconv%d", i);
+    const int li = add_layer(n, A, sc, 1, 3, 2, net.C, co, net.lvl, lvl, poff);
+    n->deconv.push_back(li);
+    n->deconv_in.push_back(net);
+    n->deconv_out.push_back(sub_act(n->cat[i], 0, co));
+    snprintf(sc, sizeof(sc), "resnet_module%d/module1", i + 5);
+    BAct u1 = add_unit(sc, n->cat[i], co, 1, lvl, nullptr);
+    snprintf(sc, sizeof(sc), "resnet_module%d/module2", i + 5);
+    net = add_unit(sc, u1, co, 1, lvl, nullptr);
+  }
+  n->a_pre1 = net;
+  n->conv1 = add_layer(n, A, "conv1", 0, 3, 1, net.C, F, 0, 0, poff);
+  n->a_conv1 = make_act(n, A, 0, F, tr);
+  n->conv2 = add_layer(n, A, "conv2", 0, 3, 1, F, c.num_class, 0, 0, poff);
+
+  const int64_t V0 = (int64_t)c.max_batch * n->lvox[0];
+  n->dlog = tr ? (bf16_t*)A.take((size_t)V0 * 8 * sizeof(bf16_t)) : nullptr;
+  n->metrics = (float*)A.take(8 * sizeof(float));
+  n->beta_pad = (float*)A.take(8 * sizeof(float));
+  n->head_scratch = A.take(head_scratch_bytes(c.max_batch, n->lvox[0]) + 64);
+  size_t wp = 0, st = 0, bn = 0, wg = 0;
+  for (const BLayer& L : n->layers) {
+    const size_t b = bbn_scratch_bytes((int64_t)c.max_batch * n->lvox[L.lout], L.kout);
+    if (b > bn) bn = b;
+    for (int nb = 1; nb <= c.max_batch; ++nb) {   // the launch geometry is chosen per call from the batch actually fed
+      GatherGeom g[8];
+      for (int pass = 0; pass < (tr ? 3 : 1); ++pass) {
+        const int cnt = layer_geoms(n, L, (ConvPass)pass, nb, L.kin, L.kout, g);
+        URSN_REQUIRE(cnt >= 1, "bf16 plan: bad geometry for %s", L.name.c_str());
+        size_t stl = 0;
+        for (int i = 0; i < cnt; ++i) {
+          if (g[i].ntaps == 0) continue;
+          if (pass == PASS_WGRAD) {
+            const size_t w = bwgrad_scratch_bytes(g[i]);
+            URSN_REQUIRE(w > 0, "bf16 plan: no weight-gradient kernel for %s", L.name.c_str());
+            if (w > wg) wg = w;
+          } else {
+            const size_t e = bconv_pack_elems(g[i]);
+            URSN_REQUIRE(e > 0, "bf16 plan: no conv kernel for %s (pass %d)", L.name.c_str(), pass);
+            if (e > wp) wp = e;
+            if (pass == PASS_FWD) stl += bconv_stats_scratch_doubles(g[i]);
+          }
+        }
+        if (stl > st) st = stl;
+      }
+    }
+  }
+  n->wpack_elems = wp;
+  n->wpack = (bf16_t*)A.take(wp * sizeof(bf16_t) + 256);
+  n->stats_doubles = st;
+  n->stats = (double*)A.take(st * sizeof(double) + 256);
+  n->bn_scratch = A.take(bn + 256);
+  n->wg_bytes = wg;
+  n->wg_scratch = tr ? A.take(wg + 256) : nullptr;
+
+  n->sizes.n_params = poff;
+  n->sizes.n_layers = (int64_t)n->layers.size();
+  n->sizes.n_tensors = 2 * (int64_t)n->layers.size();
+  n->sizes.workspace_bytes = (int64_t)((A.off + 255) & ~(size_t)255);
+  return 0;
+}
+
+// ---- forward -------------------------------------------------------------------------------------------------------------
+int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
+  BLayer& L = n->layers[li];
+  GatherGeom g[8];
+  const int cnt = layer_geoms(n, L, PASS_FWD, N, in.cs, L.kout, g);
+  int Kw, Nw;
+  real_extents(L, PASS_FWD, Kw, Nw);
+  int total = 0, off = 0;
+  for (int i = 0; i < cnt; ++i) total += bconv_grid_blocks(g[i]);
+  URSN_REQUIRE(total > 0, "bf16 forward: no kernel for %s", L.name.c_str());
+  for (int i = 0; i < cnt; ++i) {
+    g[i].accumulate = 0;
+    URSN_TRY(launch_bconv(g[i], in.p, n->params + L.w_off, Kw, Nw, n->wpack, L.z, n->stats, off, total, s));
+    off += bconv_grid_blocks(g[i]);
+  }
+  return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
+}
+
+const float* beta_of(ursn_bnet* n, const BLayer& L) { return L.cout == L.kout ? n->params + L.b_off : n->beta_pad; }
+
+int bn_out(ursn_bnet* n, int li, const BAct& out, int relu, int N, int li2, const BAct* res, hipStream_t s) {
+  BLayer& L = n->layers[li];
+  BBnActArgs a;
+  memset(&a, 0, sizeof(a));
+  a.z = L.z; a.zcs = L.kout; a.mean = L.mean; a.rstd = L.rstd; a.beta = beta_of(n, L);
+  if (li2 >= 0) {
+    BLayer& L2 = n->layers[li2];
+    a.z2 = L2.z; a.z2cs = L2.kout; a.mean2 = L2.mean; a.rstd2 = L2.rstd; a.beta2 = beta_of(n, L2);
+  }
+  if (res) { a.res = res->p; a.rescs = res->cs; }
+  a.y = out.p; a.ycs = out.cs; a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.kout; a.relu = relu;
+  return launch_bbn_act(a, s);
+}
+
+int unit_fwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s) {
+  if (u.sc >= 0) URSN_TRY(conv_stats(n, u.sc, u.in, N, s));
+  URSN_TRY(conv_stats(n, u.c1, u.in, N, s));
+  URSN_TRY(bn_out(n, u.c1, u.a1, 0, N, -1, nullptr, s));
+  URSN_TRY(conv_stats(n, u.c2, u.a1, N, s));
+  if (u.sc >= 0) return bn_out(n, u.c2, u.out, 1, N, u.sc, nullptr, s);
+  return bn_out(n, u.c2, u.out, 1, N, -1, &u.in, s);
+}
+
+int forward(ursn_bnet* n, const float* data, int N, hipStream_t s) {
+  const int ns = n->cfg.num_strides;
+  {  // conv2's beta, padded to the 8-channel piece
+    const BLayer& L2 = n->layers[n->conv2];
+    URSN_HIP(hipMemsetAsync(n->beta_pad, 0, 8 * sizeof(float), s));
+    URSN_HIP(hipMemcpyAsync(n->beta_pad, n->params + L2.b_off, L2.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  URSN_TRY(launch_bf16_input(data, n->a_data.p, (int64_t)N * n->lvox[0], s));
+  URSN_TRY(conv_stats(n, n->conv0, n->a_data, N, s));
+  URSN_TRY(bn_out(n, n->conv0, n->a_conv0, 1, N, -1, nullptr, s));
+  size_t ui = 0;
+  for (int step = 0; step < ns; ++step) {
+    URSN_TRY(unit_fwd(n, n->units[ui++], N, s));
+    URSN_TRY(unit_fwd(n, n->units[ui++], N, s));
+  }
+  for (int i = 0; i < ns; ++i) {
+    URSN_TRY(conv_stats(n, n->deconv[i], n->deconv_in[i], N, s));
+    URSN_TRY(bn_out(n, n->deconv[i], n->deconv_out[i], 1, N, -1, nullptr, s));
+    URSN_TRY(unit_fwd(n, n->units[ui++], N, s));
+    URSN_TRY(unit_fwd(n, n->units[ui++], N, s));
+  }
+  URSN_TRY(conv_stats(n, n->conv1, n->a_pre1, N, s));
+  URSN_TRY(bn_out(n, n->conv1, n->a_conv1, 1, N, -1, nullptr, s));
+  return conv_stats(n, n->conv2, n->a_conv1, N, s);
+}
+
+int head(ursn_bnet* n, const float* data, const float* label, const float* weight, int N, float* softmax_out, bool want_grad,
+         hipStream_t s, float* ana_out = nullptr) {
+  BLayer& L = n->layers[n->conv2];
+  BHeadArgs a;
+  memset(&a, 0, sizeof(a));
+  a.z = L.z; a.z_cs = L.kout; a.mean = L.mean; a.rstd = L.rstd; a.beta = n->beta_pad;
+  a.data = data; a.data_cs = 1; a.label = label; a.weight = weight; a.n = N; a.pix = n->lvox[0]; a.ncls = n->cfg.num_class;
+  a.softmax_out = softmax_out; a.dlogits = want_grad ? n->dlog : nullptr; a.dl_cs = 8; a.ana_out = ana_out;
+  a.metrics = n->metrics; a.scratch = n->head_scratch;
+  return launch_bhead(a, s);
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------------
+bool take_flag(ursn_bnet* n, const BAct& a) {
+  const bool acc = n->ginit[a.flag] != 0;
+  n->ginit[a.flag] = 1;
+  return acc;
+}
+
+int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipStream_t s) {
+  BLayer& L = n->layers[li];
+  GatherGeom g[8];
+  int Kw, Nw;
+  {  // weight gradient on the second stream, ordered after the dz it reads
+    URSN_REQUIRE(layer_geoms(n, L, PASS_WGRAD, N, in.cs, L.kout, g) == 1, "bf16 backward: bad weight-gradient geometry");
+    real_extents(L, PASS_WGRAD, Kw, Nw);
+    hipStream_t ws = s;
+    if (n->s2) {
+      if (n->ev_used == n->evs.size()) {
+        hipEvent_t e;
+        URSN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        n->evs.push_back(e);
+      }
+      hipEvent_t e = n->evs[n->ev_used++];
+      URSN_HIP(hipEventRecord(e, s));
+      URSN_HIP(hipStreamWaitEvent(n->s2, e, 0));
+      ws = n->s2;
+    }
+    const bf16_t* S = L.kind ? L.dz : in.p;
+    const bf16_t* Cq = L.kind ? in.p : L.dz;
+    URSN_TRY(launch_bwgrad(g[0], S, Cq, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, ws));
+  }
+  if (!need_dgrad) return 0;
+  const bool acc = take_flag(n, in);
+  const int cnt = layer_geoms(n, L, PASS_DGRAD, N, in.cs, L.kout, g);
+  real_extents(L, PASS_DGRAD, Kw, Nw);
+  bool empty = false;
+  for (int i = 0; i < cnt; ++i) empty = empty || g[i].ntaps == 0;
+  URSN_REQUIRE(!empty || acc, "bf16 backward: %s would leave voxels of its input gradient unwritten", L.name.c_str());
+  for (int i = 0; i < cnt; ++i) {
+    if (g[i].ntaps == 0) continue;
+    g[i].accumulate = acc ? 1 : 0;
+    URSN_TRY(launch_bconv(g[i], L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, 0, 0, s));
+  }
+  return 0;
+}
+
+int bn_back(ursn_bnet* n, int li, const bf16_t* dy, int dycs, const bf16_t* y, int ycs, int relu, int li2, bf16_t* dres,
+            int drescs, int dres_acc, int N, hipStream_t s) {
+  BLayer& L = n->layers[li];
+  BBnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dy = dy; a.dycs = dycs; a.y = y; a.ycs = ycs;
+  a.z = L.z; a.zcs = L.kout; a.mean = L.mean; a.rstd = L.rstd; a.dz = L.dz; a.dzcs = L.kout;
+  a.dbeta = n->grads + L.b_off; a.beta = beta_of(n, L);
+  if (li2 >= 0) {
+    BLayer& L2 = n->layers[li2];
+    a.z2 = L2.z; a.z2cs = L2.kout; a.mean2 = L2.mean; a.rstd2 = L2.rstd; a.dz2 = L2.dz; a.dz2cs = L2.kout;
+    a.dbeta2 = n->grads + L2.b_off;
+  }
+  a.dres = dres; a.drescs = drescs; a.dres_accumulate = dres_acc;
+  a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.kout; a.Cw = L.cout; a.relu = relu; a.scratch = n->bn_scratch;
+  return launch_bbn_bwd(a, s);
+}
+
+int unit_bwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s) {
+  if (u.sc >= 0) {
+    URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, u.sc, nullptr, 0, 0, N, s));
+  } else {
+    const bool acc = take_flag(n, u.in);
+    URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, -1, u.in.g, u.in.cs, acc ? 1 : 0, N, s));
+  }
+  URSN_TRY(conv_bwd(n, u.c2, u.a1, true, N, s));
+  URSN_TRY(bn_back(n, u.c1, u.a1.g, u.a1.cs, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
+  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s));                 // k3 (s1 | s2): writes every voxel of d(in)
+  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, true, N, s));  // 1x1 (s1 | s2): accumulates
+  return 0;
+}
+
+int backward(ursn_bnet* n, int N, hipStream_t s) {
+  const int ns = n->cfg.num_strides;
+  for (size_t i = 0; i < n->ginit.size(); ++i) n->ginit[i] = 0;
+  n->ev_used = 0;
+  URSN_TRY(bn_back(n, n->conv2, n->dlog, 8, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
+  URSN_TRY(conv_bwd(n, n->conv2, n->a_conv1, true, N, s));
+  URSN_TRY(bn_back(n, n->conv1, n->a_conv1.g, n->a_conv1.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
+  URSN_TRY(conv_bwd(n, n->conv1, n->a_pre1, true, N, s));
+  size_t ui = n->units.size();
+  for (int i = ns - 1; i >= 0; --i) {
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
+    const BAct& dout = n->deconv_out[i];
+    URSN_TRY(bn_back(n, n->deconv[i], dout.g, dout.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
+    URSN_TRY(conv_bwd(n, n->deconv[i], n->deconv_in[i], true, N, s));
+  }
+  for (int step = ns - 1; step >= 0; --step) {
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
+  }
+  const BAct& a0 = n->a_conv0;
+  URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
+  URSN_TRY(conv_bwd(n, n->conv0, n->a_data, false, N, s));
+  if (n->s2) {
+    URSN_HIP(hipEventRecord(n->s2_done, n->s2));
+    URSN_HIP(hipStreamWaitEvent(s, n->s2_done, 0));
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ---- entry points used by net.hip's C-ABI dispatch -----------------------------------------------------------------------
+int bnet_query(const ursn_config* cfg, ursn_sizes* out) {
+  ursn_bnet tmp;
+  tmp.cfg = *cfg;
+  if (tmp.cfg.bn_eps <= 0.f) tmp.cfg.bn_eps = 1e-3f;
+  Arena A;
+  URSN_TRY(plan(&tmp, A));
+  *out = tmp.sizes;
+  return 0;
+}
+
+int bnet_layer(const ursn_config* cfg, int64_t index, ursn_layer_info* out, int* n_layers) {
+  ursn_bnet tmp;
+  tmp.cfg = *cfg;
+  Arena A;
+  URSN_TRY(plan(&tmp, A));
+  if (n_layers) *n_layers = (int)tmp.layers.size();
+  if (!out) return 0;
+  URSN_REQUIRE(index >= 0 && index < (int64_t)tmp.layers.size(), "query_layer: index %lld out of range", (long long)index);
+  const BLayer& L = tmp.layers[index];
+  memset(out, 0, sizeof(*out));
+  snprintf(out->name, sizeof(out->name), "%s", L.name.c_str());
+  out->transposed = L.kind; out->k = L.k; out->stride = L.stride; out->cin = L.cin; out->cout = L.cout;
+  out->relu = (L.kind == 1 || L.name == "UResNet/conv0" || L.name == "UResNet/conv1") ? 1 : 0;
+  out->w_offset = L.w_off; out->beta_offset = L.b_off;
+  return 0;
+}
+
+int bnet_create(const ursn_config* cfg, float* params, float* grads, void* workspace, size_t workspace_bytes, ursn_bnet** out) {
+  ursn_bnet* n = new ursn_bnet();
+  n->cfg = *cfg;
+  if (n->cfg.bn_eps <= 0.f) n->cfg.bn_eps = 1e-3f;
+  Arena A;
+  A.base = (char*)workspace;
+  int rc = plan(n, A);
+  if (rc == 0 && (size_t)n->sizes.workspace_bytes > workspace_bytes) {
+    ursn_set_error("create: workspace too small: need %lld bytes, got %zu", (long long)n->sizes.workspace_bytes, workspace_bytes);
+    rc = 2;
+  }
+  if (rc) { delete n; return rc; }
+  n->params = params; n->grads = grads;
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (hipStreamCreateWithPriority(&n->s2, hipStreamNonBlocking, lo) != hipSuccess ||
+      hipEventCreateWithFlags(&n->s2_done, hipEventDisableTiming) != hipSuccess) {
+    ursn_set_error("create: could not create the weight-gradient stream");
+    delete n;
+    return 1;
+  }
+  // pad channels of the logits buffers / input expansion are written by the kernels themselves (zero weights -> zeros)
+  *out = n;
+  return 0;
+}
+
+void bnet_destroy(ursn_bnet* n) {
+  if (!n) return;
+  if (n->s2) { (void)hipStreamSynchronize(n->s2); (void)hipStreamDestroy(n->s2); }
+  if (n->s2_done) (void)hipEventDestroy(n->s2_done);
+  for (hipEvent_t e : n->evs) (void)hipEventDestroy(e);
+  delete n;
+}
+
+const ursn_sizes* bnet_sizes(const ursn_bnet* n) { return &n->sizes; }
+float* bnet_metrics(ursn_bnet* n) { return n->metrics; }
+
+int bnet_param(const ursn_bnet* n, int64_t index, ursn_param_info* out) {
+  URSN_REQUIRE(index >= 0 && index < n->sizes.n_tensors, "param: index %lld out of range", (long long)index);
+  const BLayer& L = n->layers[index / 2];
+  memset(out, 0, sizeof(*out));
+  if (index % 2 == 0) {
+    snprintf(out->name, sizeof(out->name), "%s/weights", L.name.c_str());
+    out->offset = L.w_off; out->nelem = L.w_n; out->rank = n->cfg.ndim + 2;
+    for (int j = 0; j < n->cfg.ndim; ++j) out->shape[j] = L.k;
+    out->shape[n->cfg.ndim] = L.kind ? L.cout : L.cin;
+    out->shape[n->cfg.ndim + 1] = L.kind ? L.cin : L.cout;
+  } else {
+    snprintf(out->name, sizeof(out->name), "%s/BatchNorm/beta", L.name.c_str());
+    out->offset = L.b_off; out->nelem = L.cout; out->rank = 1; out->shape[0] = L.cout;
+  }
+  return 0;
+}
+
+int bnet_step(ursn_bnet* n, const float* data, const float* label, const float* weight, int N, int mode, float* softmax_out,
+              float* labels_out, hipStream_t s) {
+  // mode 0: accumulate gradients (forward + loss + backward); 1: evaluate (forward + loss); 2: inference
+  URSN_TRY(forward(n, data, N, s));
+  const float* w = n->cfg.use_weight ? weight : nullptr;
+  if (mode == 0) {
+    URSN_TRY(head(n, data, label, w, N, nullptr, true, s));
+    return backward(n, N, s);
+  }
+  if (mode == 1) return head(n, data, label, w, N, nullptr, false, s);
+  return head(n, data, label, nullptr, N, softmax_out, false, s, labels_out);
+}
+
+int bnet_tensor(const ursn_bnet* n, const char* name, void** ptr, int64_t* voxels, int32_t* channels, int32_t* cstride) {
+  std::string s(name);
+  bool want_z = false, want_dz = false;
+  auto strip = [&](const char* suf, bool& f) {
+    const size_t L = strlen(suf);
+    if (s.size() > L && s.compare(s.size() - L, L, suf) == 0) { f = true; s = s.substr(0, s.size() - L); }
+  };
+  strip(":dz", want_dz);
+  strip(":z", want_z);
+  for (const BLayer& L : n->layers)
+    if (L.name == s && (want_z || want_dz)) {
+      *ptr = want_z ? (void*)L.z : (void*)L.dz;
+      *voxels = n->lvox[L.lout]; *channels = L.cout; *cstride = L.kout;
+      return 0;
+    }
+  ursn_set_error("tensor: the bf16 plan exposes raw conv outputs only (<scope>:z, <scope>:dz), not %s", name);
+  return 2;
+}

@@ -61,7 +61,13 @@ class ssnet_base(object):
     # construct (lib/ssnet.py:20-89)
     # ------------------------------------------------------------------------------------------
     def construct(self, trainable=True, use_weight=True, learning_rate=None, allocate=True, device=None,
-                  seed=1234, bn_eps=1e-3):
+                  seed=1234, bn_eps=1e-3, precision='fp32'):
+        """``precision='bf16'`` (not in the reference, which is fp32 TensorFlow): mixed precision -- activations and
+        gradient tensors bf16 in HBM, bf16 MFMA convolutions with fp32 accumulation; parameters, BatchNorm statistics,
+        accumulated gradients and Adam stay fp32 (BASELINE.json configs[4])."""
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self._precision = precision
         self._trainable = bool(trainable)
         self._use_weight = bool(use_weight)
         self._learning_rate = learning_rate
@@ -108,6 +114,7 @@ class ssnet_base(object):
         cfg.trainable = int(self._trainable)
         cfg.use_weight = int(self._use_weight)
         cfg.bn_eps = self._bn_eps
+        cfg.act_dtype = 1 if getattr(self, '_precision', 'fp32') == 'bf16' else 0
         return cfg
 
     def _check_plan(self):
@@ -502,10 +509,16 @@ class ssnet_base(object):
         total = int(n * vox.value * cs.value)
         valid = total - (cs.value - ch.value)  # a channel-slice view ends `ch` floats into its last voxel
         torch.cuda.synchronize(self._device)
-        buf = (ctypes.c_float * total)()
         from . import hiprt
-        hiprt.memcpy_d2h(buf, ptr.value, valid * 4)
-        a = np.frombuffer(buf, dtype=np.float32).reshape(n, int(vox.value), cs.value)[:, :, :ch.value]
+        if getattr(self, '_precision', 'fp32') == 'bf16':   # bf16 bit patterns: widen on the host
+            raw = (ctypes.c_uint16 * total)()
+            hiprt.memcpy_d2h(raw, ptr.value, valid * 2)
+            a = (np.frombuffer(raw, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+        else:
+            buf = (ctypes.c_float * total)()
+            hiprt.memcpy_d2h(buf, ptr.value, valid * 4)
+            a = np.frombuffer(buf, dtype=np.float32)
+        a = a.reshape(n, int(vox.value), cs.value)[:, :, :ch.value]
         return a.reshape((n,) + tuple(int(d) for d in self._level_dims(int(vox.value))) + (ch.value,)).copy()
 
     def _level_dims(self, voxels):
