@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0      # spec; ~6300 achievable
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
 
 WORKLOADS = {
     # name: dims, base filters, classes, per-GPU batch, generator
@@ -35,9 +36,61 @@ WORKLOADS = {
     "cfg2_2d512_f16_b16": ((512, 512, 1), 16, 5, 16, "lartpc_sparse"),
     "cfg1_2d256_f16_b4": ((256, 256, 1), 16, 3, 4, "dense_uniform"),
     "tiny_3d64_f8_b2": ((64, 64, 64, 1), 8, 3, 2, "lartpc_sparse"),
-    # BASELINE.json cfg5's volume in fp32 (the bf16 variant is not built): 96.5 GB of workspace, sized for 288 GB HBM
+    # BASELINE.json configs[4]: 3-D 256^3 bf16 mixed precision (batch 4 per GPU) -- graded against HBM
+    "cfg5_3d256_f8_b4_bf16": ((256, 256, 256, 1), 8, 3, 4, "lartpc_sparse"),
+    # the same volume in fp32: 96.5 GB of workspace, sized for 288 GB HBM
     "cfg5shape_3d256_f8_b4_fp32": ((256, 256, 256, 1), 8, 3, 4, "lartpc_sparse"),
+    "tiny_3d64_f8_b2_bf16": ((64, 64, 64, 1), 8, 3, 2, "lartpc_sparse"),
 }
+
+
+def algorithmic_work(dims, F, ncls, batch, elem):
+    """SURVEY.md 8(d) conventions: FLOPs = 2 MACs of the 58 conv-like layers, bwd = dgrad + wgrad (conv0 has no dgrad);
+    bytes per pass = x + y + w with activations at `elem` bytes and weights / weight gradients fp32.  Returns
+    (flops fwd+bwd, bytes fwd+bwd, T_roof seconds against `peak_flops`, 8 TB/s) through a closure."""
+    nd = len(dims) - 1
+    vox0 = 1
+    for d in dims[:-1]:
+        vox0 *= int(d)
+    layers = []   # (k, cin, cout, in level, out level, has_dgrad)
+
+    def unit(ci, co, s, lin, lout):
+        if not (ci == co and s == 1):
+            layers.append((1, ci, co, lin, lout, True))
+        layers.append((3, ci, co, lin, lout, True))
+        layers.append((3, co, co, lout, lout, True))
+    layers.append((3, int(dims[-1]), F, 0, 0, False))
+    c = F
+    for step in range(5):
+        unit(c, 2 * c, 2, step, step + 1)
+        unit(2 * c, 2 * c, 1, step + 1, step + 1)
+        c *= 2
+    for step in range(5):
+        lvl = 4 - step
+        layers.append((3, c, c // 2, lvl + 1, lvl, True))       # deconv: MACs counted on the INPUT grid
+        unit(c, c // 2, 1, lvl, lvl)
+        unit(c // 2, c // 2, 1, lvl, lvl)
+        c //= 2
+    layers.append((3, c, F, 0, 0, True))
+    layers.append((3, F, ncls, 0, 0, True))
+    out = []
+    for i, (k, ci, co, lin, lout, dg) in enumerate(layers):
+        vin, vout = batch * vox0 / (2 ** nd) ** lin, batch * vox0 / (2 ** nd) ** lout
+        is_deconv = lin > lout
+        macs = (vin if is_deconv else vout) * (k ** nd) * ci * co
+        byts = elem * (vin * ci + vout * co) + 4.0 * (k ** nd) * ci * co
+        out.append((2.0 * macs, byts, dg))
+    return out
+
+
+def step_roofline(dims, F, ncls, batch, elem, peak_flops, peak_bw):
+    fl = by = t = 0.0
+    for f, b, dg in algorithmic_work(dims, F, ncls, batch, elem):
+        passes = 3 if dg else 2
+        fl += passes * f
+        by += passes * b
+        t += max(f / peak_flops, b / peak_bw) + max((passes - 1) * f / peak_flops, (passes - 1) * b / peak_bw)
+    return fl, by, t
 
 
 def cpu_baseline_child(kind, size, reps, warm):
@@ -175,8 +228,9 @@ def main():
     dims, base, ncls, batch, gen = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
+    bf16 = args.workload.endswith("_bf16")
     net = uresnet(dims=list(dims), num_class=ncls, base_num_outputs=base)
-    net.construct(trainable=True, use_weight=True, learning_rate=1e-4, seed=1234)
+    net.construct(trainable=True, use_weight=True, learning_rate=1e-4, seed=1234, precision="bf16" if bf16 else "fp32")
 
     # device-resident synthetic batch, per rank its own entries (weak scaling: per-GPU work fixed)
     g = sio.GENERATORS[gen]
@@ -307,7 +361,19 @@ def main():
     except Exception:
         pmc = {}
     roofline = None
-    if by_kernel:
+    if bf16:
+        # The bf16 plan is graded against HBM (30-34 of its 58 layers are bandwidth-bound at the bf16 MFMA
+        # peak).  It has no per-launch event records yet, so the figure is for the WHOLE step: algorithmic bytes of the 58
+        # conv-like layers (BatchNorm / join / head assumed fused = 0 bytes, as the model prices them) over the step time.
+        fl, by, t_roof = step_roofline(dims, base, ncls, batch, 2, PEAK_BF16_TFLOPS * 1e12, PEAK_HBM_GBS * 1e9)
+        ach = by / (ms_per_step * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "whole step (bconv_bf16 / bwgrad_bf16 / bf16 BatchNorm kernels)",
+                    "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+                    "traffic": None, "traffic_source": None,
+                    "algorithmic_bytes_per_step": round(by), "step_algorithmic_TFLOPs": round(fl / 1e12, 3),
+                    "step_T_roof_ms": round(t_roof * 1e3, 3), "step_frac_of_roofline": round(t_roof * 1e3 / ms_per_step, 4),
+                    "achieved_TFLOPs": round(fl / (ms_per_step * 1e-3) / 1e12, 1)}
+    if by_kernel and not bf16:
         dom_name, dom = max(((k, v) for k, v in by_kernel.items() if v["conv"]), key=lambda kv: kv[1]["ms"])
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
@@ -352,7 +418,7 @@ def main():
                       else "fwd+bwd images/sec (%s)" % args.workload,
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "dims": list(dims), "base_filters": base, "num_class": ncls,
                        "batch_per_gpu": batch, "global_batch": batch * world,
                        "step": "zero_gradients+accum_gradients(fwd+loss+bwd)+allreduce+adam",

@@ -19,7 +19,12 @@ typedef float bf_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 // round-to-nearest-even, NaN stays NaN (plain cast: v_cvt_pk_bf16_f32, MI355X_MICROARCH.md correctness boundaries)
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
-__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+typedef float bf_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bfx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {   // one v_cvt_pk_bf16_f32
+  const bf_f32x2 f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bfx2));
+}
 // 8 bf16 (one 16-byte piece) <-> 8 floats
 __device__ __forceinline__ void unpack8(const u32x4& p, float (&f)[8]) {
 #pragma unroll

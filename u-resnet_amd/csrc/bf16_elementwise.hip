@@ -17,7 +17,7 @@ BMap make_bmap(int64_t V, int C) {
   while ((1 << m.shift) < cp) ++m.shift;
   const int vpb = 256 >> m.shift;
   int64_t blocks = cdiv64(V, (int64_t)vpb * 8);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   m.grid = (int)blocks;
   return m;
@@ -64,10 +64,11 @@ __global__ __launch_bounds__(256) void bbn_act_kernel(BBnActArgs a, int shift) {
     sh2[j] = a.z2 ? a.beta2[c + j] - a.mean2[c + j] * sc2[j] : 0.f;
   }
   const int64_t stride = (int64_t)gridDim.x * VPB;
-  for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += 2 * stride) {
-    u32x4 x[2], x2[2], r[2];
+  constexpr int U = 4;
+  for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += U * stride) {
+    u32x4 x[U], x2[U], r[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int64_t v = v0 + u * stride;
       if (v < a.V) {
         x[u] = ld16(a.z + v * a.zcs + c);
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void bbn_act_kernel(BBnActArgs a, int shift) {
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int64_t v = v0 + u * stride;
       if (v >= a.V) continue;
       float f[8], f2[8], fr[8], y[8];
@@ -113,24 +114,36 @@ __global__ __launch_bounds__(256) void bbn_bwd_reduce_kernel(BBnBwdArgs a, int s
       be[j] = zmask ? a.beta[c + j] - mu[j] * rs[j] : 0.f;
     }
     const int64_t stride = (int64_t)gridDim.x * VPB;
-    for (int64_t v = (int64_t)blockIdx.x * VPB + vr; v < a.V; v += stride) {
-      const u32x4 gp = ld16(a.dy + v * a.dycs + c), zp = ld16(a.z + v * a.zcs + c);
-      u32x4 yp, z2p;
-      if (ymask) yp = ld16(a.y + v * a.ycs + c);
-      if (a.z2) z2p = ld16(a.z2 + v * a.z2cs + c);
-      float g[8], z[8], y[8], z2[8];
-      unpack8(gp, g); unpack8(zp, z);
-      if (ymask) unpack8(yp, y);
-      if (a.z2) unpack8(z2p, z2);
+    constexpr int U = 4;   // voxels in flight per thread (all loads issued before the first use)
+    for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += U * stride) {
+      u32x4 gp[U], zp[U], yp[U], z2p[U];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float gj = g[j];
-        if (ymask && !(y[j] > 0.f)) gj = 0.f;
-        if (zmask && !(fmaf(z[j], rs[j], be[j]) > 0.f)) gj = 0.f;
-        const double gd = (double)gj;
-        acc[0][j] += gd;
-        acc[1][j] += gd * (double)((z[j] - mu[j]) * rs[j]);
-        if (a.z2) acc[2][j] += gd * (double)((z2[j] - mu2[j]) * rs2[j]);
+      for (int u = 0; u < U; ++u) {
+        const int64_t v = v0 + u * stride;
+        if (v < a.V) {
+          gp[u] = ld16(a.dy + v * a.dycs + c);
+          zp[u] = ld16(a.z + v * a.zcs + c);
+          if (ymask) yp[u] = ld16(a.y + v * a.ycs + c);
+          if (a.z2) z2p[u] = ld16(a.z2 + v * a.z2cs + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (v0 + u * stride >= a.V) continue;
+        float g[8], z[8], y[8], z2[8];
+        unpack8(gp[u], g); unpack8(zp[u], z);
+        if (ymask) unpack8(yp[u], y);
+        if (a.z2) unpack8(z2p[u], z2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float gj = g[j];
+          if (ymask && !(y[j] > 0.f)) gj = 0.f;
+          if (zmask && !(fmaf(z[j], rs[j], be[j]) > 0.f)) gj = 0.f;
+          const double gd = (double)gj;
+          acc[0][j] += gd;
+          acc[1][j] += gd * (double)((z[j] - mu[j]) * rs[j]);
+          if (a.z2) acc[2][j] += gd * (double)((z2[j] - mu2[j]) * rs2[j]);
+        }
       }
     }
   }
@@ -151,29 +164,42 @@ __global__ __launch_bounds__(256) void bbn_bwd_apply_kernel(BBnBwdArgs a, int sh
     mg[j] = (float)finals[c + j]; mgx[j] = (float)finals[a.C + c + j]; mgx2[j] = (float)finals[2 * a.C + c + j];
   }
   const int64_t stride = (int64_t)gridDim.x * VPB;
-  for (int64_t v = (int64_t)blockIdx.x * VPB + vr; v < a.V; v += stride) {
-    const u32x4 gp = ld16(a.dy + v * a.dycs + c), zp = ld16(a.z + v * a.zcs + c);
-    u32x4 yp, z2p, drp;
-    if (ymask) yp = ld16(a.y + v * a.ycs + c);
-    if (a.z2) z2p = ld16(a.z2 + v * a.z2cs + c);
-    if (a.dres && a.dres_accumulate) drp = ld16(a.dres + v * a.drescs + c);
-    float g[8], z[8], y[8], z2[8], dr[8], dz[8], dz2[8];
-    unpack8(gp, g); unpack8(zp, z);
-    if (ymask) unpack8(yp, y);
-    if (a.z2) unpack8(z2p, z2);
-    if (a.dres && a.dres_accumulate) unpack8(drp, dr);
+  constexpr int U = 4;
+  for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += U * stride) {
+    u32x4 gp[U], zp[U], yp[U], z2p[U], drp[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float gj = g[j];
-      if (ymask && !(y[j] > 0.f)) gj = 0.f;
-      if (zmask && !(fmaf(z[j], rs[j], be[j]) > 0.f)) gj = 0.f;
-      dz[j] = rs[j] * (gj - mg[j] - (z[j] - mu[j]) * rs[j] * mgx[j]);
-      if (a.z2) dz2[j] = rs2[j] * (gj - mg[j] - (z2[j] - mu2[j]) * rs2[j] * mgx2[j]);
-      if (a.dres) dr[j] = a.dres_accumulate ? dr[j] + gj : gj;
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * stride;
+      if (v < a.V) {
+        gp[u] = ld16(a.dy + v * a.dycs + c);
+        zp[u] = ld16(a.z + v * a.zcs + c);
+        if (ymask) yp[u] = ld16(a.y + v * a.ycs + c);
+        if (a.z2) z2p[u] = ld16(a.z2 + v * a.z2cs + c);
+        if (a.dres && a.dres_accumulate) drp[u] = ld16(a.dres + v * a.drescs + c);
+      }
     }
-    *(u32x4*)(a.dz + v * a.dzcs + c) = pack8(dz);
-    if (a.z2) *(u32x4*)(a.dz2 + v * a.dz2cs + c) = pack8(dz2);
-    if (a.dres) *(u32x4*)(a.dres + v * a.drescs + c) = pack8(dr);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * stride;
+      if (v >= a.V) continue;
+      float g[8], z[8], y[8], z2[8], dr[8], dz[8], dz2[8];
+      unpack8(gp[u], g); unpack8(zp[u], z);
+      if (ymask) unpack8(yp[u], y);
+      if (a.z2) unpack8(z2p[u], z2);
+      if (a.dres && a.dres_accumulate) unpack8(drp[u], dr);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float gj = g[j];
+        if (ymask && !(y[j] > 0.f)) gj = 0.f;
+        if (zmask && !(fmaf(z[j], rs[j], be[j]) > 0.f)) gj = 0.f;
+        dz[j] = rs[j] * (gj - mg[j] - (z[j] - mu[j]) * rs[j] * mgx[j]);
+        if (a.z2) dz2[j] = rs2[j] * (gj - mg[j] - (z2[j] - mu2[j]) * rs2[j] * mgx2[j]);
+        if (a.dres) dr[j] = a.dres_accumulate ? dr[j] + gj : gj;
+      }
+      *(u32x4*)(a.dz + v * a.dzcs + c) = pack8(dz);
+      if (a.z2) *(u32x4*)(a.dz2 + v * a.dz2cs + c) = pack8(dz2);
+      if (a.dres) *(u32x4*)(a.dres + v * a.drescs + c) = pack8(dr);
+    }
   }
 }
 

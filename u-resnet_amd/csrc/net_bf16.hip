@@ -9,6 +9,7 @@
 //   * weight gradients run on a second stream beside the data-gradient / BatchNorm chain (they only feed the optimiser).
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -503,6 +504,8 @@ int bnet_create(const ursn_config* cfg, float* params, float* grads, void* works
   n->params = params; n->grads = grads;
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  const char* e2 = getenv("URSN_WGRAD_STREAM");
+  if (e2 && e2[0] == '0') { *out = n; return 0; }   // weight gradients on the caller's stream (per-kernel profiling)
   if (hipStreamCreateWithPriority(&n->s2, hipStreamNonBlocking, lo) != hipSuccess ||
       hipEventCreateWithFlags(&n->s2_done, hipEventDisableTiming) != hipSuccess) {
     ursn_set_error("create: could not create the weight-gradient stream");

@@ -183,6 +183,7 @@ int launch_tiled_deconv(const ursn_conv_desc& d, ConvPass pass, const float* in,
 int tiled_deconv_blocks(const ursn_conv_desc& d, ConvPass pass);
 // z-segment choice of the marching kernels (conv_tiled.hip): minimises rounds x (segment + prologue)
 void ursn_pick_zseg(int64_t base, int Z, int occ, int min_seg, int& zseg, int& nzseg);
+int ursn_cu_count();
 // LDS-staged stride-2 scatter-type conv for channel counts that are multiples of 16 (deconv_lds.hip)
 int lds_scatter_supported(const ursn_conv_desc& d, ConvPass pass);
 size_t lds_scatter_stats_scratch_doubles(const ursn_conv_desc& d);
