@@ -391,41 +391,44 @@ static bool bconv_plan(const GatherGeom& g, BPlan& p) {
   }
   const int ncand = (int)(sizeof(cand) / sizeof(cand[0]));
   const size_t wbytes = (size_t)p.nj * p.cot * 64 * 16;
+  // per box candidate (largest first): two input buffers (the next stage lands while this one computes), else one (the
+  // co-resident workgroups hide the staging latency); first within half the LDS (two workgroups per CU), then all of it
   const size_t limits[2] = {lds_cap, 158 * 1024};
   for (size_t limit : limits) {
     BPlan fit;
     bool have = false;
-    for (int ci = 0; ci < ncand; ++ci) {
-      BPlan c = p;
-      int bq[3] = {cand[ci][0], cand[ci][1], cand[ci][2]};
-      if (g.q_d[0] == 1) { bq[1] *= bq[0]; bq[0] = 1; }          // 2-D problems: all rows in y
-      for (int j = 0; j < 3; ++j) {
-        c.bq[j] = bq[j];
-        c.hb[j] = (bq[j] - 1) * g.si[j] + (dmax[j] - p.dmin[j]) + 1;
-        c.nb[j] = (g.q_d[j] + bq[j] - 1) / bq[j];
+    for (int ci = 0; ci < ncand; ++ci)
+      for (int nbuf = (nbuf_env == 1 ? 1 : 2); nbuf >= 1; --nbuf) {
+        BPlan c = p;
+        int bq[3] = {cand[ci][0], cand[ci][1], cand[ci][2]};
+        if (g.q_d[0] == 1) { bq[1] *= bq[0]; bq[0] = 1; }          // 2-D problems: all rows in y
+        for (int j = 0; j < 3; ++j) {
+          c.bq[j] = bq[j];
+          c.hb[j] = (bq[j] - 1) * g.si[j] + (dmax[j] - p.dmin[j]) + 1;
+          c.nb[j] = (g.q_d[j] + bq[j] - 1) / bq[j];
+        }
+        const int nq = c.bq[0] * c.bq[1] * c.bq[2];
+        c.vt = nq / 64;
+        c.pp = (c.hb[1] * c.hb[2] * (c.cinc / 8) + 255) & ~255;   // pieces per plane, padded
+        if (c.pp > 256 * BCONV_PMAX) continue;
+        c.stage_bytes = c.hb[0] * c.pp * 16;
+        c.nbuf = nbuf;
+        c.lds = (size_t)c.nbuf * c.stage_bytes + ((c.nchunks > 1 && c.nbuf > 1) ? 2 : 1) * wbytes;
+        const int64_t boxes = (int64_t)g.N * c.nb[0] * c.nb[1] * c.nb[2];
+        if (c.lds > limit || boxes <= 0 || boxes >= (1ll << 30)) continue;
+        c.nboxes = (int)boxes;
+        int64_t occ = (int64_t)(160 * 1024) / (c.lds + 2048);
+        if (occ > 8) occ = 8;
+        if (occ < 1) occ = 1;
+        int64_t wg = (int64_t)ursn_cu_count() * occ / c.ncob;   // persistent workgroups: every resident slot
+        if (wg < 1) wg = 1;
+        if (wg > boxes) wg = boxes;
+        c.per = (int)((boxes + wg - 1) / wg);
+        c.gridx = (int)((boxes + c.per - 1) / c.per);
+        fit = c;
+        have = true;
+        if (boxes * c.ncob >= 512) { p = c; return true; }
       }
-      const int nq = c.bq[0] * c.bq[1] * c.bq[2];
-      c.vt = nq / 64;
-      c.pp = (c.hb[1] * c.hb[2] * (c.cinc / 8) + 255) & ~255;   // pieces per plane, padded
-      if (c.pp > 256 * BCONV_PMAX) continue;
-      c.stage_bytes = c.hb[0] * c.pp * 16;
-      c.nbuf = nbuf_env;
-      c.lds = (size_t)c.nbuf * c.stage_bytes + ((c.nchunks > 1 && c.nbuf > 1) ? 2 : 1) * wbytes;
-      const int64_t boxes = (int64_t)g.N * c.nb[0] * c.nb[1] * c.nb[2];
-      if (c.lds > limit || boxes <= 0 || boxes >= (1ll << 30)) continue;
-      c.nboxes = (int)boxes;
-      int64_t occ = (int64_t)(160 * 1024) / (c.lds + 1024);
-      if (occ > 8) occ = 8;
-      if (occ < 1) occ = 1;
-      int64_t wg = (int64_t)ursn_cu_count() * occ / c.ncob;   // persistent workgroups: every resident slot
-      if (wg < 1) wg = 1;
-      if (wg > boxes) wg = boxes;
-      c.per = (int)((boxes + wg - 1) / wg);
-      c.gridx = (int)((boxes + c.per - 1) / c.per);
-      fit = c;
-      have = true;
-      if (boxes * c.ncob >= 512) { p = c; return true; }
-    }
     if (have) { p = fit; return true; }
   }
   }   // next (smaller) chunk

@@ -3,7 +3,13 @@
 // counts that are multiples of 8, so a thread moves one 16-byte piece (8 channels of one voxel) per access.
 // Thread mapping: CP = next_pow2(C / 8) channel pieces per voxel, 256 / CP voxels per block iteration, a thread keeps its
 // channel piece for the whole kernel (per-channel parameters and sums live in registers).
+#include <stdlib.h>
+
 #include "bf16_common.h"
+
+#ifndef URSN_BEW_U
+#define URSN_BEW_U 4
+#endif
 
 namespace {
 
@@ -16,8 +22,9 @@ BMap make_bmap(int64_t V, int C) {
   m.shift = 0;
   while ((1 << m.shift) < cp) ++m.shift;
   const int vpb = 256 >> m.shift;
+  static const int cap = getenv("URSN_BEW_GRID") ? atoi(getenv("URSN_BEW_GRID")) : 2048;
   int64_t blocks = cdiv64(V, (int64_t)vpb * 8);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   m.grid = (int)blocks;
   return m;
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(256) void bbn_act_kernel(BBnActArgs a, int shift) {
     sh2[j] = a.z2 ? a.beta2[c + j] - a.mean2[c + j] * sc2[j] : 0.f;
   }
   const int64_t stride = (int64_t)gridDim.x * VPB;
-  constexpr int U = 4;
+  constexpr int U = URSN_BEW_U;
   for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += U * stride) {
     u32x4 x[U], x2[U], r[U];
 #pragma unroll
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256) void bbn_bwd_reduce_kernel(BBnBwdArgs a, int s
       be[j] = zmask ? a.beta[c + j] - mu[j] * rs[j] : 0.f;
     }
     const int64_t stride = (int64_t)gridDim.x * VPB;
-    constexpr int U = 4;   // voxels in flight per thread (all loads issued before the first use)
+    constexpr int U = URSN_BEW_U;   // voxels in flight per thread (all loads issued before the first use)
     for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += U * stride) {
       u32x4 gp[U], zp[U], yp[U], z2p[U];
 #pragma unroll
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void bbn_bwd_apply_kernel(BBnBwdArgs a, int sh
     mg[j] = (float)finals[c + j]; mgx[j] = (float)finals[a.C + c + j]; mgx2[j] = (float)finals[2 * a.C + c + j];
   }
   const int64_t stride = (int64_t)gridDim.x * VPB;
-  constexpr int U = 4;
+  constexpr int U = URSN_BEW_U;
   for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += U * stride) {
     u32x4 gp[U], zp[U], yp[U], z2p[U], drp[U];
 #pragma unroll
