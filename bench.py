@@ -282,6 +282,28 @@ def main():
         elapsed = float(t.item())
     metrics = net.read_metrics()
 
+    # the non-conv parts of the step, each timed alone (SURVEY.md 8d: Adam and the all-reduce reported separately)
+    def timed_ms(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        tt = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - tt) / reps * 1e3
+    parts = {"zero_gradients_ms": round(timed_ms(lambda: net.zero_gradients(None)), 4),
+             "allreduce_ms": round(timed_ms(net.allreduce_gradients), 4) if world > 1 else 0.0}
+    # Adam last (it moves the weights; the bench is over): gradient buffer zeroed so the update is a pure decay of m, v
+    net.zero_gradients(None)
+    parts["adam_ms"] = round(timed_ms(lambda: _lib.check(lib.ursn_apply_adam(net._handle, 1e-4, None))), 4)
+
+    # per-launch HIP-event records of the timed region (rank 0)
+    cnt = ctypes.c_int64(0)
+    _lib.check(lib.ursn_profile_read(net._handle, None, 0, ctypes.byref(cnt)))
+    nrec = 1 << 20
+    recs = (_lib.ursn_prof_rec * nrec)()
+    _lib.check(lib.ursn_profile_read(net._handle, recs, nrec, ctypes.byref(cnt)))
+    _lib.check(lib.ursn_profile_enable(net._handle, 0))
     host_feed = None
     if args.host_feed:
         # the same step fed from host memory every iteration (lib/ssnet_trainval.py:167-188 hands over host buffers):
@@ -314,28 +336,6 @@ def main():
                      "h2d_ms_alone": round(ev0.elapsed_time(ev1), 3),
                      "note": "pinned source buffers, copy stream, H2D of step k+1 overlaps the kernels of step k"}
 
-    # the non-conv parts of the step, each timed alone (SURVEY.md 8d: Adam and the all-reduce reported separately)
-    def timed_ms(fn, reps=5):
-        fn()
-        torch.cuda.synchronize()
-        tt = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - tt) / reps * 1e3
-    parts = {"zero_gradients_ms": round(timed_ms(lambda: net.zero_gradients(None)), 4),
-             "allreduce_ms": round(timed_ms(net.allreduce_gradients), 4) if world > 1 else 0.0}
-    # Adam last (it moves the weights; the bench is over): gradient buffer zeroed so the update is a pure decay of m, v
-    net.zero_gradients(None)
-    parts["adam_ms"] = round(timed_ms(lambda: _lib.check(lib.ursn_apply_adam(net._handle, 1e-4, None))), 4)
-
-    # per-launch HIP-event records of the timed region (rank 0)
-    cnt = ctypes.c_int64(0)
-    _lib.check(lib.ursn_profile_read(net._handle, None, 0, ctypes.byref(cnt)))
-    nrec = 1 << 20
-    recs = (_lib.ursn_prof_rec * nrec)()
-    _lib.check(lib.ursn_profile_read(net._handle, recs, nrec, ctypes.byref(cnt)))
-    _lib.check(lib.ursn_profile_enable(net._handle, 0))
     by_kernel, t_roof_ms, conv_flops, conv_bytes, all_ms = {}, 0.0, 0.0, 0.0, 0.0
     by_layer = {}
     for i in range(cnt.value):

@@ -1,4 +1,4 @@
-"""Aggregates gpurun_out/pmc_traffic/{FETCH_SIZE,WRITE_SIZE} (tools/pmc_traffic.sh) into profiles/r01_pmc_traffic_cfg3.csv and
+"""Aggregates gpurun_out/pmc_traffic/{FETCH_SIZE,WRITE_SIZE} (tools/pmc_traffic.sh) into profiles/r02_pmc_traffic_cfg3.csv and
 profiles/pmc_traffic.json (bench.py reads the latter for roofline.traffic).  gfx950: FETCH_SIZE counts 64 B per 128-B
 request for wide coalesced loads (MI355X_MICROARCH.md) -> hbm_bytes = 2 * fetch + write."""
 import collections
@@ -34,7 +34,7 @@ for k in sorted(vals["FETCH_SIZE"], key=lambda k: -sum(vals["FETCH_SIZE"][k])):
     for pat, lab in LABEL:
         if re.search(pat, k) and lab not in out:
             out[lab] = {"launches": len(f), "fetch_kib_raw": fa, "write_kib": wa, "hbm_bytes_per_launch": (2 * fa + wa) * 1024}
-with open("profiles/r01_pmc_traffic_cfg3.csv", "w") as fh:
+with open("profiles/r02_pmc_traffic_cfg3.csv", "w") as fh:
     fh.write("kernel,launches,FETCH_SIZE_KiB_raw_per_launch,WRITE_SIZE_KiB_per_launch\n")
     for k, n, fa, wa in rows:
         fh.write('"%s",%d,%s,%s\n' % (k, n, fa, wa))
