@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define URSN_ABI_VERSION 4
+#define URSN_ABI_VERSION 5
 
 typedef struct ursn_net ursn_net; /* opaque */
 
@@ -196,6 +196,26 @@ typedef struct ursn_conv_desc {
   const float* in_mean;
   const float* in_rstd;
   const float* in_beta;
+  /* Data gradient only: the BatchNorm-backward reductions of the layer(s) whose INPUT gradient this call finishes, fused
+   * into its epilogue (slim.batch_norm backward, lib/resnet_module.py:31,49,64: dz = r (g - mean g - xhat mean(g xhat))):
+   * with g = dx * mask, bs_partial[block][0][c] = sum g, [1][c] = sum g * xhat(bs_z), [2][c] = sum g * xhat(bs_z2) over the
+   * voxels of the block, ursn_conv_bs_blocks(d) blocks of 3 * cin doubles.  bs_relu: 0 no mask, 1 mask = bn(bs_z) > 0 (needs
+   * bs_beta), 2 mask = the bit mask a residual join's forward wrote (bs_mask).  bs_z2 (optional): the second BatchNorm'd
+   * branch of a residual join.  With a split input the reductions cover dx (the first tensor) only.
+   * bs_partial = NULL: none.  3-D k3 s1 tiled kernels with 8 input channels per tensor only.                              */
+  const float* bs_z;
+  const float* bs_mean;
+  const float* bs_rstd;
+  const float* bs_beta;
+  const float* bs_z2;
+  const float* bs_mean2;
+  const float* bs_rstd2;
+  const void* bs_mask;
+  double* bs_partial;
+  int32_t bs_z_cstride;  /* 0 = compact */
+  int32_t bs_z2_cstride;
+  int32_t bs_relu;
+  int32_t reserved2_;
 } ursn_conv_desc;
 
 /* y = conv(x, w).  w layout [k..,Cin,Cout] (transposed: [k..,Cout,Cin]). */
@@ -211,6 +231,8 @@ int ursn_conv_backward_data(const ursn_conv_desc* d, const float* dy, const floa
 int ursn_conv_backward_weight(const ursn_conv_desc* d, const float* x, const float* dy, float* dw,
                               void* scratch, size_t scratch_bytes, void* stream);
 size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d);
+/* Blocks of bs_partial a data-gradient call with fused BatchNorm-backward reductions writes (0: shape not supported). */
+int32_t ursn_conv_bs_blocks(const ursn_conv_desc* d);
 
 /* Batch-statistics BatchNorm (beta only) + optional residual + optional ReLU:
  * y = act((z-mu)*rsqrt(var+eps)+beta [+ res]); stats_out (optional) gets {mean[C], rstd[C]} as fp32. */

@@ -789,3 +789,90 @@ def test_fused_statistics_with_large_mean_to_std_ratio(case, ratio):
     # the fp32 output itself is exact here; what is left is the rounding of the fp32 mean (ulp(mean)/std)
     assert e_mu < 1e-7 * ratio + 1e-5
     assert e_rs < 1e-4
+
+
+def _join_mask_words(keep):
+    """The bit mask a residual join's forward pass writes for an 8-channel tensor: every 32 voxels (256 elements) take four
+    64-bit words; channel 4*q+j of voxel v is bit (v % 32) * 2 + q of word (v // 32) * 4 + j (include/uresnet_hip.h)."""
+    k = keep.reshape(-1, 8)
+    V = k.shape[0]
+    words = np.zeros(((V + 31) // 32) * 4, dtype=np.uint64)
+    for q in range(2):
+        for j in range(4):
+            idx = np.nonzero(k[:, 4 * q + j])[0]
+            np.bitwise_or.at(words, (idx // 32) * 4 + j, np.uint64(1) << ((idx % 32) * 2 + q).astype(np.uint64))
+    return words
+
+
+@pytest.mark.parametrize("co,split,relu,two", [(8, False, 0, False), (8, False, 1, False), (8, False, 2, True),
+                                               (8, False, 2, False), (3, False, 1, False), (8, True, 1, False)])
+@pytest.mark.parametrize("S", [(8, 16, 32), (9, 11, 37)])
+def test_data_gradient_with_fused_bn_backward_reductions(S, co, split, relu, two):
+    """The data gradient of a 3^3 conv is the LAST contribution to d(input); the BatchNorm backward of the layer(s) that
+    produced that input starts with sum g, sum g*xhat(, sum g*xhat2), g = dx * relu mask (lib/resnet_module.py:43-60 under
+    tf.gradients).  ursn_conv_desc.bs_* takes those sums in the data-gradient kernel's epilogue."""
+    N, ci = 2, 16 if split else 8
+    rng = np.random.default_rng(S[2] + co + 7 * relu + two)
+    x_shape = (N,) + S + (ci,)
+    w = _rand(rng, (3, 3, 3, ci, co)) * 0.2
+    dy = _rand(rng, (N,) + S + (co,))
+    dx = O.conv_bwd(np.zeros(x_shape), w, 1, dy)[0]
+    z, z2 = _rand(rng, (N,) + S + (8,)) * 1.5 + 0.3, _rand(rng, (N,) + S + (8,)) * 0.7 - 0.2
+    ax = (0, 1, 2, 3)
+    mean, rstd = z.mean(axis=ax), 1.0 / np.sqrt(z.var(axis=ax) + 1e-3)
+    mean2, rstd2 = z2.mean(axis=ax), 1.0 / np.sqrt(z2.var(axis=ax) + 1e-3)
+    beta = _rand(rng, (8,)) * 0.3
+    f32 = lambda a: np.asarray(a, dtype=np.float32)   # noqa: E731
+    if relu == 1:   # the kernel's own expression in fp32, so that the two sides agree on borderline elements
+        keep = (f32(z) * f32(rstd) + (f32(beta) - f32(mean) * f32(rstd))) > 0
+    elif relu == 2:
+        keep = rng.random(z.shape) < 0.6
+    else:
+        keep = np.ones(z.shape, dtype=bool)
+    pc = (co + 3) // 4 * 4   # the logits layer's gradient buffer is padded to 4 channels
+    dyp = np.zeros(dy.shape[:-1] + (pc,))
+    dyp[..., :co] = dy
+    wg, dyg, zg, z2g = dev(w), dev(dyp), dev(z), dev(z2)
+    mg_, rg_, bg_, m2g, r2g = dev(mean), dev(rstd), dev(beta), dev(mean2), dev(rstd2)
+    maskg = torch.from_numpy(_join_mask_words(keep).view(np.int64)).cuda()
+    lib = _lib.load()
+    d = desc(3, N, S, ci, co, 3, 1, out_cs=pc)
+    d.bs_z, d.bs_mean, d.bs_rstd, d.bs_beta, d.bs_z_cstride = zg.data_ptr(), mg_.data_ptr(), rg_.data_ptr(), bg_.data_ptr(), 8
+    d.bs_relu = relu
+    if relu == 2:
+        d.bs_mask = maskg.data_ptr()
+    if two:
+        d.bs_z2, d.bs_mean2, d.bs_rstd2, d.bs_z2_cstride = z2g.data_ptr(), m2g.data_ptr(), r2g.data_ptr(), 8
+    if split:
+        d.in_split, d.in_cstride, d.in2_cstride = 8, 8, 8
+    nb = lib.ursn_conv_bs_blocks(ctypes.byref(d))
+    assert nb > 0
+    for acc in (0, 1):
+        partial = torch.full((nb, 3, 8), float("nan"), dtype=torch.float64, device="cuda")
+        d.bs_partial = partial.data_ptr()
+        base = _rand(rng, x_shape) if acc else np.zeros(x_shape)
+        if split:
+            dxa, dxb = dev(base[..., :8]), dev(base[..., 8:])
+            d.dx2 = dxb.data_ptr()
+            _lib.check(lib.ursn_conv_backward_data(ctypes.byref(d), P(dyg), P(wg), P(dxa), acc, stream()))
+            torch.cuda.synchronize()
+            got = np.concatenate([dxa.cpu().numpy(), dxb.cpu().numpy()], axis=-1)
+        else:
+            got = conv_backward_data(d, dyg, wg, x_shape, accumulate=acc, dx_init=dev(base)).cpu().numpy()
+        want = dx + base
+        assert rel_err(got, want) < TOL
+        g = want[..., :8] * keep
+        sums = partial.cpu().numpy().sum(axis=0)
+        ref = np.stack([g.sum(axis=ax), (g * (z - mean) * rstd).sum(axis=ax), (g * (z2 - mean2) * rstd2).sum(axis=ax)])
+        scale = np.abs(g).sum(axis=ax).max()
+        assert np.abs(sums[:2] - ref[:2]).max() < 1e-6 * scale
+        if two:
+            assert np.abs(sums[2] - ref[2]).max() < 1e-6 * scale
+    # no kernel with this epilogue for 2-D layers or other channel counts: the query says so and the call is refused
+    d2 = desc(2, N, S[1:], 8, 8, 3, 1)
+    d2.bs_z, d2.bs_mean, d2.bs_rstd, d2.bs_z_cstride, d2.bs_partial = zg.data_ptr(), mg_.data_ptr(), rg_.data_ptr(), 8, partial.data_ptr()
+    assert lib.ursn_conv_bs_blocks(ctypes.byref(d2)) == 0
+    dxx = torch.empty((N,) + S[1:] + (8,), dtype=torch.float32, device="cuda")
+    dy2 = torch.zeros((N,) + S[1:] + (8,), dtype=torch.float32, device="cuda")
+    w2 = torch.zeros((3, 3, 8, 8), dtype=torch.float32, device="cuda")
+    assert lib.ursn_conv_backward_data(ctypes.byref(d2), P(dy2), P(w2), P(dxx), 0, stream()) != 0

@@ -35,7 +35,11 @@ class ursn_conv_desc(C.Structure):
                 ("in_cstride", C.c_int32), ("out_cstride", C.c_int32), ("algo", C.c_int32),
                 ("in_split", C.c_int32), ("in2_cstride", C.c_int32), ("x2", C.c_void_p), ("dx2", C.c_void_p),
                 ("pw_dy", C.c_void_p), ("pw_w", C.c_void_p), ("pw_dy_cstride", C.c_int32), ("dtype", C.c_int32),
-                ("in_mean", C.c_void_p), ("in_rstd", C.c_void_p), ("in_beta", C.c_void_p)]
+                ("in_mean", C.c_void_p), ("in_rstd", C.c_void_p), ("in_beta", C.c_void_p),
+                ("bs_z", C.c_void_p), ("bs_mean", C.c_void_p), ("bs_rstd", C.c_void_p), ("bs_beta", C.c_void_p),
+                ("bs_z2", C.c_void_p), ("bs_mean2", C.c_void_p), ("bs_rstd2", C.c_void_p), ("bs_mask", C.c_void_p),
+                ("bs_partial", C.c_void_p), ("bs_z_cstride", C.c_int32), ("bs_z2_cstride", C.c_int32),
+                ("bs_relu", C.c_int32), ("reserved2_", C.c_int32)]
 
 
 class ursn_prof_rec(C.Structure):
@@ -73,6 +77,7 @@ _SIGS = {
     "ursn_conv_backward_data": (C.c_int, [C.POINTER(ursn_conv_desc), _P, _P, _P, C.c_int32, _P]),
     "ursn_conv_backward_weight": (C.c_int, [C.POINTER(ursn_conv_desc), _P, _P, _P, _P, C.c_size_t, _P]),
     "ursn_conv_wgrad_scratch_bytes": (C.c_size_t, [C.POINTER(ursn_conv_desc)]),
+    "ursn_conv_bs_blocks": (C.c_int32, [C.POINTER(ursn_conv_desc)]),
     "ursn_bn_forward": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, C.c_int32, _P, _P,
                                   C.c_size_t, _P]),
     "ursn_bn_backward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, C.c_int32, _P,
@@ -86,7 +91,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS.keys())
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

@@ -229,6 +229,10 @@ int launch_tiled_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, c
 
 int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out, int accumulate,
                   hipStream_t s) {
+  if (d.bs_partial) {   // fused BatchNorm-backward reductions: tiled data-gradient kernels only
+    URSN_REQUIRE(pass == PASS_DGRAD && tiled_conv_supported(d, pass), "conv: fused BatchNorm-backward reductions (bs_partial) not supported for this shape / pass");
+    return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
+  }
   if (d.in_mean && pass != PASS_DGRAD) {   // normalise-on-load: tiled kernels only (the data gradient does not read x)
     URSN_REQUIRE(d.in_rstd && d.in_beta && tiled_conv_supported(d, pass), "conv: normalise-on-load (in_mean) not supported for this shape / pass");
     return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
@@ -396,6 +400,8 @@ int tiled_wgrad_supported(const ursn_conv_desc& d);
 size_t tiled_wgrad_scratch_bytes(const ursn_conv_desc& d);
 int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
                        size_t scratch_bytes, hipStream_t s);
+
+extern "C" int32_t ursn_conv_bs_blocks(const ursn_conv_desc* d) { return d ? tiled_conv_bs_blocks(*d) : 0; }
 
 extern "C" size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d) {
   if (!d) return 0;

@@ -155,7 +155,19 @@ int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass) {
   // dropped half of the term)
   if (d.pw_dy && !(pass == PASS_DGRAD && p.cin <= 16 && b.nbi == 1)) return 0;
   if (d.in_mean && pass == PASS_FWD && (b.nbi > 1 || b.nbo > 1 || p.cin != p.cout || !(p.cin == 8 || p.cin == 16))) return 0;   // normalise-on-load: 8->8 / 16->16
+  // fused BatchNorm-backward reductions: 3-D data gradients producing 8 channels (per tensor of a split input) from 4 | 8
+  if (d.bs_partial && !(pass == PASS_DGRAD && p.mode == 3 && p.cout == 8 && (p.cin == 8 || p.cin == 4) && b.nbi == 1 &&
+                        (b.nbo == 1 || b.split))) return 0;
   return 1;
+}
+
+int tiled_conv_bs_blocks(const ursn_conv_desc& d) {
+  ursn_conv_desc t = d;
+  t.bs_partial = (double*)1;   // only "non-null" matters for the support check
+  TPlan p;
+  Blocking b;
+  if (!make_plan(t, PASS_DGRAD, p, b) || !tiled_conv_supported(t, PASS_DGRAD)) return 0;
+  return p.grid;
 }
 
 // doubles of scratch the fused-statistics forward needs
@@ -180,6 +192,12 @@ static int launch_blocks(const ursn_conv_desc& d, const TPlan& p, const Blocking
   a.cin_w = d.cin; a.cout_w = d.cout;
   a.pw_in = nullptr; a.pw_w = nullptr; a.pw_in_cs = d.pw_dy_cstride > 0 ? d.pw_dy_cstride : d.cout; a.pw_ws = d.cout;
   a.aff_mean = a.aff_rstd = a.aff_beta = nullptr;
+  a.bs_z = a.bs_mean = a.bs_rstd = a.bs_beta = a.bs_z2 = a.bs_mean2 = a.bs_rstd2 = nullptr;
+  a.bs_mask = nullptr; a.bs_partial = nullptr; a.bs_z_cs = a.bs_z2_cs = 0; a.bs_relu = 0;
+  if (d.bs_partial) {
+    URSN_REQUIRE(p.flip && d.bs_z && d.bs_mean && d.bs_rstd && (d.bs_relu != 1 || d.bs_beta) && (d.bs_relu != 2 || d.bs_mask) &&
+                 (!d.bs_z2 || (d.bs_mean2 && d.bs_rstd2)), "tiled conv: incomplete fused BatchNorm-backward arguments");
+  }
   if (d.in_mean && !p.flip) {
     URSN_REQUIRE(b.nbi == 1 && b.nbo == 1 && d.in_rstd && d.in_beta, "tiled conv: normalise-on-load needs a native 8 / 16 channel shape");
     a.aff_mean = d.in_mean; a.aff_rstd = d.in_rstd; a.aff_beta = d.in_beta;
@@ -203,6 +221,13 @@ static int launch_blocks(const ursn_conv_desc& d, const TPlan& p, const Blocking
       if (d.pw_dy && bi == 0) { a.pw_in = d.pw_dy; a.pw_w = d.pw_w + (size_t)b.bsz * bo * d.cout; }   // once per produced block
       else a.pw_in = nullptr;
       a.stats_partial = (stats_partial && last) ? stats_partial : nullptr;
+      a.bs_partial = nullptr;
+      if (d.bs_partial && bo == 0 && last) {   // the reductions belong to the first produced tensor, once its value is final
+        a.bs_partial = d.bs_partial; a.bs_z = d.bs_z; a.bs_mean = d.bs_mean; a.bs_rstd = d.bs_rstd; a.bs_beta = d.bs_beta;
+        a.bs_z2 = d.bs_z2; a.bs_mean2 = d.bs_mean2; a.bs_rstd2 = d.bs_rstd2; a.bs_mask = (const unsigned long long*)d.bs_mask;
+        a.bs_z_cs = d.bs_z_cstride > 0 ? d.bs_z_cstride : 8; a.bs_z2_cs = d.bs_z2_cstride > 0 ? d.bs_z2_cstride : 8;
+        a.bs_relu = d.bs_relu;
+      }
       URSN_TRY(p.mode == 3 ? tconv_dispatch_3d(p, a, s) : tconv_dispatch_2d(p, a, s));
       if (stats_partial && last) {
         int cb = (b.nbo > 1) ? b.bsz : real_out;  // real channels produced by this block
@@ -210,7 +235,11 @@ static int launch_blocks(const ursn_conv_desc& d, const TPlan& p, const Blocking
                                        a.out, a.out_cs));
       }
     }
-  if (b.split) ursn_relabel_kernel(p.flip ? "tconv_dgrad x2(split)" : "tconv x2(split)");
+  if (d.bs_partial) {   // own lines in the per-kernel breakdown: the epilogue is not free
+    if (b.split) ursn_relabel_kernel("tconv_dgrad x2(split)+bnred");
+    else if (p.cin == 4) ursn_relabel_kernel("tconv_dgrad<4,8>+bnred");
+    else ursn_relabel_kernel(d.bs_z2 ? "tconv_dgrad<8,8>+bnred2" : (d.bs_relu == 2 ? "tconv_dgrad<8,8>+bnred(mask)" : "tconv_dgrad<8,8>+bnred"));
+  } else if (b.split) ursn_relabel_kernel(p.flip ? "tconv_dgrad x2(split)" : "tconv x2(split)");
   else if (b.nbi > 1 || b.nbo > 1) ursn_relabel_kernel(p.flip ? "tconv_dgrad<16,16>xB" : "tconv<16,16>xB");
   return 0;
 }

@@ -59,6 +59,15 @@ struct TConvArgs {
   const float* aff_mean;
   const float* aff_rstd;
   const float* aff_beta;
+  // data gradient only (BS instantiations): BatchNorm-backward reductions of the layer(s) whose input gradient this launch
+  // FINISHES, fused into the epilogue (the separate bn_bwd_reduce pass read this tensor and z again):
+  //   g = out * mask;  partial[block][0][c] = sum g, [1][c] = sum g * xhat(z), [2][c] = sum g * xhat2(z2)
+  // mask: none (bs_relu 0) | bn(z) > 0 recomputed with bs_beta (1) | the join's bit mask as written by bn_act (2)
+  const float* bs_z;  const float* bs_mean;  const float* bs_rstd;  const float* bs_beta;
+  const float* bs_z2; const float* bs_mean2; const float* bs_rstd2;
+  const unsigned long long* bs_mask;
+  double* bs_partial;      // [grid][3][COUT]
+  int bs_z_cs, bs_z2_cs, bs_relu;
 };
 
 template <int MODE> struct Tile;
@@ -66,8 +75,9 @@ template <> struct Tile<3> { static constexpr int TX = 32, TY = 8, NTY = 3, NT =
 template <> struct Tile<2> { static constexpr int TX = 256, TY = 1, NTY = 1, NT = 9; };
 
 // CIN = contraction channels, COUT = produced channels (already swapped for the data gradient).
-template <int CIN, int COUT, int MODE, bool FLIP, bool AFF = false>
-__global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
+template <int CIN, int COUT, int MODE, bool FLIP, bool AFF = false, int BS = 0>
+__global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kernel(TConvArgs a) {
+  static_assert(BS == 0 || (FLIP && COUT == 8 && MODE == 3), "fused BatchNorm-backward reductions: 3-D data gradients producing 8 channels");
   constexpr bool STATS = !FLIP;  // the data gradient never feeds a BatchNorm
   using TL = Tile<MODE>;
   constexpr int TX = TL::TX, TY = TL::TY, NTY = TL::NTY, NT = TL::NT;
@@ -185,6 +195,14 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
   float s1[STATS ? COUT : 1], s2[STATS ? COUT : 1];
 #pragma unroll
   for (int c = 0; c < (STATS ? COUT : 1); ++c) s1[c] = s2[c] = 0.f;
+  // fused BatchNorm-backward reductions.  Per lane (its <= zseg voxels of one column) fp32 in packed-math form -- the
+  // MFMA-bound loop has few VALU slots to spare (fp64 per-lane sums: +0.9 ms/step); fp64 from the cross-lane step on, where
+  // the cancellation of sum g (~1e-3 of sum |g|) happens
+  f32x4 bg[BS ? CQ : 1], bgx[BS ? CQ : 1], bgx2[BS == 2 ? CQ : 1];
+#pragma unroll
+  for (int c = 0; c < (BS ? CQ : 1); ++c) bg[c] = bgx[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < (BS == 2 ? CQ : 1); ++c) bgx2[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // prologue: planes z0-1, z0, z0+1
   for (int p = -1; p <= 1; ++p) {
@@ -209,6 +227,27 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
         const float* pp = a.pw_in + ((((size_t)n * a.Z + z) * a.Y + cy) * a.X + cx) * a.pw_in_cs;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) pv[q] = *(const f32x4*)(pp + 4 * q);
+      }
+    }
+    // fused BatchNorm-backward reductions: everything the epilogue reads is requested here, a whole MFMA block ahead of
+    // its use (loaded in the epilogue itself the latency sat between the MFMAs and the plane barrier: +40 % kernel time)
+    f32x4 bz[BS ? CQ : 1], bz2[BS == 2 ? CQ : 1], bold[BS ? CQ : 1];
+    unsigned bmw[BS ? 4 : 1], bvlo = 0;
+    if constexpr (BS != 0) {
+      if (vox_ok) {
+        const size_t vox = (((size_t)n * a.Z + z) * a.Y + gy) * a.X + gx;
+#pragma unroll
+        for (int cq = 0; cq < CQ; ++cq) {
+          bz[cq] = *(const f32x4*)(a.bs_z + vox * a.bs_z_cs + 4 * cq);
+          if constexpr (BS == 2) bz2[cq] = *(const f32x4*)(a.bs_z2 + vox * a.bs_z2_cs + 4 * cq);
+          if (a.accumulate) bold[cq] = *(const f32x4*)(a.out + vox * a.out_cs + 4 * cq);
+        }
+        if (a.bs_relu == 2) {   // the 32-bit half of each mask word that holds this voxel's two bits (see below)
+          const unsigned* mw = (const unsigned*)(a.bs_mask + (vox >> 5) * 4) + (((unsigned)vox & 31u) >> 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bmw[j] = mw[2 * j];
+          bvlo = (unsigned)vox & 15u;
+        }
       }
     }
     static_for<3>([&](auto TZ) {
@@ -257,7 +296,11 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
       for (int cq = 0; cq < CQ; ++cq) {
         f32x4 v = acc[cq];
         if constexpr (CQ == 1) v += acc2;
-        if (a.accumulate) v += *(f32x4*)(op + 4 * cq);
+        if constexpr (BS != 0) {
+          if (a.accumulate) v += bold[cq];
+        } else {
+          if (a.accumulate) v += *(f32x4*)(op + 4 * cq);
+        }
 #if URSN_TCONV_NT_STORE
         __builtin_nontemporal_store(v, (f32x4*)(op + 4 * cq));
 #else
@@ -268,6 +311,29 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
           for (int j = 0; j < 4; ++j) {
             s1[4 * cq + j] += v[j];
             s2[4 * cq + j] += v[j] * v[j];
+          }
+        }
+        if constexpr (BS != 0) {
+          const f32x4 zv = bz[cq];
+          const f32x4 mu = *(const f32x4*)(a.bs_mean + 4 * cq), rs = *(const f32x4*)(a.bs_rstd + 4 * cq);
+          f32x4 g = v;
+          if (a.bs_relu == 1) {        // single conv-BN-ReLU layer: the mask is bn(z) > 0, same expression as bn_act
+            const f32x4 be = *(const f32x4*)(a.bs_beta + 4 * cq);
+            const f32x4 t = __builtin_elementwise_fma(zv, rs, be - mu * rs);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (!(t[j] > 0.f)) g[j] = 0.f;
+          } else if (a.bs_relu == 2) { // residual join: bit (v & 31) * 2 + cq of word j of the voxel's 256-element group
+            const int bit = (int)(bvlo * 2u) + cq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (!((bmw[j] >> bit) & 1u)) g[j] = 0.f;
+          }
+          bg[cq] += g;
+          bgx[cq] = __builtin_elementwise_fma(g, (zv - mu) * rs, bgx[cq]);
+          if constexpr (BS == 2) {
+            const f32x4 mu2 = *(const f32x4*)(a.bs_mean2 + 4 * cq), rs2 = *(const f32x4*)(a.bs_rstd2 + 4 * cq);
+            bgx2[cq] = __builtin_elementwise_fma(g, (bz2[cq] - mu2) * rs2, bgx2[cq]);
           }
         }
       }
@@ -297,6 +363,23 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(TConvArgs a) {
       a.stats_partial[(size_t)blockIdx.x * 2 * COUT + tid] = t;
     }
   }
+  if constexpr (BS != 0) {   // [block][3][COUT] doubles, the layout bn_bwd_final_kernel reads
+    __shared__ double bred[4][3 * COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+      double u = (double)bg[c / 4][c % 4], w = (double)bgx[c / 4][c % 4], x2 = BS == 2 ? (double)bgx2[c / 4][c % 4] : 0.0;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        u += __shfl_xor(u, o);
+        w += __shfl_xor(w, o);
+        if constexpr (BS == 2) x2 += __shfl_xor(x2, o);
+      }
+      if (lane == 0) { bred[tid >> 6][c] = u; bred[tid >> 6][COUT + c] = w; bred[tid >> 6][2 * COUT + c] = x2; }
+    }
+    __syncthreads();
+    if (tid < 3 * COUT)
+      a.bs_partial[(size_t)blockIdx.x * 3 * COUT + tid] = (bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid]);
+  }
 }
 
 
@@ -308,9 +391,9 @@ struct TPlan {
   int grid;
 };
 
-template <int CIN, int COUT, int MODE, bool FLIP, bool AFF = false>
+template <int CIN, int COUT, int MODE, bool FLIP, bool AFF = false, int BS = 0>
 static int launch_t(const TPlan& p, const TConvArgs& a, hipStream_t s) {
-  auto kern = tconv_kernel<CIN, COUT, MODE, FLIP, AFF>;
+  auto kern = tconv_kernel<CIN, COUT, MODE, FLIP, AFF, BS>;
   static size_t attr_lds = 48 * 1024;  // dynamic LDS above the default limit must be opted into per kernel
   if (p.lds > attr_lds) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
@@ -327,6 +410,12 @@ static int launch_t(const TPlan& p, const TConvArgs& a, hipStream_t s) {
     if (!flip && a.aff_mean) {                           \
       if constexpr (ci == co && (ci == 8 || ci == 16)) return launch_t<ci, co, MODE, false, true>(p, a, s); \
       ursn_set_error("tiled conv: no normalise-on-load instantiation for %d->%d", ci, co); \
+      return 3;                                          \
+    }                                                    \
+    if (flip && a.bs_partial) {                          \
+      if constexpr (MODE == 3 && co == 8 && (ci == 8 || ci == 4))                                       \
+        return a.bs_z2 ? launch_t<ci, co, MODE, true, false, 2>(p, a, s) : launch_t<ci, co, MODE, true, false, 1>(p, a, s); \
+      ursn_set_error("tiled conv: no fused BatchNorm-backward instantiation for %d->%d", ci, co);      \
       return 3;                                          \
     }                                                    \
     return flip ? launch_t<ci, co, MODE, true>(p, a, s) : launch_t<ci, co, MODE, false>(p, a, s); \

@@ -473,10 +473,16 @@ int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
   Map m = make_map(a.V, a.C, v4 ? 4 : 1);
   double* partial = (double*)a.scratch;
   double* finals = partial + (size_t)m.grid * 3 * a.C;
-  if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(m.grid), dim3(256), 0, s, a, m.shift, partial);
-  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(m.grid), dim3(256), 0, s, a, m.shift, partial);
-  URSN_HIP(hipGetLastError());
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(a.C), dim3(256), 0, s, (const double*)partial, m.grid, a.C, a.V, finals,
+  int nblocks = m.grid;
+  if (a.pre_partial) {   // sum g, sum g xhat(, sum g xhat2) came out of the epilogue of the kernel that produced dy
+    partial = const_cast<double*>(a.pre_partial);
+    nblocks = a.pre_nblocks;
+  } else {
+    if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(m.grid), dim3(256), 0, s, a, m.shift, partial);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(m.grid), dim3(256), 0, s, a, m.shift, partial);
+    URSN_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(a.C), dim3(256), 0, s, (const double*)partial, nblocks, a.C, a.V, finals,
                      a.dbeta, a.z2 ? a.dbeta2 : nullptr, a.Cw > 0 ? a.Cw : a.C);
   URSN_HIP(hipGetLastError());
   if (v4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(m.grid), dim3(256), 0, s, a, m.shift, (const double*)finals);

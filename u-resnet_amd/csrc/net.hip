@@ -85,6 +85,9 @@ struct ursn_net {
   void* head_scratch = nullptr;
   void* wg_scratch = nullptr;
   size_t wg_scratch_bytes = 0;
+  // BatchNorm-backward reductions taken in the epilogue of the data-gradient kernel that finished a layer's output gradient
+  double* bs_scratch = nullptr;
+  int bs_layer = -1, bs_blocks = 0;   // layer whose (first) reductions are waiting in bs_scratch
   int64_t adam_t = 0;
   int last_n = 0;
   // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
@@ -357,6 +360,7 @@ int plan(ursn_net* n, Arena& A) {
   }
   n->wg_scratch_bytes = wg;
   n->wg_scratch = tr ? A.take(wg + 256) : nullptr;
+  n->bs_scratch = tr ? (double*)A.take((size_t)16384 * 3 * 8 * sizeof(double)) : nullptr;
 
   n->sizes.n_params = poff;
   n->sizes.n_layers = (int64_t)n->layers.size();
@@ -605,8 +609,15 @@ ursn_conv_desc bwd_desc(ursn_net* n, int li, const Act& in, int N, const Act* in
   return d;
 }
 
+// The layer(s) whose BatchNorm backward consumes the gradient a data-gradient launch finishes: their reductions ride in
+// that launch's epilogue where the kernel supports it (ursn_conv_desc.bs_partial), which removes one bn_bwd_reduce pass
+struct BsTarget {
+  int li = -1, li2 = -1, relu = 0;             // relu: 0 none, 1 bn(z) > 0, 2 the join's bit mask
+  const unsigned long long* mask = nullptr;
+};
+
 int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStream_t s, const Act* in2 = nullptr,
-             int fused_sc = -1, bool dgrad_done_elsewhere = false, int aff = -1) {
+             int fused_sc = -1, bool dgrad_done_elsewhere = false, int aff = -1, const BsTarget* bs = nullptr) {
   Layer& L = n->layers[li];
   ursn_conv_desc d = bwd_desc(n, li, in, N, in2, -1, aff);
   hipStream_t ws = s;
@@ -632,6 +643,25 @@ int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStre
     bool acc = take_flag(n, in);
     if (in2) URSN_REQUIRE(take_flag(n, *in2) == acc, "split input: the two halves disagree on gradient initialisation");
     d = bwd_desc(n, li, in, N, in2, fused_sc);   // the data gradient does not read x: no normalise-on-load fields
+    n->bs_layer = -1;
+    static const bool bs_off = getenv("URSN_FUSE_BN_BWD_REDUCE") && getenv("URSN_FUSE_BN_BWD_REDUCE")[0] == '0';
+    if (bs && bs->li >= 0 && !bs_off) {
+      const Layer& T = n->layers[bs->li];
+      ursn_conv_desc t = d;
+      t.bs_z = T.z; t.bs_z_cstride = T.zcs; t.bs_mean = T.mean; t.bs_rstd = T.rstd; t.bs_beta = n->params + T.b_off;
+      t.bs_relu = bs->relu; t.bs_mask = bs->mask;
+      if (bs->li2 >= 0) {
+        const Layer& T2 = n->layers[bs->li2];
+        t.bs_z2 = T2.z; t.bs_z2_cstride = T2.zcs; t.bs_mean2 = T2.mean; t.bs_rstd2 = T2.rstd;
+      }
+      t.bs_partial = n->bs_scratch;
+      // the target's channels are the channels this launch writes (block 0 of a split input)
+      // (a split input is left to the separate pass: measured 2.15 vs 1.77 ms for the pair of launches against 0.33 ms saved)
+      const bool fits = T.cout == 8 && T.zcs == 8 && in.C == 8 && in.cs == 8 && !in2 &&
+                        (bs->li2 < 0 || n->layers[bs->li2].zcs == 8) && (bs->relu != 2 || bs->mask);
+      const int blocks = fits ? tiled_conv_bs_blocks(t) : 0;
+      if (blocks > 0 && blocks <= 16384) { d = t; n->bs_layer = bs->li; n->bs_blocks = blocks; }
+    }
     ProfScope pd(n, s, li, 1, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
     URSN_TRY(conv_dispatch(d, PASS_DGRAD, L.dz, n->params + L.w_off, in.g, acc ? 1 : 0, s));
     pd.done(ursn_last_kernel_name());
@@ -656,13 +686,15 @@ int bn_back(ursn_net* n, int li, const float* dy, int dycs, const float* y, int 
   a.dres = dres; a.drescs = drescs; a.dres_accumulate = dres_acc;
   a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.cout; a.relu = relu; a.scratch = n->red_scratch;
   if (L.zcs != L.cout && li2 < 0 && !relu && dycs == L.zcs && !dres) { a.C = L.zcs; a.Cw = L.cout; }   // logits layer: float4 path
+  if (n->bs_layer == li && a.C == 8) { a.pre_partial = n->bs_scratch; a.pre_nblocks = n->bs_blocks; }
+  n->bs_layer = -1;
   ProfScope ps(n, s, li, 5, 0.0, 4.0 * a.V * a.C * (2.0 * (2 + (relu && !mask) + (li2 >= 0)) + 1 + (li2 >= 0) + (dres != nullptr)));
   URSN_TRY(launch_bn_bwd(a, s));
   ps.done("bn_bwd");
   return 0;
 }
 
-int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
+int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s, const BsTarget* in_target = nullptr) {
   // join: g = dout * (out > 0); BN2 (and shortcut BN) backward; identity shortcut adds g into d(in)
   if (u.sc >= 0) {
     URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, u.sc, nullptr, 0, 0, N, s, u.jmask));
@@ -670,12 +702,14 @@ int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
     bool acc = take_flag(n, u.in);
     URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, -1, u.in.g, u.in.cs, acc ? 1 : 0, N, s, u.jmask));
   }
+  BsTarget t1;   // conv2's data gradient IS d(a1): resnet_conv1's BatchNorm (no activation) consumes it
+  t1.li = u.c1;
   if (u.a1_virtual) {
     Act z1 = u.a1;   // x = z1 normalised on load, dx -> a1.g
     z1.p = n->layers[u.c1].z; z1.cs = n->layers[u.c1].zcs;
-    URSN_TRY(conv_bwd(n, u.c2, z1, true, N, s, nullptr, -1, false, u.c1));
+    URSN_TRY(conv_bwd(n, u.c2, z1, true, N, s, nullptr, -1, false, u.c1, &t1));
   } else {
-    URSN_TRY(conv_bwd(n, u.c2, u.a1, true, N, s));
+    URSN_TRY(conv_bwd(n, u.c2, u.a1, true, N, s, nullptr, -1, false, -1, &t1));
   }
   URSN_TRY(bn_back(n, u.c1, u.a1.g, u.a1.cs, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
   const Act* in2 = u.in2.C ? &u.in2 : nullptr;
@@ -688,8 +722,13 @@ int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s) {
     fuse = !off && ((!in2 && igemm_conv_supported(d, PASS_DGRAD)) ||
                     (tiled_conv_supported(d, PASS_DGRAD) && !igemm_conv_supported(d0, PASS_DGRAD)));
   }
-  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, in2, fuse ? u.sc : -1));
-  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, !fuse, N, s, in2, -1, fuse));
+  // conv1's data gradient is the LAST contribution to d(in) when the shortcut is the identity (the join wrote the first) or
+  // rides in the same kernel: the consumer of d(in) named by the caller gets its reductions from this launch
+  const BsTarget* tin = (in_target && (u.sc < 0 || fuse)) ? in_target : nullptr;
+  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, in2, fuse ? u.sc : -1, false, -1, tin));
+  const int keep_layer = n->bs_layer, keep_blocks = n->bs_blocks;
+  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, !fuse, N, s, in2, -1, fuse));   // weight gradient (+ data gradient when not fused)
+  if (fuse) { n->bs_layer = keep_layer; n->bs_blocks = keep_blocks; }
   return 0;
 }
 
@@ -699,20 +738,34 @@ int backward(ursn_net* n, const float* data, int N, hipStream_t s) {
   n->sync_used = 0;
   Layer& L2 = n->layers[n->conv2];
   URSN_TRY(bn_back(n, n->conv2, n->dlog, L2.zcs, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));   // over the padded channels
-  URSN_TRY(conv_bwd(n, n->conv2, n->a_conv1, true, N, s));
+  BsTarget tc;   // consumer of the gradient each data-gradient launch below completes (see BsTarget)
+  tc.li = n->conv1; tc.relu = 1;
+  URSN_TRY(conv_bwd(n, n->conv2, n->a_conv1, true, N, s, nullptr, -1, false, -1, &tc));
   URSN_TRY(bn_back(n, n->conv1, n->a_conv1.g, n->a_conv1.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
-  URSN_TRY(conv_bwd(n, n->conv1, n->a_pre1, true, N, s));
   size_t ui = n->units.size();
+  auto join_of = [&](const Unit& u) {
+    BsTarget t;
+    if (u.jmask) { t.li = u.c2; t.li2 = u.sc; t.relu = 2; t.mask = u.jmask; }
+    return t;
+  };
+  auto act_of = [&](int li) { BsTarget t; t.li = li; t.relu = 1; return t; };
+  tc = join_of(n->units[ui - 1]);
+  URSN_TRY(conv_bwd(n, n->conv1, n->a_pre1, true, N, s, nullptr, -1, false, -1, &tc));
   for (int i = ns - 1; i >= 0; --i) {
-    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
-    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
+    tc = join_of(n->units[ui - 2]);
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s, &tc));
+    tc = act_of(n->deconv[i]);   // block 0 of module1's input is the transposed conv's activation
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s, &tc));
     const Act& dout = n->deconv_out[i];
     URSN_TRY(bn_back(n, n->deconv[i], dout.g, dout.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
-    URSN_TRY(conv_bwd(n, n->deconv[i], n->deconv_in[i], true, N, s));
+    tc = join_of(n->units[ui - 1]);   // its input: the output of the unit below (or of the bottom of the encoder)
+    URSN_TRY(conv_bwd(n, n->deconv[i], n->deconv_in[i], true, N, s, nullptr, -1, false, -1, &tc));
   }
   for (int step = ns - 1; step >= 0; --step) {
-    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
-    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
+    tc = join_of(n->units[ui - 2]);
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s, &tc));
+    tc = ui >= 2 ? join_of(n->units[ui - 2]) : act_of(n->conv0);
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s, &tc));
   }
   const Act& a0 = n->a_conv0;
   URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));

@@ -148,6 +148,7 @@ size_t tiled_conv_stats_scratch_doubles(const ursn_conv_desc& d);
 int launch_tiled_conv_bn(const ursn_conv_desc& d, const float* in, const float* w, float* out, double* scratch,
                          float eps, float* mean, float* rstd, hipStream_t s);
 int tiled_wgrad_supported(const ursn_conv_desc& d);
+int tiled_conv_bs_blocks(const ursn_conv_desc& d);   // partial blocks of a data gradient with fused BatchNorm-backward sums (0: unsupported)
 // LDS-staged implicit GEMM for k3 s1 layers with >= 32 channels (conv_igemm.hip)
 int igemm_conv_supported(const ursn_conv_desc& d, ConvPass pass);
 size_t igemm_stats_scratch_doubles(const ursn_conv_desc& d);
@@ -224,6 +225,9 @@ struct BnBwdArgs {
   int64_t V; int C; int relu;
   void* scratch;
   const unsigned long long* mask;  // relu mask bits written by launch_bn_act (mask_out); replaces the y reads
+  // the reductions were already taken by the kernel that produced dy (ursn_conv_desc.bs_partial): [pre_nblocks][3][C]
+  // doubles; the reduce pass is skipped
+  const double* pre_partial; int pre_nblocks;
   int Cw;  // channels that own a dbeta entry (0 = C); C may be the 4-padded count of the logits layer (pad: mean = rstd = 0)
 };
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
