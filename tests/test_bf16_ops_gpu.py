@@ -26,6 +26,10 @@ def bf(a):
 CASES = [
     # tag, ndim, N, S, cin, cout, k, stride, transposed
     ("k3s1_8_8", 3, 2, (8, 12, 40), 8, 8, 3, 1, 0),
+    ("k3s1_8_8_odd", 3, 2, (9, 21, 37), 8, 8, 3, 1, 0),         # input-stationary kernel (bf16_conv3.hip): ragged tiles
+    ("k3s1_8_8_zseg", 3, 1, (40, 18, 34), 8, 8, 3, 1, 0),       # ... several z segments per column of tiles
+    ("k3s1_16_8_odd", 3, 2, (11, 19, 35), 16, 8, 3, 1, 0),      # ... 16 contraction channels (two pieces per staged voxel)
+    ("k3s1_16_16_zseg", 3, 1, (36, 9, 40), 16, 16, 3, 1, 0),    # ... 16 produced channels (two row tiles, 32 x 8 voxel tiles)
     ("k3s1_8_16", 3, 1, (6, 10, 33), 8, 16, 3, 1, 0),
     ("k3s1_16_16", 3, 2, (4, 8, 32), 16, 16, 3, 1, 0),
     ("k3s1_32_32", 3, 1, (6, 6, 18), 32, 32, 3, 1, 0),
@@ -83,7 +87,7 @@ def test_bf16_conv_forward_data_and_weight_gradients(case):
         assert rel_err(dwg.cpu().numpy(), rep * dw) < 2e-5, ("wgrad", rep)
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if not c[8]][:10], ids=[c[0] for c in CASES if not c[8]][:10])
+@pytest.mark.parametrize("case", [c for c in CASES if not c[8]][:14], ids=[c[0] for c in CASES if not c[8]][:14])
 def test_bf16_conv_forward_fused_statistics(case):
     tag, ndim, N, S, ci, co, k, st, tr = case
     lib = _lib.load()

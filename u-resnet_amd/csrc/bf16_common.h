@@ -57,6 +57,12 @@ int bconv_grid_blocks(const GatherGeom& g);
 size_t bconv_stats_scratch_doubles(const GatherGeom& g);   // for ONE launch; x classes for a transposed conv
 int bconv_stats_finalize(const GatherGeom& g, const double* partial, int total_blocks, int64_t V, float eps, float* mean,
                          float* rstd, hipStream_t s);
+// 8 -> 8 channel 3x3x3 stride-1 layers run on the input-stationary kernel of bf16_conv3.hip; the entry points above dispatch
+bool b3conv_ok(const GatherGeom& g);
+size_t b3conv_pack_elems();
+int b3conv_grid_blocks(const GatherGeom& g);
+int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
+                  double* stats_partial, int stats_off, int stats_total, hipStream_t s);
 // dW[t][m][n] += sum_q S[q*si+d_t][m] * C[q][n]   (fp32 accumulation, fp32 dW [t][Kw][Nw])
 size_t bwgrad_scratch_bytes(const GatherGeom& g);
 int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,

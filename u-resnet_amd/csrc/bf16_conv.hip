@@ -436,12 +436,14 @@ static bool bconv_plan(const GatherGeom& g, BPlan& p) {
 }
 
 size_t bconv_pack_elems(const GatherGeom& g) {
+  if (b3conv_ok(g)) return b3conv_pack_elems();
   BPlan p;
   if (!bconv_plan(g, p)) return 0;
   return (size_t)p.ncob * p.nchunks * p.nj * p.cot * 64 * 8 + 8;   // + the zero piece
 }
 
 size_t bconv_stats_scratch_doubles(const GatherGeom& g) {
+  if (b3conv_ok(g)) return (size_t)b3conv_grid_blocks(g) * 2 * 16;
   BPlan p;
   if (!bconv_plan(g, p)) return 0;
   return (size_t)p.ncob * p.gridx * 2 * 16 * p.cot;
@@ -461,12 +463,14 @@ static int bconv_launch(const BPlan& p, const BConvArgs& a, hipStream_t s) {
 }
 
 int bconv_grid_blocks(const GatherGeom& g) {
+  if (b3conv_ok(g)) return b3conv_grid_blocks(g);
   BPlan p;
   return bconv_plan(g, p) ? p.gridx : 0;
 }
 
 int bconv_stats_finalize(const GatherGeom& g, const double* partial, int total_blocks, int64_t V, float eps, float* mean,
                          float* rstd, hipStream_t s) {
+  if (b3conv_ok(g)) return launch_bn_stats_final(partial, total_blocks, g.Nn, 16, V, eps, mean, rstd, s);
   BPlan p;
   URSN_REQUIRE(bconv_plan(g, p), "bf16 conv: unsupported geometry");
   for (int cb = 0; cb < p.ncob; ++cb) {
@@ -480,6 +484,7 @@ int bconv_stats_finalize(const GatherGeom& g, const double* partial, int total_b
 
 int launch_bconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                  double* stats_partial, int stats_off, int stats_total, hipStream_t s) {
+  if (b3conv_ok(g)) return launch_b3conv(g, in, w, Kw, Nw, wpack, out, stats_partial, stats_off, stats_total, s);
   BPlan p;
   URSN_REQUIRE(bconv_plan(g, p), "bf16 conv: unsupported geometry (channels %d -> %d, strides %d / %d)", g.K, g.Nn, g.in_cs, g.out_cs);
   {

@@ -1,0 +1,328 @@
+// bf16 3x3x3 stride-1 convolution of the 8-channel levels (lib/uresnet.py:31-36 conv0, :84-100 conv1 / conv2,
+// lib/resnet_module.py:43-51 at spatial level 0; forward and data gradient) -- INPUT-STATIONARY on v_mfma_f32_32x32x16_bf16.
+//
+// The generic bconv kernel (bf16_conv.hip) reads every (voxel, tap) operand piece from LDS once per MFMA and, with 8 produced
+// channels, fills half of the MFMA's rows: at 256^3 it ran 4-5x over its HBM time, bound by LDS reads and address
+// arithmetic.  Here one staged input plane p serves the THREE output planes p+1, p, p-1 at once: the MFMA rows are
+// (tap plane dz = 0, 1, 2; produced channel) -- 24 of 32 -- and the 16-deep contraction is 2 in-plane taps x 8 channels, so a
+// B operand piece is read from LDS once per input plane (5 reads per 32 voxels instead of 14) at a fixed per-lane address
+// plus an immediate, and each input plane is staged exactly once (two LDS slots).  An output plane's partial sums move one
+// row group down per input plane -- row groups are register quads of the 32x32 accumulator (row = (reg & 3) + 8 (reg >> 2)
+// + 4 (lane >> 5)), so the move is 8 register copies per 32 voxels, hidden in the MFMA gaps -- and leave from group 2.
+#include <stdlib.h>
+
+#include "bf16_common.h"
+
+namespace {
+
+typedef float b3_f32x16 __attribute__((ext_vector_type(16)));
+
+// CI, CO in {8, 16} (spatial levels 0 and 1 of an F = 8 network).  CO = 16: two 32-row tiles -- tile 0 = tap planes 0 and 1,
+// tile 1 = tap plane 2 (+ 16 idle rows) -- and a 32 x 8 voxel workgroup tile (the accumulators of 32 x 16 would not fit).
+template <int CI, int CO>
+struct B3 {
+  static constexpr int CPV = CI / 8;                    // 16-byte pieces per staged voxel
+  static constexpr int TY = CO == 8 ? 16 : 8;           // tile rows; 32 columns
+  static constexpr int RPW = TY / 4;                    // rows (32-voxel MFMA column blocks) per wave
+  static constexpr int PX = 34, PY = TY + 2;
+  static constexpr int PIECES = PX * PY * CPV;
+  static constexpr int PLANE = PIECES * 16;             // bytes
+  static constexpr int NST = (PIECES + 255) / 256;      // staging pieces per thread
+  static constexpr int KS = CI == 8 ? 5 : 9;            // k steps of 16: two in-plane taps x 8 channels | one tap x 16
+  static constexpr int MT = CO == 8 ? 1 : 2;
+  static constexpr int WPACK = KS * MT * 64 * 8;        // packed weights: [k step][row tile][lane][8] bf16
+};
+
+struct B3Args {
+  const bf16_t* in;
+  const bf16_t* wp;
+  bf16_t* out;
+  double* stats_partial;   // [stats_total][2][16] doubles (the layout bconv_stats_finalize reads) or null
+  int N, Z, Y, X;
+  int in_cs, out_cs;
+  int zseg, nzseg, nty, ntx;
+  int accumulate;
+  int stats_off, stats_total;
+};
+
+template <int CI, int CO, bool STATS>
+__global__ __launch_bounds__(256, 2) void b3conv_kernel(B3Args a) {
+  using G = B3<CI, CO>;
+  constexpr int CPV = G::CPV, PX = G::PX, RPW = G::RPW, KS = G::KS, MT = G::MT, NCH = CO / 8;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // neighbouring tiles (shared halos) on one XCD's L2
+  const int tx = bid % a.ntx;
+  int r_ = bid / a.ntx;
+  const int ty = r_ % a.nty;
+  r_ /= a.nty;
+  const int zs = r_ % a.nzseg, n = r_ / a.nzseg;
+  const int x0 = tx * 32, y0 = ty * G::TY, z0 = zs * a.zseg;
+  const int z1 = z0 + a.zseg < a.Z ? z0 + a.zseg : a.Z;
+
+  bfx8 A[KS][MT];
+#pragma unroll
+  for (int m = 0; m < KS; ++m)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) A[m][mt] = *(const bfx8*)(a.wp + ((size_t)((m * MT + mt) * 64 + lane)) * 8);
+
+  // staging geometry of this thread's pieces of a plane: fixed over z
+  int srel[G::NST];
+  unsigned sval = 0;
+#pragma unroll
+  for (int i = 0; i < G::NST; ++i) {
+    const int idx = tid + 256 * i;
+    srel[i] = 0;
+    if (idx < G::PIECES) {
+      const int vi = idx / CPV, hp = idx - vi * CPV;
+      const int yy = vi / PX, xx = vi - yy * PX;
+      const int gy = y0 + yy - 1, gx = x0 + xx - 1;
+      if (gy >= 0 && gy < a.Y && gx >= 0 && gx < a.X) {
+        sval |= 1u << i;
+        srel[i] = (gy * a.X + gx) * a.in_cs + hp * 8;
+      }
+    }
+  }
+  u32x4 st[G::NST];
+  auto stage_load = [&](int p) {
+    const bool pz = p >= 0 && p < a.Z;
+    const bf16_t* base = a.in + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
+#pragma unroll
+    for (int i = 0; i < G::NST; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (pz && ((sval >> i) & 1u)) v = *(const u32x4*)(base + srel[i]);
+      st[i] = v;
+    }
+  };
+  auto stage_store = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < G::NST; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < G::PIECES) *(u32x4*)(lds + slot * G::PLANE + idx * 16) = st[i];
+    }
+  };
+
+  // B operand: lane (column c = voxel, k half h) reads in-plane tap 2 m + h (CI = 8) | channel half h of tap m (CI = 16)
+  unsigned bm[KS];
+#pragma unroll
+  for (int m = 0; m < KS; ++m) {
+    int t = CI == 8 ? 2 * m + h : m;
+    if (t > 8) t = 8;
+    bm[m] = (unsigned)(((((t / 3) + RPW * wave) * PX + (t % 3) + c) * CPV + (CI == 16 ? h : 0)) * 16);
+  }
+
+  b3_f32x16 acc[RPW][MT];   // tap-plane groups as register blocks: partial sums of output plane p + 1 - group
+#pragma unroll
+  for (int nt = 0; nt < RPW; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
+  float piv[4 * NCH], s1[4 * NCH], s2[4 * NCH], nacc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4 * NCH; ++k) piv[k] = s1[k] = s2[k] = 0.f;
+
+  stage_load(z0 - 1);
+  stage_store(0);
+  __syncthreads();
+  int slot = 0;
+  for (int p = z0 - 1; p <= z1; ++p) {
+    if (p < z1) stage_load(p + 1);
+    const unsigned char* L = lds + slot * G::PLANE;
+#pragma unroll
+    for (int nt = 0; nt < RPW; ++nt) {
+      b3_f32x16 cc[MT];
+      // the plane that was p + 1 is now p, p becomes p - 1, a new one starts
+      if constexpr (CO == 8) {
+        cc[0] = acc[nt][0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          cc[0][8 + i] = acc[nt][0][4 + i];
+          cc[0][4 + i] = acc[nt][0][i];
+          cc[0][i] = 0.f;
+        }
+      } else {
+        cc[1] = acc[nt][1];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          cc[1][i] = acc[nt][0][8 + i];
+          cc[0][8 + i] = acc[nt][0][i];
+          cc[0][i] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < KS; ++m) {
+        const bfx8 b = *(const bfx8*)(L + bm[m] + nt * (PX * CPV * 16));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) cc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][mt], b, cc[mt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = cc[mt];
+    }
+    const int q = p - 1;   // complete: it has seen input planes q - 1, q, q + 1
+    if (q >= z0 && q < z1) {
+#pragma unroll
+      for (int nt = 0; nt < RPW; ++nt) {
+        const int gy = y0 + RPW * wave + nt, gx = x0 + c;
+        if (gy < a.Y && gx < a.X) {
+          bf16_t* ob = a.out + ((((size_t)n * a.Z + q) * a.Y + gy) * a.X + gx) * a.out_cs + h * 4;
+#pragma unroll
+          for (int cb = 0; cb < NCH; ++cb) {   // channels 8 cb + 4 h + (0..3): registers 8 + i (CO = 8) | 4 cb + i of tile 1
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = CO == 8 ? acc[nt][0][8 + i] : acc[nt][1][4 * cb + i];
+            u32x2* o = (u32x2*)(ob + 8 * cb);
+            if (a.accumulate) {
+              const u32x2 e = *o;
+              v[0] += __uint_as_float(e[0] << 16); v[1] += __uint_as_float(e[0] & 0xffff0000u);
+              v[2] += __uint_as_float(e[1] << 16); v[3] += __uint_as_float(e[1] & 0xffff0000u);
+            }
+            u32x2 pk;
+            pk[0] = pack_bf2(v[0], v[1]);
+            pk[1] = pack_bf2(v[2], v[3]);
+            *o = pk;
+            if constexpr (STATS) {   // moments of the STORED (rounded) tensor: that is what BatchNorm will normalise
+              const float rv[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
+                                   __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (nacc == 0.f) piv[4 * cb + k] = rv[k];
+                ursn_sacc(piv[4 * cb + k], s1[4 * cb + k], s2[4 * cb + k], rv[k]);
+              }
+            }
+          }
+          if constexpr (STATS) nacc += 1.f;
+        }
+      }
+    }
+    if (p < z1) stage_store(slot ^ 1);
+    __syncthreads();
+    slot ^= 1;
+  }
+
+  if constexpr (STATS) {
+    __shared__ double red[4][32];
+#pragma unroll
+    for (int k = 0; k < 4 * NCH; ++k) {
+      double u, w2;
+      ursn_sacc_final(piv[k], s1[k], s2[k], nacc, u, w2);
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
+      if (c == 0) {
+        const int ch = 8 * (k >> 2) + 4 * h + (k & 3);
+        red[wave][ch] = u;
+        red[wave][16 + ch] = w2;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int ch = tid & 15;
+      double t = 0.0;
+      if (ch < CO) t = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      a.stats_partial[((size_t)a.stats_off + blockIdx.x) * 32 + tid] = t;
+    }
+  }
+}
+
+struct B3PackArgs {
+  const float* w;
+  bf16_t* wp;
+  int tapw[27];   // weight tap index by displacement (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1), -1 = no such tap
+  int Kw, Nw, w_tap_stride, w_sk, w_sn;
+};
+
+// fp32 master weights -> A operands: lane (row = l & 31, k half h = l >> 5) of k step m, row tile mt holds 8 contraction
+// channels of in-plane tap t (CI = 8: t = 2 m + h, channels 0..7; CI = 16: t = m, channels 8 h ..) for row (tap plane rg,
+// produced channel co): CO = 8: rg = row >> 3 (rows 24..31 zero); CO = 16: tile 0 rg = row >> 4, tile 1 rows 0..15 rg = 2
+template <int CI, int CO>
+__global__ void b3conv_pack_kernel(B3PackArgs k) {
+  using G = B3<CI, CO>;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= G::WPACK) return;
+  const int j = e & 7, lane = (e >> 3) & 63, mm = e >> 9, mt = mm % G::MT, m = mm / G::MT;
+  const int row = lane & 31, h = lane >> 5;
+  const int t = CI == 8 ? 2 * m + h : m, ci = CI == 8 ? j : 8 * h + j;
+  int rg, co;
+  if (CO == 8) { rg = row >> 3; co = row & 7; }
+  else { rg = mt == 0 ? (row >> 4) : (row < 16 ? 2 : 3); co = row & 15; }
+  float v = 0.f;
+  if (t < 9 && rg < 3 && ci < k.Kw && co < k.Nw) {
+    const int tw = k.tapw[rg * 9 + t];
+    if (tw >= 0) v = k.w[(size_t)tw * k.w_tap_stride + (size_t)ci * k.w_sk + (size_t)co * k.w_sn];
+  }
+  k.wp[e] = f2bf(v);
+}
+
+struct B3Plan { int zseg, nzseg, nty, ntx, grid; };
+B3Plan b3_plan(const GatherGeom& g) {
+  B3Plan p;
+  const int Z = g.in_d[0], Y = g.in_d[1], X = g.in_d[2];
+  const int TY = g.Nn == 8 ? 16 : 8;
+  p.ntx = (X + 31) / 32;
+  p.nty = (Y + TY - 1) / TY;
+  // two halo planes per z segment: long segments, but enough workgroups to fill 256 CUs x 2 a few times over
+  int zseg = Z;
+  const int64_t tiles = (int64_t)g.N * p.nty * p.ntx;
+  while (zseg > 16 && tiles * ((Z + zseg - 1) / zseg) < 2048) zseg = (zseg + 1) / 2;
+  p.zseg = zseg;
+  p.nzseg = (Z + zseg - 1) / zseg;
+  p.grid = (int)(tiles * p.nzseg);
+  return p;
+}
+
+}  // namespace
+
+bool b3conv_ok(const GatherGeom& g) {
+  static const bool off = getenv("URSN_B3CONV") && getenv("URSN_B3CONV")[0] == '0';
+  if (off) return false;
+  if ((g.K != 8 && g.K != 16) || (g.Nn != 8 && g.Nn != 16) || g.ntaps != 27 || (g.in_cs & 7) || (g.out_cs & 7)) return false;
+  for (int j = 0; j < 3; ++j) {
+    if (g.so[j] != 1 || g.si[j] != 1 || g.po[j] != 0) return false;
+    if (g.in_d[j] != g.out_d[j] || g.in_d[j] != g.q_d[j]) return false;
+  }
+  for (int t = 0; t < 27; ++t)
+    for (int j = 0; j < 3; ++j)
+      if (g.tap_d[t][j] < -1 || g.tap_d[t][j] > 1) return false;
+  const int64_t tiles = (int64_t)g.N * ((g.in_d[1] + 7) / 8) * ((g.in_d[2] + 31) / 32) * g.in_d[0];
+  if (tiles > (int64_t)1 << 30) return false;
+  if ((int64_t)g.in_d[1] * g.in_d[2] * (g.in_cs > g.out_cs ? g.in_cs : g.out_cs) >= ((int64_t)1 << 31)) return false;   // int plane offsets
+  return true;
+}
+
+size_t b3conv_pack_elems() { return (size_t)B3<16, 16>::WPACK + 8; }
+int b3conv_grid_blocks(const GatherGeom& g) { return b3_plan(g).grid; }
+
+int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
+                  double* stats_partial, int stats_off, int stats_total, hipStream_t s) {
+  URSN_REQUIRE(b3conv_ok(g), "bf16 3x3x3 conv: unsupported geometry");
+  B3PackArgs k;
+  k.w = w; k.wp = wpack; k.Kw = Kw > 0 ? Kw : g.K; k.Nw = Nw > 0 ? Nw : g.Nn;
+  k.w_tap_stride = g.w_tap_stride; k.w_sk = g.w_sk; k.w_sn = g.w_sn;
+  for (int i = 0; i < 27; ++i) k.tapw[i] = -1;
+  for (int t = 0; t < g.ntaps; ++t) k.tapw[(g.tap_d[t][0] + 1) * 9 + (g.tap_d[t][1] + 1) * 3 + (g.tap_d[t][2] + 1)] = g.tap_w[t];
+  const B3Plan p = b3_plan(g);
+  B3Args a;
+  a.in = in; a.wp = wpack; a.out = out; a.stats_partial = stats_partial;
+  a.N = g.N; a.Z = g.in_d[0]; a.Y = g.in_d[1]; a.X = g.in_d[2];
+  a.in_cs = g.in_cs; a.out_cs = g.out_cs;
+  a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
+  a.accumulate = g.accumulate;
+  a.stats_off = stats_off; a.stats_total = stats_total > 0 ? stats_total : p.grid;
+#define B3GO(ci, co, label)                                                                                              \
+  if (g.K == ci && g.Nn == co) {                                                                                          \
+    hipLaunchKernelGGL((b3conv_pack_kernel<ci, co>), dim3((B3<ci, co>::WPACK + 255) / 256), dim3(256), 0, s, k);          \
+    ursn_note_kernel(label);                                                                                              \
+    if (stats_partial) hipLaunchKernelGGL((b3conv_kernel<ci, co, true>), dim3(p.grid), dim3(256), 0, s, a);               \
+    else hipLaunchKernelGGL((b3conv_kernel<ci, co, false>), dim3(p.grid), dim3(256), 0, s, a);                            \
+  }
+  B3GO(8, 8, "b3conv_bf16<8,8>")
+  B3GO(16, 8, "b3conv_bf16<16,8>")
+  B3GO(8, 16, "b3conv_bf16<8,16>")
+  B3GO(16, 16, "b3conv_bf16<16,16>")
+#undef B3GO
+  URSN_HIP(hipGetLastError());
+  return 0;
+}

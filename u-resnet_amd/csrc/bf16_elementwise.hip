@@ -8,7 +8,7 @@
 #include "bf16_common.h"
 
 #ifndef URSN_BEW_U
-#define URSN_BEW_U 4
+#define URSN_BEW_U 2
 #endif
 
 namespace {
@@ -32,181 +32,218 @@ BMap make_bmap(int64_t V, int C) {
 
 __device__ __forceinline__ u32x4 ld16(const bf16_t* p) { return __builtin_nontemporal_load((const u32x4*)p); }
 
-// NS sums x 8 channels per thread -> partial[block][NS][C] doubles
+// NS x 8 per-thread fp32 sums -> partial[block][NS][C] doubles.  Lanes that share a channel piece (lane & (CP - 1)) are summed
+// with shuffles in fp64, the four waves through 3 KB of LDS (a [24][257]-double staging array held the kernel to three
+// workgroups per CU).
 template <int NS>
-__device__ inline void block_reduce_store8(double (&acc)[NS][8], int CP, int C, double* partial_blk) {
-  __shared__ double sm[NS * 8][257];
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int s = 0; s < NS; ++s)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) sm[s * 8 + j][tid] = acc[s][j];
-  __syncthreads();
-  for (int st = 128; st >= CP; st >>= 1) {
-    if (tid < st) {
-#pragma unroll
-      for (int k = 0; k < NS * 8; ++k) sm[k][tid] += sm[k][tid + st];
-    }
-    __syncthreads();
-  }
-  if (tid < CP && tid * 8 < C) {
+__device__ inline void block_reduce_store8(const float (&acc)[NS][8], int CP, int C, double* partial_blk) {
+  __shared__ double sm[4][NS * 8 * 4];   // [wave][sum][piece slot < 4 when CP <= 4 .. see below]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (CP <= 64) {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) partial_blk[s * C + tid * 8 + j] = sm[s * 8 + j][tid];
+      for (int j = 0; j < 8; ++j) {
+        double v = (double)acc[s][j];
+        for (int o = 32; o >= CP; o >>= 1) v += __shfl_xor(v, o);
+        // lanes 0 .. CP-1 of every wave now hold the wave's sum for piece = lane
+        if (CP <= 4) { if (lane < CP) sm[wave][(s * 8 + j) * 4 + lane] = v; }
+        else if (lane < CP) atomicAdd(&partial_blk[s * C + lane * 8 + j], lane * 8 < C ? v : 0.0);
+      }
+    if (CP <= 4) {
+      __syncthreads();
+      if (tid < NS * 8 * CP) {
+        const int k = tid / CP, piece = tid - k * CP;   // k = s * 8 + j
+        if (piece * 8 < C)
+          partial_blk[(k >> 3) * C + piece * 8 + (k & 7)] = (sm[0][k * 4 + piece] + sm[1][k * 4 + piece]) + (sm[2][k * 4 + piece] + sm[3][k * 4 + piece]);
+      }
+    }
+  } else {   // CP = 128 | 256: a piece is held by 2 | 1 threads of the block
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int piece = tid & (CP - 1);
+        if (piece * 8 < C) atomicAdd(&partial_blk[s * C + piece * 8 + j], (double)acc[s][j]);
+      }
   }
 }
 
 // ---- BN apply / join ------------------------------------------------------------------------------------------------
+// Work unit: a chunk of U x (voxels per block pass) consecutive voxels; a full chunk runs without per-voxel bounds checks and
+// all of its loads are issued before the first use.  The optional operands are template parameters (as runtime flags every
+// one of them cost registers and a branch per voxel: 145 / 248 / 256 VGPRs, 2-3 waves per SIMD, 2.7-3.5 TB/s).
+// C8: 8-channel tensors (spatial level 0: 70 % of the bytes), one piece per voxel, every thread on the same channels.
+#define BEW_MAP                                                                                           \
+  const int CP = C8 ? 1 : 1 << shift, VPB = C8 ? 256 : 256 >> shift;                                      \
+  const int c = C8 ? 0 : (threadIdx.x & (CP - 1)) * 8, vr = C8 ? threadIdx.x : threadIdx.x >> shift;      \
+  constexpr int U = URSN_BEW_U;                                                                           \
+  const int64_t chunkv = (int64_t)VPB * U, nchunks = (a.V + chunkv - 1) / chunkv
+
+template <bool C8, bool HAS2, bool HASR>
 __global__ __launch_bounds__(256) void bbn_act_kernel(BBnActArgs a, int shift) {
-  const int CP = 1 << shift, VPB = 256 >> shift;
-  const int c = (threadIdx.x & (CP - 1)) * 8, vr = threadIdx.x >> shift;
+  BEW_MAP;
   if (c >= a.C) return;
   float sc[8], sh[8], sc2[8], sh2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     sc[j] = a.rstd[c + j];
     sh[j] = a.beta[c + j] - a.mean[c + j] * sc[j];
-    sc2[j] = a.z2 ? a.rstd2[c + j] : 0.f;
-    sh2[j] = a.z2 ? a.beta2[c + j] - a.mean2[c + j] * sc2[j] : 0.f;
+    sc2[j] = HAS2 ? a.rstd2[c + j] : 0.f;
+    sh2[j] = HAS2 ? a.beta2[c + j] - a.mean2[c + j] * sc2[j] : 0.f;
   }
-  const int64_t stride = (int64_t)gridDim.x * VPB;
-  constexpr int U = URSN_BEW_U;
-  for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += U * stride) {
-    u32x4 x[U], x2[U], r[U];
+  const bool relu = a.relu != 0;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t vb = ch * chunkv + vr;
+    auto body = [&](auto FULL) {
+      constexpr bool full = decltype(FULL)::value;
+      u32x4 x[U], x2[U], r[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t v = v0 + u * stride;
-      if (v < a.V) {
-        x[u] = ld16(a.z + v * a.zcs + c);
-        if (a.z2) x2[u] = ld16(a.z2 + v * a.z2cs + c);
-        if (a.res) r[u] = ld16(a.res + v * a.rescs + c);
+      for (int u = 0; u < U; ++u) {
+        const int64_t v = vb + (int64_t)u * VPB;
+        if (full || v < a.V) {
+          x[u] = ld16(a.z + v * a.zcs + c);
+          if constexpr (HAS2) x2[u] = ld16(a.z2 + v * a.z2cs + c);
+          if constexpr (HASR) r[u] = ld16(a.res + v * a.rescs + c);
+        }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t v = v0 + u * stride;
-      if (v >= a.V) continue;
-      float f[8], f2[8], fr[8], y[8];
-      unpack8(x[u], f);
-      if (a.z2) unpack8(x2[u], f2);
-      if (a.res) unpack8(r[u], fr);
+      for (int u = 0; u < U; ++u) {
+        const int64_t v = vb + (int64_t)u * VPB;
+        if (!full && v >= a.V) continue;
+        float f[8], f2[8], fr[8], y[8];
+        unpack8(x[u], f);
+        if constexpr (HAS2) unpack8(x2[u], f2);
+        if constexpr (HASR) unpack8(r[u], fr);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float t = fmaf(f[j], sc[j], sh[j]);
-        if (a.z2) t += fmaf(f2[j], sc2[j], sh2[j]);
-        if (a.res) t += fr[j];
-        if (a.relu) t = fmaxf(t, 0.f);
-        y[j] = t;
+        for (int j = 0; j < 8; ++j) {
+          float t = fmaf(f[j], sc[j], sh[j]);
+          if constexpr (HAS2) t += fmaf(f2[j], sc2[j], sh2[j]);
+          if constexpr (HASR) t += fr[j];
+          if (relu) t = fmaxf(t, 0.f);
+          y[j] = t;
+        }
+        *(u32x4*)(a.y + v * a.ycs + c) = pack8(y);
       }
-      *(u32x4*)(a.y + v * a.ycs + c) = pack8(y);
-    }
+    };
+    if ((ch + 1) * chunkv <= a.V) body(std::true_type{});
+    else body(std::false_type{});
   }
 }
 
 // ---- BN backward ----------------------------------------------------------------------------------------------------
+// MASK: 0 no activation, 1 mask = y > 0 (y given), 2 mask = bn(z) > 0 (beta given).
+// Per-thread sums in fp32: a thread adds <= ~1e3 terms of bf16-rounded data (relative error ~1e-6 of its own partial sum);
+// everything across threads and blocks is fp64.
+template <bool C8, int MASK, bool HAS2>
 __global__ __launch_bounds__(256) void bbn_bwd_reduce_kernel(BBnBwdArgs a, int shift, double* __restrict__ partial) {
-  const int CP = 1 << shift, VPB = 256 >> shift;
-  const int c = (threadIdx.x & (CP - 1)) * 8, vr = threadIdx.x >> shift;
-  double acc[3][8];
+  BEW_MAP;
+  float acc[3][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.0;
+  for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = acc[2][j] = 0.f;
   if (c < a.C) {
     float mu[8], rs[8], mu2[8], rs2[8], be[8];
-    const bool ymask = a.relu && a.y != nullptr, zmask = a.relu && a.y == nullptr;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       mu[j] = a.mean[c + j]; rs[j] = a.rstd[c + j];
-      mu2[j] = a.z2 ? a.mean2[c + j] : 0.f; rs2[j] = a.z2 ? a.rstd2[c + j] : 0.f;
-      be[j] = zmask ? a.beta[c + j] - mu[j] * rs[j] : 0.f;
+      mu2[j] = HAS2 ? a.mean2[c + j] : 0.f; rs2[j] = HAS2 ? a.rstd2[c + j] : 0.f;
+      be[j] = MASK == 2 ? a.beta[c + j] - mu[j] * rs[j] : 0.f;
     }
-    const int64_t stride = (int64_t)gridDim.x * VPB;
-    constexpr int U = URSN_BEW_U;   // voxels in flight per thread (all loads issued before the first use)
-    for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += U * stride) {
-      u32x4 gp[U], zp[U], yp[U], z2p[U];
+    for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+      const int64_t vb = ch * chunkv + vr;
+      auto body = [&](auto FULL) {
+        constexpr bool full = decltype(FULL)::value;
+        u32x4 gp[U], zp[U], yp[U], z2p[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t v = v0 + u * stride;
-        if (v < a.V) {
-          gp[u] = ld16(a.dy + v * a.dycs + c);
-          zp[u] = ld16(a.z + v * a.zcs + c);
-          if (ymask) yp[u] = ld16(a.y + v * a.ycs + c);
-          if (a.z2) z2p[u] = ld16(a.z2 + v * a.z2cs + c);
+        for (int u = 0; u < U; ++u) {
+          const int64_t v = vb + (int64_t)u * VPB;
+          if (full || v < a.V) {
+            gp[u] = ld16(a.dy + v * a.dycs + c);
+            zp[u] = ld16(a.z + v * a.zcs + c);
+            if constexpr (MASK == 1) yp[u] = ld16(a.y + v * a.ycs + c);
+            if constexpr (HAS2) z2p[u] = ld16(a.z2 + v * a.z2cs + c);
+          }
         }
-      }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (v0 + u * stride >= a.V) continue;
-        float g[8], z[8], y[8], z2[8];
-        unpack8(gp[u], g); unpack8(zp[u], z);
-        if (ymask) unpack8(yp[u], y);
-        if (a.z2) unpack8(z2p[u], z2);
+        for (int u = 0; u < U; ++u) {
+          if (!full && vb + (int64_t)u * VPB >= a.V) continue;
+          float g[8], z[8], y[8], z2[8];
+          unpack8(gp[u], g); unpack8(zp[u], z);
+          if constexpr (MASK == 1) unpack8(yp[u], y);
+          if constexpr (HAS2) unpack8(z2p[u], z2);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float gj = g[j];
-          if (ymask && !(y[j] > 0.f)) gj = 0.f;
-          if (zmask && !(fmaf(z[j], rs[j], be[j]) > 0.f)) gj = 0.f;
-          const double gd = (double)gj;
-          acc[0][j] += gd;
-          acc[1][j] += gd * (double)((z[j] - mu[j]) * rs[j]);
-          if (a.z2) acc[2][j] += gd * (double)((z2[j] - mu2[j]) * rs2[j]);
+          for (int j = 0; j < 8; ++j) {
+            float gj = g[j];
+            if constexpr (MASK == 1) { if (!(y[j] > 0.f)) gj = 0.f; }
+            if constexpr (MASK == 2) { if (!(fmaf(z[j], rs[j], be[j]) > 0.f)) gj = 0.f; }
+            acc[0][j] += gj;
+            acc[1][j] = fmaf(gj, (z[j] - mu[j]) * rs[j], acc[1][j]);
+            if constexpr (HAS2) acc[2][j] = fmaf(gj, (z2[j] - mu2[j]) * rs2[j], acc[2][j]);
+          }
         }
-      }
+      };
+      if ((ch + 1) * chunkv <= a.V) body(std::true_type{});
+      else body(std::false_type{});
     }
   }
   block_reduce_store8<3>(acc, CP, a.C, partial + (size_t)blockIdx.x * 3 * a.C);
 }
 
+// DRES: 0 none, 1 dres = / += g (the identity shortcut's share of the join gradient)
+template <bool C8, int MASK, bool HAS2, bool DRES>
 __global__ __launch_bounds__(256) void bbn_bwd_apply_kernel(BBnBwdArgs a, int shift, const double* __restrict__ finals) {
-  const int CP = 1 << shift, VPB = 256 >> shift;
-  const int c = (threadIdx.x & (CP - 1)) * 8, vr = threadIdx.x >> shift;
+  BEW_MAP;
   if (c >= a.C) return;
   float mu[8], rs[8], mu2[8], rs2[8], mg[8], mgx[8], mgx2[8], be[8];
-  const bool ymask = a.relu && a.y != nullptr, zmask = a.relu && a.y == nullptr;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     mu[j] = a.mean[c + j]; rs[j] = a.rstd[c + j];
-    be[j] = zmask ? a.beta[c + j] - mu[j] * rs[j] : 0.f;
-    mu2[j] = a.z2 ? a.mean2[c + j] : 0.f; rs2[j] = a.z2 ? a.rstd2[c + j] : 0.f;
-    mg[j] = (float)finals[c + j]; mgx[j] = (float)finals[a.C + c + j]; mgx2[j] = (float)finals[2 * a.C + c + j];
+    be[j] = MASK == 2 ? a.beta[c + j] - mu[j] * rs[j] : 0.f;
+    mu2[j] = HAS2 ? a.mean2[c + j] : 0.f; rs2[j] = HAS2 ? a.rstd2[c + j] : 0.f;
+    mg[j] = (float)finals[c + j]; mgx[j] = (float)finals[a.C + c + j]; mgx2[j] = HAS2 ? (float)finals[2 * a.C + c + j] : 0.f;
   }
-  const int64_t stride = (int64_t)gridDim.x * VPB;
-  constexpr int U = URSN_BEW_U;
-  for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += U * stride) {
-    u32x4 gp[U], zp[U], yp[U], z2p[U], drp[U];
+  const bool dacc = DRES && a.dres_accumulate;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t vb = ch * chunkv + vr;
+    auto body = [&](auto FULL) {
+      constexpr bool full = decltype(FULL)::value;
+      u32x4 gp[U], zp[U], yp[U], z2p[U], drp[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t v = v0 + u * stride;
-      if (v < a.V) {
-        gp[u] = ld16(a.dy + v * a.dycs + c);
-        zp[u] = ld16(a.z + v * a.zcs + c);
-        if (ymask) yp[u] = ld16(a.y + v * a.ycs + c);
-        if (a.z2) z2p[u] = ld16(a.z2 + v * a.z2cs + c);
-        if (a.dres && a.dres_accumulate) drp[u] = ld16(a.dres + v * a.drescs + c);
+      for (int u = 0; u < U; ++u) {
+        const int64_t v = vb + (int64_t)u * VPB;
+        if (full || v < a.V) {
+          gp[u] = ld16(a.dy + v * a.dycs + c);
+          zp[u] = ld16(a.z + v * a.zcs + c);
+          if constexpr (MASK == 1) yp[u] = ld16(a.y + v * a.ycs + c);
+          if constexpr (HAS2) z2p[u] = ld16(a.z2 + v * a.z2cs + c);
+          if constexpr (DRES) { if (dacc) drp[u] = ld16(a.dres + v * a.drescs + c); }
+        }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t v = v0 + u * stride;
-      if (v >= a.V) continue;
-      float g[8], z[8], y[8], z2[8], dr[8], dz[8], dz2[8];
-      unpack8(gp[u], g); unpack8(zp[u], z);
-      if (ymask) unpack8(yp[u], y);
-      if (a.z2) unpack8(z2p[u], z2);
-      if (a.dres && a.dres_accumulate) unpack8(drp[u], dr);
+      for (int u = 0; u < U; ++u) {
+        const int64_t v = vb + (int64_t)u * VPB;
+        if (!full && v >= a.V) continue;
+        float g[8], z[8], y[8], z2[8], dr[8], dz[8], dz2[8];
+        unpack8(gp[u], g); unpack8(zp[u], z);
+        if constexpr (MASK == 1) unpack8(yp[u], y);
+        if constexpr (HAS2) unpack8(z2p[u], z2);
+        if constexpr (DRES) { if (dacc) unpack8(drp[u], dr); }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float gj = g[j];
-        if (ymask && !(y[j] > 0.f)) gj = 0.f;
-        if (zmask && !(fmaf(z[j], rs[j], be[j]) > 0.f)) gj = 0.f;
-        dz[j] = rs[j] * (gj - mg[j] - (z[j] - mu[j]) * rs[j] * mgx[j]);
-        if (a.z2) dz2[j] = rs2[j] * (gj - mg[j] - (z2[j] - mu2[j]) * rs2[j] * mgx2[j]);
-        if (a.dres) dr[j] = a.dres_accumulate ? dr[j] + gj : gj;
+        for (int j = 0; j < 8; ++j) {
+          float gj = g[j];
+          if constexpr (MASK == 1) { if (!(y[j] > 0.f)) gj = 0.f; }
+          if constexpr (MASK == 2) { if (!(fmaf(z[j], rs[j], be[j]) > 0.f)) gj = 0.f; }
+          dz[j] = rs[j] * (gj - mg[j] - (z[j] - mu[j]) * rs[j] * mgx[j]);
+          if constexpr (HAS2) dz2[j] = rs2[j] * (gj - mg[j] - (z2[j] - mu2[j]) * rs2[j] * mgx2[j]);
+          if constexpr (DRES) dr[j] = dacc ? dr[j] + gj : gj;
+        }
+        *(u32x4*)(a.dz + v * a.dzcs + c) = pack8(dz);
+        if constexpr (HAS2) *(u32x4*)(a.dz2 + v * a.dz2cs + c) = pack8(dz2);
+        if constexpr (DRES) *(u32x4*)(a.dres + v * a.drescs + c) = pack8(dr);
       }
-      *(u32x4*)(a.dz + v * a.dzcs + c) = pack8(dz);
-      if (a.z2) *(u32x4*)(a.dz2 + v * a.dz2cs + c) = pack8(dz2);
-      if (a.dres) *(u32x4*)(a.dres + v * a.drescs + c) = pack8(dr);
-    }
+    };
+    if ((ch + 1) * chunkv <= a.V) body(std::true_type{});
+    else body(std::false_type{});
   }
 }
 
@@ -305,11 +342,26 @@ size_t bbn_scratch_bytes(int64_t V, int C) {
   return ((size_t)make_bmap(V, C).grid * 3 * C + (size_t)3 * C) * sizeof(double) + 256;
 }
 
+// grid: act / apply run one chunk per workgroup (the hardware scheduler overlaps the load and store phases of different
+// workgroups); the reduce keeps a bounded number of partial-sum rows
+static int bew_grid(int64_t V, int shift, int cap) {
+  const int64_t chunkv = (int64_t)(256 >> shift) * URSN_BEW_U;
+  int64_t n = cdiv64(V, chunkv);
+  if (n > cap) n = cap;
+  return (int)(n < 1 ? 1 : n);
+}
+
 int launch_bbn_act(const BBnActArgs& a, hipStream_t s) {
   URSN_REQUIRE(piece_ok(a.C, {a.zcs, a.ycs, a.z2 ? a.z2cs : 0, a.res ? a.rescs : 0}, {a.z, a.y, a.z2, a.res}),
                "bf16 bn_act: channels / strides must be multiples of 8 and pointers 16-byte aligned (C = %d)", a.C);
   const BMap m = make_bmap(a.V, a.C);
-  hipLaunchKernelGGL(bbn_act_kernel, dim3(m.grid), dim3(256), 0, s, a, m.shift);
+  const int grid = bew_grid(a.V, m.shift, 1 << 20);
+#define BACT(c8, h2, hr) hipLaunchKernelGGL((bbn_act_kernel<c8, h2, hr>), dim3(grid), dim3(256), 0, s, a, m.shift)
+#define BACT2(c8) do { if (a.z2 && a.res) BACT(c8, true, true); else if (a.z2) BACT(c8, true, false); \
+                       else if (a.res) BACT(c8, false, true); else BACT(c8, false, false); } while (0)
+  if (a.C == 8) BACT2(true); else BACT2(false);
+#undef BACT2
+#undef BACT
   URSN_HIP(hipGetLastError());
   return 0;
 }
@@ -319,13 +371,30 @@ int launch_bbn_bwd(const BBnBwdArgs& a, hipStream_t s) {
   URSN_REQUIRE(piece_ok(a.C, {a.dycs, (a.relu && a.y) ? a.ycs : 0, a.zcs, a.dzcs, a.z2 ? a.z2cs : 0, a.z2 ? a.dz2cs : 0, a.dres ? a.drescs : 0},
                         {a.dy, a.relu ? a.y : nullptr, a.z, a.dz, a.z2, a.dz2, a.dres}),
                "bf16 bn_bwd: channels / strides must be multiples of 8 and pointers 16-byte aligned (C = %d)", a.C);
-  const BMap m = make_bmap(a.V, a.C);
+  const BMap m = make_bmap(a.V, a.C);   // m.grid: rows of the partial-sum scratch (bbn_scratch_bytes)
+  const int rgrid = bew_grid(a.V, m.shift, m.grid), agrid = bew_grid(a.V, m.shift, 1 << 20);
   double* partial = (double*)a.scratch;
   double* finals = partial + (size_t)m.grid * 3 * a.C;
-  hipLaunchKernelGGL(bbn_bwd_reduce_kernel, dim3(m.grid), dim3(256), 0, s, a, m.shift, partial);
+  const int mask = !a.relu ? 0 : (a.y ? 1 : 2);
+  if (m.shift > 2) URSN_HIP(hipMemsetAsync(partial, 0, (size_t)rgrid * 3 * a.C * sizeof(double), s));   // atomics path of the block reduce
+#define BRED(c8, mk, h2) hipLaunchKernelGGL((bbn_bwd_reduce_kernel<c8, mk, h2>), dim3(rgrid), dim3(256), 0, s, a, m.shift, partial)
+#define BRED2(c8, mk) do { if (a.z2) BRED(c8, mk, true); else BRED(c8, mk, false); } while (0)
+#define BRED3(c8) do { if (mask == 0) BRED2(c8, 0); else if (mask == 1) BRED2(c8, 1); else BRED2(c8, 2); } while (0)
+  if (a.C == 8) BRED3(true); else BRED3(false);
   URSN_HIP(hipGetLastError());
-  URSN_TRY(launch_bn_bwd_final(partial, m.grid, a.C, a.V, finals, a.dbeta, a.z2 ? a.dbeta2 : nullptr, a.Cw > 0 ? a.Cw : a.C, s));
-  hipLaunchKernelGGL(bbn_bwd_apply_kernel, dim3(m.grid), dim3(256), 0, s, a, m.shift, (const double*)finals);
+  URSN_TRY(launch_bn_bwd_final(partial, rgrid, a.C, a.V, finals, a.dbeta, a.z2 ? a.dbeta2 : nullptr, a.Cw > 0 ? a.Cw : a.C, s));
+#define BAPP(c8, mk, h2, dr) hipLaunchKernelGGL((bbn_bwd_apply_kernel<c8, mk, h2, dr>), dim3(agrid), dim3(256), 0, s, a, m.shift, (const double*)finals)
+#define BAPP1(c8, mk, h2) do { if (a.dres) BAPP(c8, mk, h2, true); else BAPP(c8, mk, h2, false); } while (0)
+#define BAPP2(c8, mk) do { if (a.z2) BAPP1(c8, mk, true); else BAPP1(c8, mk, false); } while (0)
+#define BAPP3(c8) do { if (mask == 0) BAPP2(c8, 0); else if (mask == 1) BAPP2(c8, 1); else BAPP2(c8, 2); } while (0)
+  if (a.C == 8) BAPP3(true); else BAPP3(false);
+#undef BAPP3
+#undef BAPP2
+#undef BAPP1
+#undef BAPP
+#undef BRED3
+#undef BRED2
+#undef BRED
   URSN_HIP(hipGetLastError());
   return 0;
 }
