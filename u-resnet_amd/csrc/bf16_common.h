@@ -63,6 +63,10 @@ size_t b3conv_pack_elems();
 int b3conv_grid_blocks(const GatherGeom& g);
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                   double* stats_partial, int stats_off, int stats_total, hipStream_t s);
+bool b3wgrad_ok(const GatherGeom& g);   // z-marching weight gradient of the same layers (bf16_wgrad3.hip)
+size_t b3wgrad_scratch_bytes(const GatherGeom& g);
+int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,
+                   size_t scratch_bytes, hipStream_t s);
 // dW[t][m][n] += sum_q S[q*si+d_t][m] * C[q][n]   (fp32 accumulation, fp32 dW [t][Kw][Nw])
 size_t bwgrad_scratch_bytes(const GatherGeom& g);
 int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,

@@ -1,0 +1,290 @@
+// bf16 weight gradient of the 3x3x3 stride-1 layers of the 8/16-channel levels (lib/uresnet.py:31-36, :84-100,
+// lib/resnet_module.py:43-51 under tf.gradients): dW[t][ci][co] = sum_v x[v + d_t][ci] * dz[v][co], fp32 accumulation on
+// v_mfma_f32_16x16x32_bf16, z-MARCHING.
+//
+// The box kernel of bf16_conv.hip stages a (2+2) x (8+2) x (32+2) halo box of x per 2 x 8 x 32 voxels of dz: 2.7 x the
+// bytes of x, which alone put the 256^3 level at 0.8 ms of its 1.3 (HBM time of the layer: 0.27 ms).  Here a workgroup walks
+// a 32 x TY voxel column through z with a ring of four x planes (three in use, one arriving) and two dz planes in LDS, so
+// x is read 1.2 x and dz once, and the 27 tap products stay in the accumulators for the whole column: the fp32 slab is
+// written once per workgroup.  MFMA view (as the box kernel): rows = (tap, ci) 16 per tile -- two taps x 8 channels or one
+// tap x 16 -- columns = co, contraction = 32 voxels along x, both operands read with ds_read_b64_tr_b16; the tiles are
+// dealt round-robin to the four waves (every wave sees every voxel, a tile lives in exactly one wave: no cross-wave sum).
+#include <stdlib.h>
+
+#include "bf16_common.h"
+
+namespace {
+
+template <int K, int NN>
+struct W3 {
+  static constexpr int CPV = K / 8, DPV = NN / 8;
+  static constexpr int TY = K == 8 ? 16 : 8;
+  static constexpr int PX = 34, PY = TY + 2;
+  static constexpr int XPIECES = PX * PY * CPV, XPLANE = XPIECES * 16;
+  static constexpr int DPIECES = 32 * TY * DPV, DPLANE = DPIECES * 16;
+  static constexpr int NXS = (XPIECES + 255) / 256, NDS = (DPIECES + 255) / 256;
+  static constexpr int TPD = K == 8 ? 5 : 9;          // 16-row tiles per tap plane (K = 8: 4 tap pairs + 1 single)
+  static constexpr int NT = 3 * TPD;                  // 15 | 27
+  static constexpr int MTW = (NT + 3) / 4;            // tiles per wave
+  static constexpr int LDS = 4 * XPLANE + 2 * DPLANE;
+};
+
+struct W3Args {
+  const bf16_t* S;    // x: (N, Z, Y, X, in_cs)
+  const bf16_t* C;    // dz: (N, Z, Y, X, out_cs)
+  float* slab;        // [grid][NT][16][16] fp32
+  int N, Z, Y, X, in_cs, out_cs;
+  int zseg, nzseg, nty, ntx;
+};
+
+__device__ __forceinline__ bfx8 w3_tr_pair(const unsigned char* p0, const unsigned char* p1) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p1);
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bfx8, v);
+}
+
+template <int K, int NN>
+__global__ __launch_bounds__(256, 2) void b3wgrad_kernel(W3Args a) {
+  using G = W3<K, NN>;
+  constexpr int CPV = G::CPV, DPV = G::DPV, PX = G::PX, TY = G::TY, MTW = G::MTW, TPD = G::TPD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xring = smem;
+  unsigned char* dbuf = smem + 4 * G::XPLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Gk = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;   // transposed read: lane supplies (k row tq, column chunk tp)
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int tx = bid % a.ntx;
+  int r_ = bid / a.ntx;
+  const int ty = r_ % a.nty;
+  r_ /= a.nty;
+  const int zs = r_ % a.nzseg, n = r_ / a.nzseg;
+  const int x0 = tx * 32, y0 = ty * TY, z0 = zs * a.zseg;
+  const int z1 = z0 + a.zseg < a.Z ? z0 + a.zseg : a.Z;
+
+  // staging geometry (fixed over z)
+  int xrel[G::NXS], drel[G::NDS];
+  unsigned xval = 0, dval = 0;
+#pragma unroll
+  for (int i = 0; i < G::NXS; ++i) {
+    const int idx = tid + 256 * i;
+    xrel[i] = 0;
+    if (idx < G::XPIECES) {
+      const int vi = idx / CPV, hp = idx - vi * CPV;
+      const int yy = vi / PX, xx = vi - yy * PX;
+      const int gy = y0 + yy - 1, gx = x0 + xx - 1;
+      if (gy >= 0 && gy < a.Y && gx >= 0 && gx < a.X) { xval |= 1u << i; xrel[i] = (gy * a.X + gx) * a.in_cs + hp * 8; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < G::NDS; ++i) {
+    const int idx = tid + 256 * i;
+    drel[i] = 0;
+    if (idx < G::DPIECES) {
+      const int vi = idx / DPV, hp = idx - vi * DPV;
+      const int yy = vi >> 5, xx = vi & 31;
+      const int gy = y0 + yy, gx = x0 + xx;
+      if (gy < a.Y && gx < a.X) { dval |= 1u << i; drel[i] = (gy * a.X + gx) * a.out_cs + hp * 8; }
+    }
+  }
+  u32x4 xs[G::NXS], ds[G::NDS];
+  auto load_x = [&](int p) {
+    const bool pz = p >= 0 && p < a.Z;
+    const bf16_t* base = a.S + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
+#pragma unroll
+    for (int i = 0; i < G::NXS; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (pz && ((xval >> i) & 1u)) v = *(const u32x4*)(base + xrel[i]);
+      xs[i] = v;
+    }
+  };
+  auto store_x = [&](int p) {   // plane p lives in ring slot (p + 1) & 3
+    unsigned char* dst = xring + ((p + 1) & 3) * G::XPLANE;
+#pragma unroll
+    for (int i = 0; i < G::NXS; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < G::XPIECES) *(u32x4*)(dst + idx * 16) = xs[i];
+    }
+  };
+  auto load_d = [&](int q) {
+    const bool qz = q < z1;
+    const bf16_t* base = a.C + ((size_t)n * a.Z + (qz ? q : 0)) * a.Y * a.X * a.out_cs;
+#pragma unroll
+    for (int i = 0; i < G::NDS; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qz && ((dval >> i) & 1u)) v = *(const u32x4*)(base + drel[i]);
+      ds[i] = v;
+    }
+  };
+  auto store_d = [&](int q) {
+    unsigned char* dst = dbuf + (q & 1) * G::DPLANE;
+#pragma unroll
+    for (int i = 0; i < G::NDS; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < G::DPIECES) *(u32x4*)(dst + idx * 16) = ds[i];
+    }
+  };
+
+  // this wave's tiles: u = wave + 4 m  ->  tap plane dzm, in-plane tap(s); aoff: byte offset of the lane's A piece in a plane
+  int dzm[MTW];
+  unsigned aoff[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const int u = wave + 4 * m;
+    const int uu = u < G::NT ? u : G::NT - 1;
+    dzm[m] = uu / TPD;
+    const int i = uu - dzm[m] * TPD;
+    int j = K == 8 ? 2 * i + (tp >> 1) : i;   // in-plane tap of this lane's column chunk
+    if (j > 8) j = 8;                         // the unpaired slot of a tap plane: duplicate, dropped by the reduce
+    const int chunk = K == 8 ? (tp & 1) : tp; // 4-channel chunk of the voxel
+    aoff[m] = (unsigned)((((j / 3) * PX + (j % 3) + 8 * Gk + tq) * CPV) * 16 + chunk * 8);
+  }
+  const unsigned boff = (unsigned)(((8 * Gk + tq) * DPV) * 16 + (NN == 8 ? (tp & 1) : tp) * 8);
+
+  bf_f32x4 acc[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) acc[m] = (bf_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // prologue: x planes z0-1, z0, z0+1 and dz plane z0
+  for (int p = z0 - 1; p <= z0 + 1; ++p) { load_x(p); store_x(p); }
+  load_d(z0);
+  store_d(z0);
+  __syncthreads();
+  for (int q = z0; q < z1; ++q) {
+    load_x(q + 2);
+    load_d(q + 1);
+    const unsigned char* db = dbuf + (q & 1) * G::DPLANE;
+    unsigned sb[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) sb[m] = (unsigned)(((q + dzm[m]) & 3) * G::XPLANE) + aoff[m];   // plane q - 1 + dz -> slot (q + dz) & 3
+#pragma unroll 2
+    for (int r = 0; r < TY; ++r) {
+      const unsigned char* bp = db + boff + r * (32 * DPV * 16);
+      const bfx8 B = w3_tr_pair(bp, bp + 4 * DPV * 16);
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const unsigned char* ap = xring + sb[m] + r * (PX * CPV * 16);
+        const bfx8 A = w3_tr_pair(ap, ap + 4 * CPV * 16);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, acc[m], 0, 0, 0);
+      }
+    }
+    store_x(q + 2);
+    store_d(q + 1);
+    __syncthreads();
+  }
+  float* sl = a.slab + (size_t)blockIdx.x * (G::NT * 256);
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const int u = wave + 4 * m;
+    if (u >= G::NT) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sl[(size_t)u * 256 + (4 * Gk + r) * 16 + li] = acc[m][r];
+  }
+}
+
+struct W3ReduceArgs {
+  const float* slab; float* dw;
+  int nslabs, Kw, Nw;
+  int tapw[27];   // stored tap index by (dz * 9 + dy * 3 + dx), -1 = none
+};
+// dw[tap][ci][co] += sum over workgroup slabs (fixed order); one thread per (tile, row, column)
+template <int K, int NN>
+__global__ __launch_bounds__(256) void b3wgrad_reduce_kernel(W3ReduceArgs a) {
+  using G = W3<K, NN>;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= G::NT * 256) return;
+  const int u = e >> 8, row = (e >> 4) & 15, col = e & 15;
+  const int dz = u / G::TPD, i = u - dz * G::TPD;
+  const int j = K == 8 ? 2 * i + (row >> 3) : i, ci = K == 8 ? (row & 7) : row;
+  if (j > 8 || ci >= a.Kw || col >= a.Nw || col >= NN) return;
+  const int tw = a.tapw[dz * 9 + j];
+  if (tw < 0) return;
+  const float* p = a.slab + e;
+  const size_t per = (size_t)G::NT * 256;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < a.nslabs; k += 4) {
+    s0 += p[(size_t)k * per]; s1 += p[(size_t)(k + 1) * per]; s2 += p[(size_t)(k + 2) * per]; s3 += p[(size_t)(k + 3) * per];
+  }
+  for (; k < a.nslabs; ++k) s0 += p[(size_t)k * per];
+  a.dw[((size_t)tw * a.Kw + ci) * a.Nw + col] += (s0 + s1) + (s2 + s3);
+}
+
+struct W3Plan { int zseg, nzseg, nty, ntx, grid; };
+W3Plan w3_plan(const GatherGeom& g) {
+  W3Plan p;
+  const int Z = g.in_d[0], Y = g.in_d[1], X = g.in_d[2];
+  const int TY = g.K == 8 ? 16 : 8;
+  p.ntx = (X + 31) / 32;
+  p.nty = (Y + TY - 1) / TY;
+  const int64_t tiles = (int64_t)g.N * p.nty * p.ntx;
+  // long columns (three prologue planes each, one slab each), but at least ~2 workgroups per CU slot
+  int nz = (int)((1024 + tiles - 1) / tiles);
+  if (nz < 1) nz = 1;
+  if (nz > (Z + 7) / 8) nz = (Z + 7) / 8;
+  p.zseg = (Z + nz - 1) / nz;
+  p.nzseg = (Z + p.zseg - 1) / p.zseg;
+  p.grid = (int)(tiles * p.nzseg);
+  return p;
+}
+
+}  // namespace
+
+bool b3wgrad_ok(const GatherGeom& g) {
+  static const bool off = getenv("URSN_B3WGRAD") && getenv("URSN_B3WGRAD")[0] == '0';
+  if (off) return false;
+  if (!((g.K == 8 && g.Nn == 8) || (g.K == 16 && (g.Nn == 8 || g.Nn == 16)))) return false;
+  if (g.ntaps != 27 || (g.in_cs & 7) || (g.out_cs & 7)) return false;
+  for (int j = 0; j < 3; ++j)
+    if (g.si[j] != 1 || g.in_d[j] != g.q_d[j]) return false;
+  for (int t = 0; t < 27; ++t)
+    for (int j = 0; j < 3; ++j)
+      if (g.tap_d[t][j] < -1 || g.tap_d[t][j] > 1) return false;
+  if ((int64_t)g.in_d[1] * g.in_d[2] * (g.in_cs > g.out_cs ? g.in_cs : g.out_cs) >= ((int64_t)1 << 31)) return false;
+  return w3_plan(g).grid <= (1 << 20);
+}
+
+size_t b3wgrad_scratch_bytes(const GatherGeom& g) {
+  const int nt = g.K == 8 ? 15 : 27;
+  return (size_t)w3_plan(g).grid * nt * 256 * sizeof(float) + 256;
+}
+
+template <int K, int NN>
+static int w3_launch(const W3Plan& p, const W3Args& a, const W3ReduceArgs& r, hipStream_t s) {
+  using G = W3<K, NN>;
+  auto kern = b3wgrad_kernel<K, NN>;
+  static bool attr = false;
+  if (!attr) {
+    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), G::LDS, s, a);
+  URSN_HIP(hipGetLastError());
+  hipLaunchKernelGGL((b3wgrad_reduce_kernel<K, NN>), dim3(G::NT), dim3(256), 0, s, r);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,
+                   size_t scratch_bytes, hipStream_t s) {
+  URSN_REQUIRE(b3wgrad_ok(g), "bf16 3x3x3 wgrad: unsupported geometry");
+  URSN_REQUIRE(scratch && scratch_bytes >= b3wgrad_scratch_bytes(g), "bf16 3x3x3 wgrad: scratch too small");
+  const W3Plan p = w3_plan(g);
+  W3Args a;
+  a.S = S; a.C = C; a.slab = (float*)scratch;
+  a.N = g.N; a.Z = g.in_d[0]; a.Y = g.in_d[1]; a.X = g.in_d[2]; a.in_cs = g.in_cs; a.out_cs = g.out_cs;
+  a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
+  W3ReduceArgs r;
+  r.slab = a.slab; r.dw = dw; r.nslabs = p.grid; r.Kw = Kw > 0 ? Kw : g.K; r.Nw = Nw > 0 ? Nw : g.Nn;
+  for (int i = 0; i < 27; ++i) r.tapw[i] = -1;
+  for (int t = 0; t < g.ntaps; ++t) r.tapw[(g.tap_d[t][0] + 1) * 9 + (g.tap_d[t][1] + 1) * 3 + (g.tap_d[t][2] + 1)] = g.tap_w[t];
+  ursn_note_kernel("b3wgrad_bf16");
+  if (g.K == 8) return w3_launch<8, 8>(p, a, r, s);
+  if (g.Nn == 8) return w3_launch<16, 8>(p, a, r, s);
+  return w3_launch<16, 16>(p, a, r, s);
+}
