@@ -404,10 +404,13 @@ def main():
 
     if rank == 0 and args.layers:
         pn = ["fwd", "dgrad", "wgrad", "bn_stats", "bn_act", "bn_bwd", "head"]
-        for (lname, ps, k), (ms, fl, by) in sorted(by_layer.items(), key=lambda kv: -kv[1][0])[:60]:
+        # last column: the launch's own roofline time max(F / P, B / BW) over its measured time
+        for (lname, ps, k), (ms, fl, by) in sorted(by_layer.items(), key=lambda kv: -kv[1][0])[:400]:
             ms /= prof_steps
-            sys.stderr.write("%-52s %-8s %-20s %8.3f ms %8.2f TFLOP/s %8.1f GB/s\n" % (
-                lname, pn[ps], k, ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0, by / (ms * 1e-3) / 1e9 if ms > 0 else 0))
+            t_roof = max(fl / (PEAK_FP32_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)) * 1e3
+            sys.stderr.write("%-52s %-8s %-20s %8.3f ms %8.2f TFLOP/s %8.1f GB/s %5.0f%%\n" % (
+                lname, pn[ps], k, ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0,
+                by / (ms * 1e-3) / 1e9 if ms > 0 else 0, 100.0 * t_roof / ms if ms > 0 else 0))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and len(dims) == 4:
         cpu = run_cpu_baseline(int(dims[0]))

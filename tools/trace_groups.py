@@ -1,18 +1,21 @@
-"""Group a rocprofv3 kernel trace by (kernel, grid) -> launches and time per step.  usage: trace_groups.py trace.csv steps"""
+"""Group a rocprofv3 kernel trace by (kernel, grid) -> launches and time per step.
+usage: trace_groups.py trace.csv steps [rows] [filter]"""
 import csv
+import re
 import sys
 from collections import defaultdict
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2])
-g = defaultdict(lambda: [0, 0.0])
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+flt = sys.argv[4] if len(sys.argv) > 4 else ""
+g = defaultdict(list)
 for r in rows:
-    name = r["Kernel_Name"].split("(")[0][-60:]
-    key = (name, r["Grid_Size_X"], r["Grid_Size_Y"], r.get("LDS_Block_Size", ""))
-    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
-    g[key][0] += 1
-    g[key][1] += d
-tot = sum(v[1] for v in g.values())
-print(f"total {tot / steps:.2f} ms/step")
-for k, v in sorted(g.items(), key=lambda kv: -kv[1][1])[: int(sys.argv[3]) if len(sys.argv) > 3 else 45]:
-    print(f"{v[1] / steps:8.3f} ms/step {v[0] / steps:6.1f} launches/step  {v[1] / v[0]:8.3f} ms each  grid {k[1]}x{k[2]} lds {k[3]}  {k[0]}")
+    name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+    name = re.sub(r"\(.*", "", name)[-44:]
+    if flt and flt not in name:
+        continue
+    g[(name, r["Grid_Size_X"], r["Grid_Size_Y"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+for k, v in sorted(g.items(), key=lambda kv: -sum(kv[1]))[:top]:
+    print(f"{sum(v) / steps:7.3f} ms/step  {len(v) / steps:5.1f}/step  avg {sum(v) / len(v):6.3f} max {max(v):6.3f}  grid {k[1]}x{k[2]}  {k[0]}")
+print(f"total {sum(sum(v) for v in g.values()) / steps:.2f} ms/step")
