@@ -63,6 +63,12 @@ size_t b3conv_pack_elems();
 int b3conv_grid_blocks(const GatherGeom& g);
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                   double* stats_partial, int stats_off, int stats_total, hipStream_t s);
+// the 8 output-parity classes of a stride-2 scatter-type pass (16 -> 8 channels, even extents) in one launch (bf16_deconv3.hip)
+bool bdeconv_ok(const GatherGeom* g, int cnt);
+int bdeconv_grid_blocks(const GatherGeom* g, int cnt);   // = rows of its statistics partials ([grid][2][16] doubles)
+size_t bdeconv_pack_elems();
+int launch_bdeconv(const GatherGeom* g, int cnt, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
+                   double* stats_partial, int accumulate, hipStream_t s);
 bool b3wgrad_ok(const GatherGeom& g);   // z-marching weight gradient of the same layers (bf16_wgrad3.hip)
 size_t b3wgrad_scratch_bytes(const GatherGeom& g);
 int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,

@@ -314,6 +314,11 @@ static int bf16_conv_op(const ursn_conv_desc& d, ConvPass pass, const void* in, 
     for (int j = 0; j < 3; ++j) e *= g[0].out_d[j];
     URSN_HIP(hipMemsetAsync(out, 0, (size_t)e * sizeof(bf16_t), s));
   }
+  if (!stats_partial && bdeconv_ok(g, n)) {   // all parity classes in one launch
+    bf16_t* wp = op_wpack(bdeconv_pack_elems());
+    URSN_REQUIRE(wp, "bf16 conv: no memory for the packed weights");
+    return launch_bdeconv(g, n, (const bf16_t*)in, w, 0, 0, wp, (bf16_t*)out, nullptr, accumulate, s);
+  }
   for (int i = 0; i < n; ++i) {
     g[i].accumulate = accumulate;
     if (g[i].ntaps == 0) continue;

@@ -239,6 +239,10 @@ int plan(ursn_bnet* n, Arena& A) {
         const int cnt = layer_geoms(n, L, (ConvPass)pass, nb, L.kin, L.kout, g);
         URSN_REQUIRE(cnt >= 1, "bf16 plan: bad geometry for %s", L.name.c_str());
         size_t stl = 0;
+        if (pass != PASS_WGRAD && bdeconv_ok(g, cnt)) {
+          if (bdeconv_pack_elems() > wp) wp = bdeconv_pack_elems();
+          if (pass == PASS_FWD) stl = (size_t)bdeconv_grid_blocks(g, cnt) * 32;
+        }
         for (int i = 0; i < cnt; ++i) {
           if (g[i].ntaps == 0) continue;
           if (pass == PASS_WGRAD) {
@@ -279,6 +283,11 @@ int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
   int Kw, Nw;
   real_extents(L, PASS_FWD, Kw, Nw);
   int total = 0, off = 0;
+  if (bdeconv_ok(g, cnt)) {   // transposed conv 16 -> 8: the eight parity classes in one launch
+    total = bdeconv_grid_blocks(g, cnt);
+    URSN_TRY(launch_bdeconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, n->wpack, L.z, n->stats, 0, s));
+    return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
+  }
   for (int i = 0; i < cnt; ++i) total += bconv_grid_blocks(g[i]);
   URSN_REQUIRE(total > 0, "bf16 forward: no kernel for %s", L.name.c_str());
   for (int i = 0; i < cnt; ++i) {
@@ -389,6 +398,8 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
   bool empty = false;
   for (int i = 0; i < cnt; ++i) empty = empty || g[i].ntaps == 0;
   URSN_REQUIRE(!empty || acc, "bf16 backward: %s would leave voxels of its input gradient unwritten", L.name.c_str());
+  if (bdeconv_ok(g, cnt))   // stride-2 conv 8 -> 16: the eight parity classes of its data gradient in one launch
+    return launch_bdeconv(g, cnt, L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, acc ? 1 : 0, s);
   for (int i = 0; i < cnt; ++i) {
     if (g[i].ntaps == 0) continue;
     g[i].accumulate = acc ? 1 : 0;
