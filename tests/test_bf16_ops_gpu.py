@@ -38,6 +38,7 @@ CASES = [
     ("k3s1_24_40", 3, 1, (4, 6, 20), 24, 40, 3, 1, 0),          # channel counts that are only multiples of 8
     ("k3s2_8_16", 3, 2, (8, 12, 36), 8, 16, 3, 2, 0),
     ("k3s2_odd", 3, 1, (7, 9, 21), 16, 32, 3, 2, 0),            # odd sizes: TF SAME pad-before = 1
+    ("k1s1_16_8", 3, 2, (7, 9, 37), 16, 8, 1, 1, 0),            # 1x1 between 8 / 16 channels: operands straight from global memory
     ("k1s1_32_16", 3, 2, (6, 6, 20), 32, 16, 1, 1, 0),
     ("k1s2_8_16", 3, 2, (8, 12, 36), 8, 16, 1, 2, 0),
     ("deconv_16_8", 3, 2, (4, 6, 18), 16, 8, 3, 2, 1),
@@ -87,7 +88,7 @@ def test_bf16_conv_forward_data_and_weight_gradients(case):
         assert rel_err(dwg.cpu().numpy(), rep * dw) < 2e-5, ("wgrad", rep)
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if not c[8]][:14], ids=[c[0] for c in CASES if not c[8]][:14])
+@pytest.mark.parametrize("case", [c for c in CASES if not c[8]][:16], ids=[c[0] for c in CASES if not c[8]][:16])
 def test_bf16_conv_forward_fused_statistics(case):
     tag, ndim, N, S, ci, co, k, st, tr = case
     lib = _lib.load()

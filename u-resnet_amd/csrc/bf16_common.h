@@ -63,6 +63,11 @@ size_t b3conv_pack_elems();
 int b3conv_grid_blocks(const GatherGeom& g);
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                   double* stats_partial, int stats_off, int stats_total, hipStream_t s);
+// 1x1 stride-1 conv between 8 / 16 channel tensors, operands straight from global memory (bf16_pointwise.hip)
+bool bpw_ok(const GatherGeom& g);
+int bpw_grid_blocks(const GatherGeom& g);
+int launch_bpw(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* out, double* stats_partial,
+               hipStream_t s);
 // the 8 output-parity classes of a stride-2 scatter-type pass (16 -> 8 channels, even extents) in one launch (bf16_deconv3.hip)
 bool bdeconv_ok(const GatherGeom* g, int cnt);
 int bdeconv_grid_blocks(const GatherGeom* g, int cnt);   // = rows of its statistics partials ([grid][2][16] doubles)

@@ -436,6 +436,7 @@ static bool bconv_plan(const GatherGeom& g, BPlan& p) {
 }
 
 size_t bconv_pack_elems(const GatherGeom& g) {
+  if (bpw_ok(g)) return 8;
   if (b3conv_ok(g)) return b3conv_pack_elems();
   BPlan p;
   if (!bconv_plan(g, p)) return 0;
@@ -443,6 +444,7 @@ size_t bconv_pack_elems(const GatherGeom& g) {
 }
 
 size_t bconv_stats_scratch_doubles(const GatherGeom& g) {
+  if (bpw_ok(g)) return (size_t)bpw_grid_blocks(g) * 2 * 16;
   if (b3conv_ok(g)) return (size_t)b3conv_grid_blocks(g) * 2 * 16;
   BPlan p;
   if (!bconv_plan(g, p)) return 0;
@@ -463,6 +465,7 @@ static int bconv_launch(const BPlan& p, const BConvArgs& a, hipStream_t s) {
 }
 
 int bconv_grid_blocks(const GatherGeom& g) {
+  if (bpw_ok(g)) return bpw_grid_blocks(g);
   if (b3conv_ok(g)) return b3conv_grid_blocks(g);
   BPlan p;
   return bconv_plan(g, p) ? p.gridx : 0;
@@ -470,7 +473,7 @@ int bconv_grid_blocks(const GatherGeom& g) {
 
 int bconv_stats_finalize(const GatherGeom& g, const double* partial, int total_blocks, int64_t V, float eps, float* mean,
                          float* rstd, hipStream_t s) {
-  if (b3conv_ok(g)) return launch_bn_stats_final(partial, total_blocks, g.Nn, 16, V, eps, mean, rstd, s);
+  if (bpw_ok(g) || b3conv_ok(g)) return launch_bn_stats_final(partial, total_blocks, g.Nn, 16, V, eps, mean, rstd, s);
   BPlan p;
   URSN_REQUIRE(bconv_plan(g, p), "bf16 conv: unsupported geometry");
   for (int cb = 0; cb < p.ncob; ++cb) {
@@ -484,6 +487,7 @@ int bconv_stats_finalize(const GatherGeom& g, const double* partial, int total_b
 
 int launch_bconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                  double* stats_partial, int stats_off, int stats_total, hipStream_t s) {
+  if (bpw_ok(g)) return launch_bpw(g, in, w, Kw, Nw, out, stats_partial ? stats_partial + (size_t)stats_off * 32 : nullptr, s);
   if (b3conv_ok(g)) return launch_b3conv(g, in, w, Kw, Nw, wpack, out, stats_partial, stats_off, stats_total, s);
   BPlan p;
   URSN_REQUIRE(bconv_plan(g, p), "bf16 conv: unsupported geometry (channels %d -> %d, strides %d / %d)", g.K, g.Nn, g.in_cs, g.out_cs);
