@@ -61,8 +61,12 @@ int bconv_stats_finalize(const GatherGeom& g, const double* partial, int total_b
 bool b3conv_ok(const GatherGeom& g);
 size_t b3conv_pack_elems();
 int b3conv_grid_blocks(const GatherGeom& g);
+// pw (data gradient 8 -> 16 only, b3conv_pw_ok): + pw[v] . pw_w^T, the data gradient of the module's 1x1 shortcut
+// (pw = the shortcut's dz, 8 channels; pw_w = its weights [16][8])
+bool b3conv_pw_ok(const GatherGeom& g);
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
-                  double* stats_partial, int stats_off, int stats_total, hipStream_t s);
+                  double* stats_partial, int stats_off, int stats_total, hipStream_t s, const bf16_t* pw = nullptr,
+                  int pw_cs = 0, const float* pw_w = nullptr);
 // 1x1 stride-1 conv between 8 / 16 channel tensors, operands straight from global memory (bf16_pointwise.hip)
 bool bpw_ok(const GatherGeom& g);
 int bpw_grid_blocks(const GatherGeom& g);

@@ -43,13 +43,19 @@ struct B3Args {
   int zseg, nzseg, nty, ntx;
   int accumulate;
   int stats_off, stats_total;
+  // PW instantiation (data gradient of a module's resnet_conv1, 8 -> 16): + pw[v] . Wsc^T, the data gradient of the parallel
+  // 1x1 shortcut (lib/resnet_module.py:25-33), in the otherwise idle half of the last k step
+  const bf16_t* pw;
+  int pw_cs;
 };
 
-template <int CI, int CO, bool STATS>
+template <int CI, int CO, bool STATS, bool PW = false>
 __global__ __launch_bounds__(256, 2) void b3conv_kernel(B3Args a) {
   using G = B3<CI, CO>;
+  static_assert(!PW || (CI == 8 && CO == 16 && !STATS), "fused shortcut term: the 8 -> 16 data gradient");
   constexpr int CPV = G::CPV, PX = G::PX, RPW = G::RPW, KS = G::KS, MT = G::MT, NCH = CO / 8;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::PLANE];
+  constexpr int PWPLANE = PW ? G::PX * G::PY * 16 : 0, SLOT = G::PLANE + PWPLANE;   // the shortcut's plane rides behind the x plane
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SLOT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   int bid = blockIdx.x;
@@ -86,7 +92,11 @@ __global__ __launch_bounds__(256, 2) void b3conv_kernel(B3Args a) {
       }
     }
   }
-  u32x4 st[G::NST];
+  u32x4 st[G::NST], stpw = {0u, 0u, 0u, 0u};
+  // shortcut plane (PW): interior voxels only, one piece per thread (32 x 8 tile), kept at the x plane's coordinates
+  const int pwy = tid >> 5, pwx = tid & 31;
+  const bool pwok = PW && y0 + pwy < a.Y && x0 + pwx < a.X;
+  const int pwrel = PW ? ((y0 + pwy) * a.X + x0 + pwx) * a.pw_cs : 0;
   auto stage_load = [&](int p) {
     const bool pz = p >= 0 && p < a.Z;
     const bf16_t* base = a.in + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
@@ -96,13 +106,18 @@ __global__ __launch_bounds__(256, 2) void b3conv_kernel(B3Args a) {
       if (pz && ((sval >> i) & 1u)) v = *(const u32x4*)(base + srel[i]);
       st[i] = v;
     }
+    if constexpr (PW) {
+      stpw = (u32x4){0u, 0u, 0u, 0u};
+      if (pz && pwok) stpw = *(const u32x4*)(a.pw + ((size_t)n * a.Z + p) * a.Y * a.X * a.pw_cs + pwrel);
+    }
   };
   auto stage_store = [&](int slot) {
 #pragma unroll
     for (int i = 0; i < G::NST; ++i) {
       const int idx = tid + 256 * i;
-      if (idx < G::PIECES) *(u32x4*)(lds + slot * G::PLANE + idx * 16) = st[i];
+      if (idx < G::PIECES) *(u32x4*)(lds + slot * SLOT + idx * 16) = st[i];
     }
+    if constexpr (PW) *(u32x4*)(lds + slot * SLOT + G::PLANE + ((pwy + 1) * PX + pwx + 1) * 16) = stpw;
   };
 
   // B operand: lane (column c = voxel, k half h) reads in-plane tap 2 m + h (CI = 8) | channel half h of tap m (CI = 16)
@@ -112,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void b3conv_kernel(B3Args a) {
     int t = CI == 8 ? 2 * m + h : m;
     if (t > 8) t = 8;
     bm[m] = (unsigned)(((((t / 3) + RPW * wave) * PX + (t % 3) + c) * CPV + (CI == 16 ? h : 0)) * 16);
+    if (PW && m == KS - 1 && h == 1) bm[m] = (unsigned)(G::PLANE + ((1 + RPW * wave) * PX + 1 + c) * 16);   // the shortcut's voxel
   }
 
   b3_f32x16 acc[RPW][MT];   // tap-plane groups as register blocks: partial sums of output plane p + 1 - group
@@ -131,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void b3conv_kernel(B3Args a) {
   int slot = 0;
   for (int p = z0 - 1; p <= z1; ++p) {
     if (p < z1) stage_load(p + 1);
-    const unsigned char* L = lds + slot * G::PLANE;
+    const unsigned char* L = lds + slot * SLOT;
 #pragma unroll
     for (int nt = 0; nt < RPW; ++nt) {
       b3_f32x16 cc[MT];
@@ -232,6 +248,7 @@ struct B3PackArgs {
   bf16_t* wp;
   int tapw[27];   // weight tap index by displacement (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1), -1 = no such tap
   int Kw, Nw, w_tap_stride, w_sk, w_sn;
+  const float* pw_w;   // shortcut weights [produced channel of the data gradient][8] or null
 };
 
 // fp32 master weights -> A operands: lane (row = l & 31, k half h = l >> 5) of k step m, row tile mt holds 8 contraction
@@ -253,6 +270,8 @@ __global__ void b3conv_pack_kernel(B3PackArgs k) {
     const int tw = k.tapw[rg * 9 + t];
     if (tw >= 0) v = k.w[(size_t)tw * k.w_tap_stride + (size_t)ci * k.w_sk + (size_t)co * k.w_sn];
   }
+  // the idle slot (tap "9") of the centre tap plane carries the shortcut: dx[co] += sum_j pw[j] * Wsc[co][j]
+  if (CI == 8 && k.pw_w && t == 9 && rg == 1 && co < k.Nw) v = k.pw_w[(size_t)co * 8 + j];
   k.wp[e] = f2bf(v);
 }
 
@@ -292,13 +311,20 @@ bool b3conv_ok(const GatherGeom& g) {
   return true;
 }
 
+bool b3conv_pw_ok(const GatherGeom& g) {
+  static const bool off = getenv("URSN_B3CONV_PW") && getenv("URSN_B3CONV_PW")[0] == '0';
+  return !off && b3conv_ok(g) && g.K == 8 && g.Nn == 16;
+}
 size_t b3conv_pack_elems() { return (size_t)B3<16, 16>::WPACK + 8; }
 int b3conv_grid_blocks(const GatherGeom& g) { return b3_plan(g).grid; }
 
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
-                  double* stats_partial, int stats_off, int stats_total, hipStream_t s) {
+                  double* stats_partial, int stats_off, int stats_total, hipStream_t s, const bf16_t* pw, int pw_cs,
+                  const float* pw_w) {
   URSN_REQUIRE(b3conv_ok(g), "bf16 3x3x3 conv: unsupported geometry");
+  URSN_REQUIRE(!pw || (b3conv_pw_ok(g) && pw_w && !stats_partial && (pw_cs & 7) == 0), "bf16 3x3x3 conv: the fused shortcut term needs the 8 -> 16 data gradient");
   B3PackArgs k;
+  k.pw_w = pw ? pw_w : nullptr;
   k.w = w; k.wp = wpack; k.Kw = Kw > 0 ? Kw : g.K; k.Nw = Nw > 0 ? Nw : g.Nn;
   k.w_tap_stride = g.w_tap_stride; k.w_sk = g.w_sk; k.w_sn = g.w_sn;
   for (int i = 0; i < 27; ++i) k.tapw[i] = -1;
@@ -311,6 +337,14 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
   a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
   a.accumulate = g.accumulate;
   a.stats_off = stats_off; a.stats_total = stats_total > 0 ? stats_total : p.grid;
+  a.pw = pw; a.pw_cs = pw_cs;
+  if (pw) {
+    hipLaunchKernelGGL((b3conv_pack_kernel<8, 16>), dim3((B3<8, 16>::WPACK + 255) / 256), dim3(256), 0, s, k);
+    ursn_note_kernel("b3conv_bf16<8,16>+pw");
+    hipLaunchKernelGGL((b3conv_kernel<8, 16, false, true>), dim3(p.grid), dim3(256), 0, s, a);
+    URSN_HIP(hipGetLastError());
+    return 0;
+  }
 #define B3GO(ci, co, label)                                                                                              \
   if (g.K == ci && g.Nn == co) {                                                                                          \
     hipLaunchKernelGGL((b3conv_pack_kernel<ci, co>), dim3((B3<ci, co>::WPACK + 255) / 256), dim3(256), 0, s, k);          \

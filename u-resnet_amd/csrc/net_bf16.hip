@@ -368,7 +368,8 @@ bool take_flag(ursn_bnet* n, const BAct& a) {
   return acc;
 }
 
-int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipStream_t s) {
+// fused_sc >= 0: the data gradient also carries the term of that (1x1, stride-1) shortcut layer
+int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipStream_t s, int fused_sc = -1) {
   BLayer& L = n->layers[li];
   GatherGeom g[8];
   int Kw, Nw;
@@ -398,6 +399,12 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
   bool empty = false;
   for (int i = 0; i < cnt; ++i) empty = empty || g[i].ntaps == 0;
   URSN_REQUIRE(!empty || acc, "bf16 backward: %s would leave voxels of its input gradient unwritten", L.name.c_str());
+  if (fused_sc >= 0) {
+    const BLayer& S = n->layers[fused_sc];
+    URSN_REQUIRE(cnt == 1 && b3conv_pw_ok(g[0]) && S.kin == 16 && S.cin == 16 && S.cout == 8 && S.kout == 8, "bf16 backward: no fused shortcut term for %s", L.name.c_str());
+    g[0].accumulate = acc ? 1 : 0;
+    return launch_b3conv(g[0], L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, 0, 0, s, S.dz, S.kout, n->params + S.w_off);
+  }
   if (bdeconv_ok(g, cnt))   // stride-2 conv 8 -> 16: the eight parity classes of its data gradient in one launch
     return launch_bdeconv(g, cnt, L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, acc ? 1 : 0, s);
   for (int i = 0; i < cnt; ++i) {
@@ -435,8 +442,15 @@ int unit_bwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s) {
   }
   URSN_TRY(conv_bwd(n, u.c2, u.a1, true, N, s));
   URSN_TRY(bn_back(n, u.c1, u.a1.g, u.a1.cs, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
-  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s));                 // k3 (s1 | s2): writes every voxel of d(in)
-  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, true, N, s));  // 1x1 (s1 | s2): accumulates
+  bool fuse = false;   // stride-1 shortcut next to an 8 -> 16 data gradient: its term rides in that kernel's idle k slot
+  if (u.sc >= 0 && n->layers[u.sc].stride == 1) {
+    GatherGeom g[8];
+    const BLayer& S = n->layers[u.sc];
+    fuse = layer_geoms(n, n->layers[u.c1], PASS_DGRAD, N, u.in.cs, n->layers[u.c1].kout, g) == 1 && b3conv_pw_ok(g[0]) &&
+           S.kin == 16 && S.cin == 16 && S.cout == 8 && S.kout == 8;
+  }
+  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, fuse ? u.sc : -1));   // k3 (s1 | s2): writes every voxel of d(in)
+  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, !fuse, N, s));      // 1x1 (s1 | s2): weight gradient (+ accumulated data gradient)
   return 0;
 }
 
