@@ -64,9 +64,19 @@ int b3conv_grid_blocks(const GatherGeom& g);
 // pw (data gradient 8 -> 16 only, b3conv_pw_ok): + pw[v] . pw_w^T, the data gradient of the module's 1x1 shortcut
 // (pw = the shortcut's dz, 8 channels; pw_w = its weights [16][8])
 bool b3conv_pw_ok(const GatherGeom& g);
+// bs (data gradients 8 -> 8, b3conv_bs_ok): the BatchNorm-backward reductions of the layer(s) consuming the produced gradient,
+// taken in the epilogue: partial[b3conv_grid_blocks(g)][3][8] doubles for launch_bbn_bwd (BBnBwdArgs.pre_partial)
+struct B3BnRed {
+  const bf16_t* z; int z_cs; const float* mean; const float* rstd; const float* beta;   // beta: mode 2
+  const bf16_t* y; int y_cs;                                                           // mode 1: mask = y > 0
+  const bf16_t* z2; int z2_cs; const float* mean2; const float* rstd2;                 // second BatchNorm of a join (optional)
+  int mode;                                                                            // 0 no mask, 1 y > 0, 2 bn(z) > 0
+  double* partial;
+};
+bool b3conv_bs_ok(const GatherGeom& g);
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                   double* stats_partial, int stats_off, int stats_total, hipStream_t s, const bf16_t* pw = nullptr,
-                  int pw_cs = 0, const float* pw_w = nullptr);
+                  int pw_cs = 0, const float* pw_w = nullptr, const B3BnRed* bs = nullptr);
 // 1x1 stride-1 conv between 8 / 16 channel tensors, operands straight from global memory (bf16_pointwise.hip)
 bool bpw_ok(const GatherGeom& g);
 int bpw_grid_blocks(const GatherGeom& g);
@@ -105,6 +115,7 @@ struct BBnBwdArgs {   // as BnBwdArgs (ursn_common.h) on bf16 tensors; the relu 
   int64_t V; int C; int relu;
   void* scratch;
   int Cw;
+  const double* pre_partial; int pre_nblocks;   // the reductions came out of the producing kernel's epilogue: [pre_nblocks][3][C]
 };
 int launch_bbn_bwd(const BBnBwdArgs& a, hipStream_t s);
 size_t bbn_scratch_bytes(int64_t V, int C);

@@ -47,12 +47,20 @@ struct B3Args {
   // 1x1 shortcut (lib/resnet_module.py:25-33), in the otherwise idle half of the last k step
   const bf16_t* pw;
   int pw_cs;
+  // BS instantiations (data gradients producing 8 channels): the BatchNorm-backward reductions of the layer(s) whose output
+  // gradient this launch completes, g = stored dx * mask: partial[block][0][c] = sum g, [1][c] = sum g * xhat(z),
+  // [2][c] = sum g * xhat(z2) (BS = 2).  bs_mode: 0 no mask, 1 mask = y > 0 (bs_y), 2 mask = bn(z) > 0 (bs_beta)
+  const bf16_t* bs_z; const bf16_t* bs_y; const bf16_t* bs_z2;
+  const float* bs_mean; const float* bs_rstd; const float* bs_beta; const float* bs_mean2; const float* bs_rstd2;
+  double* bs_partial;
+  int bs_z_cs, bs_y_cs, bs_z2_cs, bs_mode;
 };
 
-template <int CI, int CO, bool STATS, bool PW = false>
-__global__ __launch_bounds__(256, 2) void b3conv_kernel(B3Args a) {
+template <int CI, int CO, bool STATS, bool PW = false, int BS = 0>
+__global__ __launch_bounds__(256, BS == 1 ? 3 : 2) void b3conv_kernel(B3Args a) {
   using G = B3<CI, CO>;
   static_assert(!PW || (CI == 8 && CO == 16 && !STATS), "fused shortcut term: the 8 -> 16 data gradient");
+  static_assert(BS == 0 || (CO == 8 && !STATS && !PW), "fused BatchNorm-backward reductions: data gradients producing 8 channels");
   constexpr int CPV = G::CPV, PX = G::PX, RPW = G::RPW, KS = G::KS, MT = G::MT, NCH = CO / 8;
   constexpr int PWPLANE = PW ? G::PX * G::PY * 16 : 0, SLOT = G::PLANE + PWPLANE;   // the shortcut's plane rides behind the x plane
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SLOT];
@@ -140,6 +148,17 @@ __global__ __launch_bounds__(256, 2) void b3conv_kernel(B3Args a) {
   float piv[4 * NCH], s1[4 * NCH], s2[4 * NCH], nacc = 0.f;
 #pragma unroll
   for (int k = 0; k < 4 * NCH; ++k) piv[k] = s1[k] = s2[k] = 0.f;
+  // BS: this lane's four channels (4 h ..); per-lane sums in fp32 (<= zseg x 4 terms of bf16 data), fp64 across lanes
+  float bmu[4], brs[4], bsh[4], bmu2[4], brs2[4], bg[4], bgx[4], bgx2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    bmu[k] = brs[k] = bsh[k] = bmu2[k] = brs2[k] = bg[k] = bgx[k] = bgx2[k] = 0.f;
+    if constexpr (BS != 0) {
+      bmu[k] = a.bs_mean[4 * h + k]; brs[k] = a.bs_rstd[4 * h + k];
+      if (a.bs_mode == 2) bsh[k] = a.bs_beta[4 * h + k] - bmu[k] * brs[k];
+      if constexpr (BS == 2) { bmu2[k] = a.bs_mean2[4 * h + k]; brs2[k] = a.bs_rstd2[4 * h + k]; }
+    }
+  }
 
   stage_load(z0 - 1);
   stage_store(0);
@@ -209,6 +228,36 @@ __global__ __launch_bounds__(256, 2) void b3conv_kernel(B3Args a) {
                 ursn_sacc(piv[4 * cb + k], s1[4 * cb + k], s2[4 * cb + k], rv[k]);
               }
             }
+            if constexpr (BS != 0) {   // g = the STORED gradient (what the BatchNorm backward will read) under the activation mask
+              const size_t vox = (((size_t)n * a.Z + q) * a.Y + gy) * a.X + gx;
+              float gq[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
+                             __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+              const u32x2 zc = *(const u32x2*)(a.bs_z + vox * a.bs_z_cs + 4 * h);
+              const float zf[4] = {__uint_as_float(zc[0] << 16), __uint_as_float(zc[0] & 0xffff0000u),
+                                   __uint_as_float(zc[1] << 16), __uint_as_float(zc[1] & 0xffff0000u)};
+              if (a.bs_mode == 1) {
+                const u32x2 yc = *(const u32x2*)(a.bs_y + vox * a.bs_y_cs + 4 * h);
+                const float yf[4] = {__uint_as_float(yc[0] << 16), __uint_as_float(yc[0] & 0xffff0000u),
+                                     __uint_as_float(yc[1] << 16), __uint_as_float(yc[1] & 0xffff0000u)};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (!(yf[k] > 0.f)) gq[k] = 0.f;
+              } else if (a.bs_mode == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (!(fmaf(zf[k], brs[k], bsh[k]) > 0.f)) gq[k] = 0.f;   // same expression as bbn_bwd
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                bg[k] += gq[k];
+                bgx[k] = fmaf(gq[k], (zf[k] - bmu[k]) * brs[k], bgx[k]);
+              }
+              if constexpr (BS == 2) {
+                const u32x2 z2c = *(const u32x2*)(a.bs_z2 + vox * a.bs_z2_cs + 4 * h);
+                const float z2f[4] = {__uint_as_float(z2c[0] << 16), __uint_as_float(z2c[0] & 0xffff0000u),
+                                      __uint_as_float(z2c[1] << 16), __uint_as_float(z2c[1] & 0xffff0000u)};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bgx2[k] = fmaf(gq[k], (z2f[k] - bmu2[k]) * brs2[k], bgx2[k]);
+              }
+            }
           }
           if constexpr (STATS) nacc += 1.f;
         }
@@ -219,6 +268,18 @@ __global__ __launch_bounds__(256, 2) void b3conv_kernel(B3Args a) {
     slot ^= 1;
   }
 
+  if constexpr (BS != 0) {   // [block][3][8] doubles: the layout bn_bwd_final_kernel reads
+    __shared__ double bred[4][24];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double u = (double)bg[k], w2 = (double)bgx[k], x2 = (double)bgx2[k];
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); x2 += __shfl_xor(x2, o); }
+      if (c == 0) { bred[wave][4 * h + k] = u; bred[wave][8 + 4 * h + k] = w2; bred[wave][16 + 4 * h + k] = x2; }
+    }
+    __syncthreads();
+    if (tid < 24) a.bs_partial[(size_t)blockIdx.x * 24 + tid] = (bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid]);
+  }
   if constexpr (STATS) {
     __shared__ double red[4][32];
 #pragma unroll
@@ -318,9 +379,17 @@ bool b3conv_pw_ok(const GatherGeom& g) {
 size_t b3conv_pack_elems() { return (size_t)B3<16, 16>::WPACK + 8; }
 int b3conv_grid_blocks(const GatherGeom& g) { return b3_plan(g).grid; }
 
+// Off unless URSN_BF16_FUSE_BN_BWD_REDUCE=1: measured at cfg5 (256^3 x 4) the five fused launches cost more than the five
+// bbn_bwd_reduce passes they replace (65.1 vs 67.0 img/s) -- the epilogue's z / y loads sit between the MFMA block and the plane
+// barrier of an HBM-bound kernel.  Kept (and parity-tested) as the starting point for a prefetched version.
+bool b3conv_bs_ok(const GatherGeom& g) {
+  static const bool on = getenv("URSN_BF16_FUSE_BN_BWD_REDUCE") && getenv("URSN_BF16_FUSE_BN_BWD_REDUCE")[0] == '1';
+  return on && b3conv_ok(g) && g.Nn == 8 && g.K == 8;
+}
+
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                   double* stats_partial, int stats_off, int stats_total, hipStream_t s, const bf16_t* pw, int pw_cs,
-                  const float* pw_w) {
+                  const float* pw_w, const B3BnRed* bs) {
   URSN_REQUIRE(b3conv_ok(g), "bf16 3x3x3 conv: unsupported geometry");
   URSN_REQUIRE(!pw || (b3conv_pw_ok(g) && pw_w && !stats_partial && (pw_cs & 7) == 0), "bf16 3x3x3 conv: the fused shortcut term needs the 8 -> 16 data gradient");
   B3PackArgs k;
@@ -338,6 +407,20 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
   a.accumulate = g.accumulate;
   a.stats_off = stats_off; a.stats_total = stats_total > 0 ? stats_total : p.grid;
   a.pw = pw; a.pw_cs = pw_cs;
+  a.bs_partial = nullptr;
+  if (bs) {
+    URSN_REQUIRE(b3conv_bs_ok(g) && !pw && !stats_partial && bs->z && bs->mean && bs->rstd && bs->partial && (bs->mode != 1 || bs->y) &&
+                 (bs->mode != 2 || bs->beta) && (!bs->z2 || (bs->mean2 && bs->rstd2)), "bf16 3x3x3 conv: bad fused BatchNorm-backward arguments");
+    a.bs_z = bs->z; a.bs_y = bs->y; a.bs_z2 = bs->z2; a.bs_mean = bs->mean; a.bs_rstd = bs->rstd; a.bs_beta = bs->beta;
+    a.bs_mean2 = bs->mean2; a.bs_rstd2 = bs->rstd2; a.bs_partial = bs->partial;
+    a.bs_z_cs = bs->z_cs; a.bs_y_cs = bs->y_cs; a.bs_z2_cs = bs->z2_cs; a.bs_mode = bs->mode;
+    hipLaunchKernelGGL((b3conv_pack_kernel<8, 8>), dim3((B3<8, 8>::WPACK + 255) / 256), dim3(256), 0, s, k);
+    ursn_note_kernel("b3conv_bf16<8,8>+bnred");
+    if (bs->z2) hipLaunchKernelGGL((b3conv_kernel<8, 8, false, false, 2>), dim3(p.grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((b3conv_kernel<8, 8, false, false, 1>), dim3(p.grid), dim3(256), 0, s, a);
+    URSN_HIP(hipGetLastError());
+    return 0;
+  }
   if (pw) {
     hipLaunchKernelGGL((b3conv_pack_kernel<8, 16>), dim3((B3<8, 16>::WPACK + 255) / 256), dim3(256), 0, s, k);
     ursn_note_kernel("b3conv_bf16<8,16>+pw");

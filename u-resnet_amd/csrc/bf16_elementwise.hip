@@ -376,13 +376,16 @@ int launch_bbn_bwd(const BBnBwdArgs& a, hipStream_t s) {
   double* partial = (double*)a.scratch;
   double* finals = partial + (size_t)m.grid * 3 * a.C;
   const int mask = !a.relu ? 0 : (a.y ? 1 : 2);
-  if (m.shift > 2) URSN_HIP(hipMemsetAsync(partial, 0, (size_t)rgrid * 3 * a.C * sizeof(double), s));   // atomics path of the block reduce
+  if (!a.pre_partial && m.shift > 2) URSN_HIP(hipMemsetAsync(partial, 0, (size_t)rgrid * 3 * a.C * sizeof(double), s));   // atomics path of the block reduce
 #define BRED(c8, mk, h2) hipLaunchKernelGGL((bbn_bwd_reduce_kernel<c8, mk, h2>), dim3(rgrid), dim3(256), 0, s, a, m.shift, partial)
 #define BRED2(c8, mk) do { if (a.z2) BRED(c8, mk, true); else BRED(c8, mk, false); } while (0)
 #define BRED3(c8) do { if (mask == 0) BRED2(c8, 0); else if (mask == 1) BRED2(c8, 1); else BRED2(c8, 2); } while (0)
-  if (a.C == 8) BRED3(true); else BRED3(false);
+  if (a.pre_partial) { /* sums taken by the kernel that produced dy */ }
+  else if (a.C == 8) BRED3(true);
+  else BRED3(false);
   URSN_HIP(hipGetLastError());
-  URSN_TRY(launch_bn_bwd_final(partial, rgrid, a.C, a.V, finals, a.dbeta, a.z2 ? a.dbeta2 : nullptr, a.Cw > 0 ? a.Cw : a.C, s));
+  URSN_TRY(launch_bn_bwd_final(a.pre_partial ? a.pre_partial : partial, a.pre_partial ? a.pre_nblocks : rgrid, a.C, a.V, finals, a.dbeta,
+                               a.z2 ? a.dbeta2 : nullptr, a.Cw > 0 ? a.Cw : a.C, s));
 #define BAPP(c8, mk, h2, dr) hipLaunchKernelGGL((bbn_bwd_apply_kernel<c8, mk, h2, dr>), dim3(agrid), dim3(256), 0, s, a, m.shift, (const double*)finals)
 #define BAPP1(c8, mk, h2) do { if (a.dres) BAPP(c8, mk, h2, true); else BAPP(c8, mk, h2, false); } while (0)
 #define BAPP2(c8, mk) do { if (a.z2) BAPP1(c8, mk, true); else BAPP1(c8, mk, false); } while (0)

@@ -55,6 +55,9 @@ struct BUnit {
 }  // namespace
 
 struct ursn_bnet {
+  // BatchNorm-backward reductions taken in the epilogue of the data gradient that completed the layer's output gradient
+  double* bs_scratch = nullptr;
+  int bs_layer = -1, bs_blocks = 0;
   ursn_config cfg;
   ursn_sizes sizes;
   int nlev = 0;
@@ -267,6 +270,7 @@ int plan(ursn_bnet* n, Arena& A) {
   n->bn_scratch = A.take(bn + 256);
   n->wg_bytes = wg;
   n->wg_scratch = tr ? A.take(wg + 256) : nullptr;
+  n->bs_scratch = tr ? (double*)A.take((size_t)16384 * 24 * sizeof(double)) : nullptr;
 
   n->sizes.n_params = poff;
   n->sizes.n_layers = (int64_t)n->layers.size();
@@ -368,8 +372,15 @@ bool take_flag(ursn_bnet* n, const BAct& a) {
   return acc;
 }
 
+// The BatchNorm backward that consumes the gradient a data-gradient launch completes (as net.hip's BsTarget)
+struct BBsTarget {
+  int li = -1, li2 = -1, mode = 0;   // mode: 0 no activation, 1 mask = y > 0, 2 mask = bn(z) > 0
+  const bf16_t* y = nullptr; int ycs = 0;
+};
+
 // fused_sc >= 0: the data gradient also carries the term of that (1x1, stride-1) shortcut layer
-int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipStream_t s, int fused_sc = -1) {
+int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipStream_t s, int fused_sc = -1,
+             const BBsTarget* bs = nullptr) {
   BLayer& L = n->layers[li];
   GatherGeom g[8];
   int Kw, Nw;
@@ -399,6 +410,26 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
   bool empty = false;
   for (int i = 0; i < cnt; ++i) empty = empty || g[i].ntaps == 0;
   URSN_REQUIRE(!empty || acc, "bf16 backward: %s would leave voxels of its input gradient unwritten", L.name.c_str());
+  n->bs_layer = -1;
+  if (bs && bs->li >= 0 && fused_sc < 0 && cnt == 1 && b3conv_bs_ok(g[0]) && in.C == 8 && in.cs == 8) {
+    const BLayer& T = n->layers[bs->li];
+    const int blocks = bconv_grid_blocks(g[0]);
+    if (T.kout == 8 && blocks <= 16384 && (bs->li2 < 0 || n->layers[bs->li2].kout == 8)) {
+      B3BnRed r;
+      memset(&r, 0, sizeof(r));
+      r.z = T.z; r.z_cs = T.kout; r.mean = T.mean; r.rstd = T.rstd; r.beta = beta_of(n, T);
+      r.y = bs->y; r.y_cs = bs->ycs; r.mode = bs->mode;
+      if (bs->li2 >= 0) {
+        const BLayer& T2 = n->layers[bs->li2];
+        r.z2 = T2.z; r.z2_cs = T2.kout; r.mean2 = T2.mean; r.rstd2 = T2.rstd;
+      }
+      r.partial = n->bs_scratch;
+      g[0].accumulate = acc ? 1 : 0;
+      URSN_TRY(launch_b3conv(g[0], L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, 0, 0, s, nullptr, 0, nullptr, &r));
+      n->bs_layer = bs->li; n->bs_blocks = blocks;
+      return 0;
+    }
+  }
   if (fused_sc >= 0) {
     const BLayer& S = n->layers[fused_sc];
     URSN_REQUIRE(cnt == 1 && b3conv_pw_ok(g[0]) && S.kin == 16 && S.cin == 16 && S.cout == 8 && S.kout == 8, "bf16 backward: no fused shortcut term for %s", L.name.c_str());
@@ -430,17 +461,21 @@ int bn_back(ursn_bnet* n, int li, const bf16_t* dy, int dycs, const bf16_t* y, i
   }
   a.dres = dres; a.drescs = drescs; a.dres_accumulate = dres_acc;
   a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.kout; a.Cw = L.cout; a.relu = relu; a.scratch = n->bn_scratch;
+  if (n->bs_layer == li && a.C == 8) { a.pre_partial = n->bs_scratch; a.pre_nblocks = n->bs_blocks; }
+  n->bs_layer = -1;
   return launch_bbn_bwd(a, s);
 }
 
-int unit_bwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s) {
+int unit_bwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s, const BBsTarget* in_target = nullptr) {
   if (u.sc >= 0) {
     URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, u.sc, nullptr, 0, 0, N, s));
   } else {
     const bool acc = take_flag(n, u.in);
     URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, -1, u.in.g, u.in.cs, acc ? 1 : 0, N, s));
   }
-  URSN_TRY(conv_bwd(n, u.c2, u.a1, true, N, s));
+  BBsTarget t1;   // conv2's data gradient IS d(a1): resnet_conv1's BatchNorm (no activation) consumes it
+  t1.li = u.c1;
+  URSN_TRY(conv_bwd(n, u.c2, u.a1, true, N, s, -1, &t1));
   URSN_TRY(bn_back(n, u.c1, u.a1.g, u.a1.cs, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
   bool fuse = false;   // stride-1 shortcut next to an 8 -> 16 data gradient: its term rides in that kernel's idle k slot
   if (u.sc >= 0 && n->layers[u.sc].stride == 1) {
@@ -449,7 +484,8 @@ int unit_bwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s) {
     fuse = layer_geoms(n, n->layers[u.c1], PASS_DGRAD, N, u.in.cs, n->layers[u.c1].kout, g) == 1 && b3conv_pw_ok(g[0]) &&
            S.kin == 16 && S.cin == 16 && S.cout == 8 && S.kout == 8;
   }
-  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, fuse ? u.sc : -1));   // k3 (s1 | s2): writes every voxel of d(in)
+  // with an identity shortcut conv1's data gradient is the last contribution to d(in): its consumer's reductions ride along
+  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, fuse ? u.sc : -1, u.sc < 0 ? in_target : nullptr));   // k3 (s1 | s2): writes every voxel of d(in)
   if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, !fuse, N, s));      // 1x1 (s1 | s2): weight gradient (+ accumulated data gradient)
   return 0;
 }
@@ -459,19 +495,25 @@ int backward(ursn_bnet* n, int N, hipStream_t s) {
   for (size_t i = 0; i < n->ginit.size(); ++i) n->ginit[i] = 0;
   n->ev_used = 0;
   URSN_TRY(bn_back(n, n->conv2, n->dlog, 8, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
-  URSN_TRY(conv_bwd(n, n->conv2, n->a_conv1, true, N, s));
+  BBsTarget tc;
+  tc.li = n->conv1; tc.mode = 2;
+  URSN_TRY(conv_bwd(n, n->conv2, n->a_conv1, true, N, s, -1, &tc));
   URSN_TRY(bn_back(n, n->conv1, n->a_conv1.g, n->a_conv1.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
-  URSN_TRY(conv_bwd(n, n->conv1, n->a_pre1, true, N, s));
   size_t ui = n->units.size();
+  auto join_of = [&](const BUnit& u) { BBsTarget t; t.li = u.c2; t.li2 = u.sc; t.mode = 1; t.y = u.out.p; t.ycs = u.out.cs; return t; };
+  tc = join_of(n->units[ui - 1]);
+  URSN_TRY(conv_bwd(n, n->conv1, n->a_pre1, true, N, s, -1, &tc));
   for (int i = ns - 1; i >= 0; --i) {
-    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
+    tc = join_of(n->units[ui - 2]);
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s, &tc));
     URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
     const BAct& dout = n->deconv_out[i];
     URSN_TRY(bn_back(n, n->deconv[i], dout.g, dout.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
     URSN_TRY(conv_bwd(n, n->deconv[i], n->deconv_in[i], true, N, s));
   }
   for (int step = ns - 1; step >= 0; --step) {
-    URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
+    tc = join_of(n->units[ui - 2]);
+    URSN_TRY(unit_bwd(n, n->units[--ui], N, s, &tc));
     URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
   }
   const BAct& a0 = n->a_conv0;
