@@ -80,8 +80,9 @@ __device__ inline void block_reduce_store8(const float (&acc)[NS][8], int CP, in
   constexpr int U = URSN_BEW_U;                                                                           \
   const int64_t chunkv = (int64_t)VPB * U, nchunks = (a.V + chunkv - 1) / chunkv
 
-template <bool C8, bool HAS2, bool HASR>
+template <bool C8, bool HAS2, bool HASR, bool CAT = false>
 __global__ __launch_bounds__(256) void bbn_act_kernel(BBnActArgs a, int shift) {
+  static_assert(!CAT || (C8 && HAS2 && !HASR), "concat form: two 8-channel BatchNorm outputs side by side");
   BEW_MAP;
   if (c >= a.C) return;
   float sc[8], sh[8], sc2[8], sh2[8];
@@ -115,6 +116,18 @@ __global__ __launch_bounds__(256) void bbn_act_kernel(BBnActArgs a, int shift) {
         unpack8(x[u], f);
         if constexpr (HAS2) unpack8(x2[u], f2);
         if constexpr (HASR) unpack8(r[u], fr);
+        if constexpr (CAT) {
+          float y2[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float t = fmaf(f[j], sc[j], sh[j]), t2 = fmaf(f2[j], sc2[j], sh2[j]);
+            if (relu) { t = fmaxf(t, 0.f); t2 = fmaxf(t2, 0.f); }
+            y[j] = t; y2[j] = t2;
+          }
+          *(u32x4*)(a.y + v * a.ycs) = pack8(y);
+          *(u32x4*)(a.y + v * a.ycs + 8) = pack8(y2);
+          continue;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float t = fmaf(f[j], sc[j], sh[j]);
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(256) void bbn_act_kernel(BBnActArgs a, int shift) {
 // MASK: 0 no activation, 1 mask = y > 0 (y given), 2 mask = bn(z) > 0 (beta given).
 // Per-thread sums in fp32: a thread adds <= ~1e3 terms of bf16-rounded data (relative error ~1e-6 of its own partial sum);
 // everything across threads and blocks is fp64.
-template <bool C8, int MASK, bool HAS2>
+template <bool C8, int MASK, bool HAS2, bool D2 = false>
 __global__ __launch_bounds__(256) void bbn_bwd_reduce_kernel(BBnBwdArgs a, int shift, double* __restrict__ partial) {
   BEW_MAP;
   float acc[3][8];
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(256) void bbn_bwd_reduce_kernel(BBnBwdArgs a, int s
       const int64_t vb = ch * chunkv + vr;
       auto body = [&](auto FULL) {
         constexpr bool full = decltype(FULL)::value;
-        u32x4 gp[U], zp[U], yp[U], z2p[U];
+        u32x4 gp[U], zp[U], yp[U], z2p[U], g2p[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int64_t v = vb + (int64_t)u * VPB;
@@ -162,6 +175,7 @@ __global__ __launch_bounds__(256) void bbn_bwd_reduce_kernel(BBnBwdArgs a, int s
             zp[u] = ld16(a.z + v * a.zcs + c);
             if constexpr (MASK == 1) yp[u] = ld16(a.y + v * a.ycs + c);
             if constexpr (HAS2) z2p[u] = ld16(a.z2 + v * a.z2cs + c);
+            if constexpr (D2) g2p[u] = ld16(a.dy2 + v * a.dy2cs + c);
           }
         }
 #pragma unroll
@@ -169,6 +183,12 @@ __global__ __launch_bounds__(256) void bbn_bwd_reduce_kernel(BBnBwdArgs a, int s
           if (!full && vb + (int64_t)u * VPB >= a.V) continue;
           float g[8], z[8], y[8], z2[8];
           unpack8(gp[u], g); unpack8(zp[u], z);
+          if constexpr (D2) {
+            float g2[8];
+            unpack8(g2p[u], g2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] += g2[j];
+          }
           if constexpr (MASK == 1) unpack8(yp[u], y);
           if constexpr (HAS2) unpack8(z2p[u], z2);
 #pragma unroll
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(256) void bbn_bwd_reduce_kernel(BBnBwdArgs a, int s
 }
 
 // DRES: 0 none, 1 dres = / += g (the identity shortcut's share of the join gradient)
-template <bool C8, int MASK, bool HAS2, bool DRES>
+template <bool C8, int MASK, bool HAS2, bool DRES, bool D2 = false>
 __global__ __launch_bounds__(256) void bbn_bwd_apply_kernel(BBnBwdArgs a, int shift, const double* __restrict__ finals) {
   BEW_MAP;
   if (c >= a.C) return;
@@ -207,12 +227,13 @@ __global__ __launch_bounds__(256) void bbn_bwd_apply_kernel(BBnBwdArgs a, int sh
     const int64_t vb = ch * chunkv + vr;
     auto body = [&](auto FULL) {
       constexpr bool full = decltype(FULL)::value;
-      u32x4 gp[U], zp[U], yp[U], z2p[U], drp[U];
+      u32x4 gp[U], zp[U], yp[U], z2p[U], drp[U], g2p[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t v = vb + (int64_t)u * VPB;
         if (full || v < a.V) {
           gp[u] = ld16(a.dy + v * a.dycs + c);
+          if constexpr (D2) g2p[u] = ld16(a.dy2 + v * a.dy2cs + c);
           zp[u] = ld16(a.z + v * a.zcs + c);
           if constexpr (MASK == 1) yp[u] = ld16(a.y + v * a.ycs + c);
           if constexpr (HAS2) z2p[u] = ld16(a.z2 + v * a.z2cs + c);
@@ -225,6 +246,12 @@ __global__ __launch_bounds__(256) void bbn_bwd_apply_kernel(BBnBwdArgs a, int sh
         if (!full && v >= a.V) continue;
         float g[8], z[8], y[8], z2[8], dr[8], dz[8], dz2[8];
         unpack8(gp[u], g); unpack8(zp[u], z);
+        if constexpr (D2) {
+          float g2[8];
+          unpack8(g2p[u], g2);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) g[j] += g2[j];
+        }
         if constexpr (MASK == 1) unpack8(yp[u], y);
         if constexpr (HAS2) unpack8(z2p[u], z2);
         if constexpr (DRES) { if (dacc) unpack8(drp[u], dr); }
@@ -359,7 +386,10 @@ int launch_bbn_act(const BBnActArgs& a, hipStream_t s) {
 #define BACT(c8, h2, hr) hipLaunchKernelGGL((bbn_act_kernel<c8, h2, hr>), dim3(grid), dim3(256), 0, s, a, m.shift)
 #define BACT2(c8) do { if (a.z2 && a.res) BACT(c8, true, true); else if (a.z2) BACT(c8, true, false); \
                        else if (a.res) BACT(c8, false, true); else BACT(c8, false, false); } while (0)
-  if (a.C == 8) BACT2(true); else BACT2(false);
+  if (a.cat) {
+    URSN_REQUIRE(a.C == 8 && a.z2 && !a.res && a.ycs >= 16, "bf16 bn_act: the concat form needs two 8-channel inputs and a 16-channel output voxel");
+    hipLaunchKernelGGL((bbn_act_kernel<true, true, false, true>), dim3(grid), dim3(256), 0, s, a, m.shift);
+  } else if (a.C == 8) BACT2(true); else BACT2(false);
 #undef BACT2
 #undef BACT
   URSN_HIP(hipGetLastError());
@@ -380,7 +410,10 @@ int launch_bbn_bwd(const BBnBwdArgs& a, hipStream_t s) {
 #define BRED(c8, mk, h2) hipLaunchKernelGGL((bbn_bwd_reduce_kernel<c8, mk, h2>), dim3(rgrid), dim3(256), 0, s, a, m.shift, partial)
 #define BRED2(c8, mk) do { if (a.z2) BRED(c8, mk, true); else BRED(c8, mk, false); } while (0)
 #define BRED3(c8) do { if (mask == 0) BRED2(c8, 0); else if (mask == 1) BRED2(c8, 1); else BRED2(c8, 2); } while (0)
+  const bool d2 = a.dy2 != nullptr;
+  if (d2) URSN_REQUIRE(a.C == 8 && mask == 2 && !a.z2 && !a.dres && !a.pre_partial && (a.dy2cs & 7) == 0, "bf16 bn_bwd: a second gradient operand is supported for 8-channel conv-BN-ReLU layers only");
   if (a.pre_partial) { /* sums taken by the kernel that produced dy */ }
+  else if (d2) hipLaunchKernelGGL((bbn_bwd_reduce_kernel<true, 2, false, true>), dim3(rgrid), dim3(256), 0, s, a, m.shift, partial);
   else if (a.C == 8) BRED3(true);
   else BRED3(false);
   URSN_HIP(hipGetLastError());
@@ -390,7 +423,8 @@ int launch_bbn_bwd(const BBnBwdArgs& a, hipStream_t s) {
 #define BAPP1(c8, mk, h2) do { if (a.dres) BAPP(c8, mk, h2, true); else BAPP(c8, mk, h2, false); } while (0)
 #define BAPP2(c8, mk) do { if (a.z2) BAPP1(c8, mk, true); else BAPP1(c8, mk, false); } while (0)
 #define BAPP3(c8) do { if (mask == 0) BAPP2(c8, 0); else if (mask == 1) BAPP2(c8, 1); else BAPP2(c8, 2); } while (0)
-  if (a.C == 8) BAPP3(true); else BAPP3(false);
+  if (d2) hipLaunchKernelGGL((bbn_bwd_apply_kernel<true, 2, false, false, true>), dim3(agrid), dim3(256), 0, s, a, m.shift, (const double*)finals);
+  else if (a.C == 8) BAPP3(true); else BAPP3(false);
 #undef BAPP3
 #undef BAPP2
 #undef BAPP1

@@ -69,6 +69,10 @@ struct ursn_bnet {
   std::vector<BAct> deconv_in, deconv_out, cat;
   int conv0 = -1, conv1 = -1, conv2 = -1;
   BAct a_data, a_conv0, a_conv1, a_pre1;
+  // F = 8: conv0's activation lives in its own contiguous tensor; the level-0 concat voxel (16 channels) is written whole
+  // when the last transposed conv's BatchNorm runs (its half from z, the skip half recomputed from conv0's z): 16-byte
+  // halves written one tensor pass apart were partial-sector writes (1.0 ms instead of 0.36 per pass at 256^3 x 4)
+  bool skip0_own = false;
   std::vector<int> ginit;
   float *params = nullptr, *grads = nullptr;
   bf16_t* dlog = nullptr;
@@ -188,7 +192,8 @@ int plan(ursn_bnet* n, Arena& A) {
 
   n->a_data = make_act(n, A, 0, 8, false);
   n->conv0 = add_layer(n, A, "conv0", 0, 3, 1, c.cin, F, 0, 0, poff);
-  n->a_conv0 = fmap_view(0);
+  n->skip0_own = F == 8 && !(getenv("URSN_BF16_SKIP0_OWN") && getenv("URSN_BF16_SKIP0_OWN")[0] == '0');
+  n->a_conv0 = n->skip0_own ? make_act(n, A, 0, F, tr) : fmap_view(0);
   auto add_unit = [&](const std::string& scope, const BAct& in, int co, int s, int lout, const BAct* out_view) {
     BUnit u;
     u.in = in;
@@ -344,7 +349,18 @@ int forward(ursn_bnet* n, const float* data, int N, hipStream_t s) {
   }
   for (int i = 0; i < ns; ++i) {
     URSN_TRY(conv_stats(n, n->deconv[i], n->deconv_in[i], N, s));
-    URSN_TRY(bn_out(n, n->deconv[i], n->deconv_out[i], 1, N, -1, nullptr, s));
+    if (n->skip0_own && i == ns - 1) {   // both halves of the level-0 concat voxel in one pass
+      const BLayer& L = n->layers[n->deconv[i]];
+      const BLayer& L0 = n->layers[n->conv0];
+      BBnActArgs a;
+      memset(&a, 0, sizeof(a));
+      a.z = L.z; a.zcs = L.kout; a.mean = L.mean; a.rstd = L.rstd; a.beta = beta_of(n, L);
+      a.z2 = L0.z; a.z2cs = L0.kout; a.mean2 = L0.mean; a.rstd2 = L0.rstd; a.beta2 = beta_of(n, L0);
+      a.y = n->cat[i].p; a.ycs = n->cat[i].cs; a.V = (int64_t)N * n->lvox[0]; a.C = 8; a.relu = 1; a.cat = 1;
+      URSN_TRY(launch_bbn_act(a, s));
+    } else {
+      URSN_TRY(bn_out(n, n->deconv[i], n->deconv_out[i], 1, N, -1, nullptr, s));
+    }
     URSN_TRY(unit_fwd(n, n->units[ui++], N, s));
     URSN_TRY(unit_fwd(n, n->units[ui++], N, s));
   }
@@ -447,11 +463,11 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
 }
 
 int bn_back(ursn_bnet* n, int li, const bf16_t* dy, int dycs, const bf16_t* y, int ycs, int relu, int li2, bf16_t* dres,
-            int drescs, int dres_acc, int N, hipStream_t s) {
+            int drescs, int dres_acc, int N, hipStream_t s, const bf16_t* dy2 = nullptr, int dy2cs = 0) {
   BLayer& L = n->layers[li];
   BBnBwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.dy = dy; a.dycs = dycs; a.y = y; a.ycs = ycs;
+  a.dy = dy; a.dycs = dycs; a.y = y; a.ycs = ycs; a.dy2 = dy2; a.dy2cs = dy2cs;
   a.z = L.z; a.zcs = L.kout; a.mean = L.mean; a.rstd = L.rstd; a.dz = L.dz; a.dzcs = L.kout;
   a.dbeta = n->grads + L.b_off; a.beta = beta_of(n, L);
   if (li2 >= 0) {
@@ -517,7 +533,12 @@ int backward(ursn_bnet* n, int N, hipStream_t s) {
     URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
   }
   const BAct& a0 = n->a_conv0;
-  URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
+  if (n->skip0_own) {   // d(conv0 activation) = the encoder's share (own tensor) + the skip's share (second half of the concat gradient)
+    const BAct& cg = n->cat[ns - 1];
+    URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s, cg.g + cg.C / 2, cg.cs));
+  } else {
+    URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
+  }
   URSN_TRY(conv_bwd(n, n->conv0, n->a_data, false, N, s));
   if (n->s2) {
     URSN_HIP(hipEventRecord(n->s2_done, n->s2));
