@@ -73,10 +73,14 @@ struct B3BnRed {
   int mode;                                                                            // 0 no mask, 1 y > 0, 2 bn(z) > 0
   double* partial;
 };
+// normalise-on-load (forward C -> C and the weight gradient): `in` / `S` is the raw z of the preceding conv, its BatchNorm
+// (+ ReLU) is applied while planes are staged
+struct B3Affine { const float* mean; const float* rstd; const float* beta; int relu; };
+bool b3conv_aff_ok(const GatherGeom& g);
 bool b3conv_bs_ok(const GatherGeom& g);
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                   double* stats_partial, int stats_off, int stats_total, hipStream_t s, const bf16_t* pw = nullptr,
-                  int pw_cs = 0, const float* pw_w = nullptr, const B3BnRed* bs = nullptr);
+                  int pw_cs = 0, const float* pw_w = nullptr, const B3BnRed* bs = nullptr, const B3Affine* aff = nullptr);
 // 1x1 stride-1 conv between 8 / 16 channel tensors, operands straight from global memory (bf16_pointwise.hip)
 bool bpw_ok(const GatherGeom& g);
 int bpw_grid_blocks(const GatherGeom& g);
@@ -91,7 +95,7 @@ int launch_bdeconv(const GatherGeom* g, int cnt, const bf16_t* in, const float* 
 bool b3wgrad_ok(const GatherGeom& g);   // z-marching weight gradient of the same layers (bf16_wgrad3.hip)
 size_t b3wgrad_scratch_bytes(const GatherGeom& g);
 int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,
-                   size_t scratch_bytes, hipStream_t s);
+                   size_t scratch_bytes, hipStream_t s, const B3Affine* aff = nullptr);
 // dW[t][m][n] += sum_q S[q*si+d_t][m] * C[q][n]   (fp32 accumulation, fp32 dW [t][Kw][Nw])
 size_t bwgrad_scratch_bytes(const GatherGeom& g);
 int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,

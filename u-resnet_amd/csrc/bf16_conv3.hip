@@ -54,10 +54,16 @@ struct B3Args {
   const float* bs_mean; const float* bs_rstd; const float* bs_beta; const float* bs_mean2; const float* bs_rstd2;
   double* bs_partial;
   int bs_z_cs, bs_y_cs, bs_z2_cs, bs_mode;
+  // AFF instantiations (forward, CI = CO): the input is the RAW output z of the preceding conv; its BatchNorm (+ ReLU) is
+  // applied while the plane is staged (lib/resnet_module.py:43-51: resnet_conv1's BatchNorm feeds resnet_conv2 only), so that
+  // activation is never written.  Padding stays zero.
+  const float* aff_mean; const float* aff_rstd; const float* aff_beta;
+  int aff_relu;
 };
 
-template <int CI, int CO, bool STATS, bool PW = false, int BS = 0>
-__global__ __launch_bounds__(256, BS == 1 ? 3 : 2) void b3conv_kernel(B3Args a) {
+template <int CI, int CO, bool STATS, bool PW = false, int BS = 0, bool AFF = false>
+__global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ? 3 : 2) void b3conv_kernel(B3Args a) {
+  static_assert(!AFF || (!PW && BS == 0), "normalise-on-load: plain forward instantiations");
   using G = B3<CI, CO>;
   static_assert(!PW || (CI == 8 && CO == 16 && !STATS), "fused shortcut term: the 8 -> 16 data gradient");
   static_assert(BS == 0 || (CO == 8 && !STATS && !PW), "fused BatchNorm-backward reductions: data gradients producing 8 channels");
@@ -101,6 +107,17 @@ __global__ __launch_bounds__(256, BS == 1 ? 3 : 2) void b3conv_kernel(B3Args a) 
     }
   }
   u32x4 st[G::NST], stpw = {0u, 0u, 0u, 0u};
+  unsigned stin = 0;   // AFF: which staged pieces are real voxels
+  float asc[8], ash[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    asc[j] = 1.f; ash[j] = 0.f;
+    if constexpr (AFF) {   // a thread always stages the same channel half (256 is even)
+      const int ch = (CI == 16 ? (tid & 1) * 8 : 0) + j;
+      asc[j] = a.aff_rstd[ch];
+      ash[j] = a.aff_beta[ch] - a.aff_mean[ch] * asc[j];
+    }
+  }
   // shortcut plane (PW): interior voxels only, one piece per thread (32 x 8 tile), kept at the x plane's coordinates
   const int pwy = tid >> 5, pwx = tid & 31;
   const bool pwok = PW && y0 + pwy < a.Y && x0 + pwx < a.X;
@@ -114,6 +131,7 @@ __global__ __launch_bounds__(256, BS == 1 ? 3 : 2) void b3conv_kernel(B3Args a) 
       if (pz && ((sval >> i) & 1u)) v = *(const u32x4*)(base + srel[i]);
       st[i] = v;
     }
+    if constexpr (AFF) stin = pz ? sval : 0u;
     if constexpr (PW) {
       stpw = (u32x4){0u, 0u, 0u, 0u};
       if (pz && pwok) stpw = *(const u32x4*)(a.pw + ((size_t)n * a.Z + p) * a.Y * a.X * a.pw_cs + pwrel);
@@ -123,6 +141,18 @@ __global__ __launch_bounds__(256, BS == 1 ? 3 : 2) void b3conv_kernel(B3Args a) 
 #pragma unroll
     for (int i = 0; i < G::NST; ++i) {
       const int idx = tid + 256 * i;
+      if constexpr (AFF) {   // applied at the store: the loads stay in flight during the MFMA block
+        if ((stin >> i) & 1u) {
+          float f[8];
+          unpack8(st[i], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            f[j] = fmaf(f[j], asc[j], ash[j]);
+            if (a.aff_relu) f[j] = fmaxf(f[j], 0.f);
+          }
+          st[i] = pack8(f);
+        }
+      }
       if (idx < G::PIECES) *(u32x4*)(lds + slot * SLOT + idx * 16) = st[i];
     }
     if constexpr (PW) *(u32x4*)(lds + slot * SLOT + G::PLANE + ((pwy + 1) * PX + pwx + 1) * 16) = stpw;
@@ -372,6 +402,7 @@ bool b3conv_ok(const GatherGeom& g) {
   return true;
 }
 
+bool b3conv_aff_ok(const GatherGeom& g) { return b3conv_ok(g) && g.K == g.Nn; }
 bool b3conv_pw_ok(const GatherGeom& g) {
   static const bool off = getenv("URSN_B3CONV_PW") && getenv("URSN_B3CONV_PW")[0] == '0';
   return !off && b3conv_ok(g) && g.K == 8 && g.Nn == 16;
@@ -389,7 +420,7 @@ bool b3conv_bs_ok(const GatherGeom& g) {
 
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                   double* stats_partial, int stats_off, int stats_total, hipStream_t s, const bf16_t* pw, int pw_cs,
-                  const float* pw_w, const B3BnRed* bs) {
+                  const float* pw_w, const B3BnRed* bs, const B3Affine* aff) {
   URSN_REQUIRE(b3conv_ok(g), "bf16 3x3x3 conv: unsupported geometry");
   URSN_REQUIRE(!pw || (b3conv_pw_ok(g) && pw_w && !stats_partial && (pw_cs & 7) == 0), "bf16 3x3x3 conv: the fused shortcut term needs the 8 -> 16 data gradient");
   B3PackArgs k;
@@ -408,6 +439,23 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
   a.stats_off = stats_off; a.stats_total = stats_total > 0 ? stats_total : p.grid;
   a.pw = pw; a.pw_cs = pw_cs;
   a.bs_partial = nullptr;
+  a.aff_mean = a.aff_rstd = a.aff_beta = nullptr; a.aff_relu = 0;
+  if (aff) {
+    URSN_REQUIRE(b3conv_aff_ok(g) && !pw && !bs && aff->mean && aff->rstd && aff->beta, "bf16 3x3x3 conv: normalise-on-load needs a C -> C forward shape");
+    a.aff_mean = aff->mean; a.aff_rstd = aff->rstd; a.aff_beta = aff->beta; a.aff_relu = aff->relu;
+#define B3AFF(c_, label)                                                                                                  \
+    if (g.K == c_) {                                                                                                      \
+      hipLaunchKernelGGL((b3conv_pack_kernel<c_, c_>), dim3((B3<c_, c_>::WPACK + 255) / 256), dim3(256), 0, s, k);        \
+      ursn_note_kernel(label);                                                                                            \
+      if (stats_partial) hipLaunchKernelGGL((b3conv_kernel<c_, c_, true, false, 0, true>), dim3(p.grid), dim3(256), 0, s, a);  \
+      else hipLaunchKernelGGL((b3conv_kernel<c_, c_, false, false, 0, true>), dim3(p.grid), dim3(256), 0, s, a);          \
+    }
+    B3AFF(8, "b3conv_bf16<8,8>+bn")
+    B3AFF(16, "b3conv_bf16<16,16>+bn")
+#undef B3AFF
+    URSN_HIP(hipGetLastError());
+    return 0;
+  }
   if (bs) {
     URSN_REQUIRE(b3conv_bs_ok(g) && !pw && !stats_partial && bs->z && bs->mean && bs->rstd && bs->partial && (bs->mode != 1 || bs->y) &&
                  (bs->mode != 2 || bs->beta) && (!bs->z2 || (bs->mean2 && bs->rstd2)), "bf16 3x3x3 conv: bad fused BatchNorm-backward arguments");

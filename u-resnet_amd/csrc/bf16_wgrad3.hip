@@ -35,6 +35,8 @@ struct W3Args {
   float* slab;        // [grid][NT][16][16] fp32
   int N, Z, Y, X, in_cs, out_cs;
   int zseg, nzseg, nty, ntx;
+  const float* aff_mean; const float* aff_rstd; const float* aff_beta;   // AFF: S is a raw conv output, normalised while staged
+  int aff_relu;
 };
 
 __device__ __forceinline__ bfx8 w3_tr_pair(const unsigned char* p0, const unsigned char* p1) {
@@ -47,7 +49,7 @@ __device__ __forceinline__ bfx8 w3_tr_pair(const unsigned char* p0, const unsign
   return __builtin_bit_cast(bfx8, v);
 }
 
-template <int K, int NN>
+template <int K, int NN, bool AFF = false>
 __global__ __launch_bounds__(256, 2) void b3wgrad_kernel(W3Args a) {
   using G = W3<K, NN>;
   constexpr int CPV = G::CPV, DPV = G::DPV, PX = G::PX, TY = G::TY, MTW = G::MTW, TPD = G::TPD;
@@ -93,6 +95,17 @@ __global__ __launch_bounds__(256, 2) void b3wgrad_kernel(W3Args a) {
     }
   }
   u32x4 xs[G::NXS], ds[G::NDS];
+  unsigned xin = 0;
+  float asc[8], ash[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    asc[j] = 1.f; ash[j] = 0.f;
+    if constexpr (AFF) {
+      const int ch = (K == 16 ? (tid & 1) * 8 : 0) + j;
+      asc[j] = a.aff_rstd[ch];
+      ash[j] = a.aff_beta[ch] - a.aff_mean[ch] * asc[j];
+    }
+  }
   auto load_x = [&](int p) {
     const bool pz = p >= 0 && p < a.Z;
     const bf16_t* base = a.S + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
@@ -102,12 +115,25 @@ __global__ __launch_bounds__(256, 2) void b3wgrad_kernel(W3Args a) {
       if (pz && ((xval >> i) & 1u)) v = *(const u32x4*)(base + xrel[i]);
       xs[i] = v;
     }
+    if constexpr (AFF) xin = pz ? xval : 0u;
   };
   auto store_x = [&](int p) {   // plane p lives in ring slot (p + 1) & 3
     unsigned char* dst = xring + ((p + 1) & 3) * G::XPLANE;
 #pragma unroll
     for (int i = 0; i < G::NXS; ++i) {
       const int idx = tid + 256 * i;
+      if constexpr (AFF) {
+        if ((xin >> i) & 1u) {
+          float f[8];
+          unpack8(xs[i], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            f[j] = fmaf(f[j], asc[j], ash[j]);
+            if (a.aff_relu) f[j] = fmaxf(f[j], 0.f);
+          }
+          xs[i] = pack8(f);
+        }
+      }
       if (idx < G::XPIECES) *(u32x4*)(dst + idx * 16) = xs[i];
     }
   };
@@ -260,10 +286,10 @@ size_t b3wgrad_scratch_bytes(const GatherGeom& g) {
   return (size_t)w3_plan(g).grid * nt * 256 * sizeof(float) + 256;
 }
 
-template <int K, int NN>
+template <int K, int NN, bool AFF>
 static int w3_launch(const W3Plan& p, const W3Args& a, const W3ReduceArgs& r, hipStream_t s) {
   using G = W3<K, NN>;
-  auto kern = b3wgrad_kernel<K, NN>;
+  auto kern = b3wgrad_kernel<K, NN, AFF>;
   static bool attr = false;
   if (!attr) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
@@ -277,7 +303,7 @@ static int w3_launch(const W3Plan& p, const W3Args& a, const W3ReduceArgs& r, hi
 }
 
 int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,
-                   size_t scratch_bytes, hipStream_t s) {
+                   size_t scratch_bytes, hipStream_t s, const B3Affine* aff) {
   URSN_REQUIRE(b3wgrad_ok(g), "bf16 3x3x3 wgrad: unsupported geometry");
   URSN_REQUIRE(scratch && scratch_bytes >= b3wgrad_scratch_bytes(g), "bf16 3x3x3 wgrad: scratch too small");
   const W3Plan p = w3_plan(g);
@@ -285,12 +311,22 @@ int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float*
   a.S = S; a.C = C; a.slab = (float*)scratch;
   a.N = g.N; a.Z = g.in_d[0]; a.Y = g.in_d[1]; a.X = g.in_d[2]; a.in_cs = g.in_cs; a.out_cs = g.out_cs;
   a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
+  a.aff_mean = a.aff_rstd = a.aff_beta = nullptr; a.aff_relu = 0;
+  if (aff) {
+    URSN_REQUIRE(aff->mean && aff->rstd && aff->beta, "bf16 3x3x3 wgrad: incomplete normalise-on-load arguments");
+    a.aff_mean = aff->mean; a.aff_rstd = aff->rstd; a.aff_beta = aff->beta; a.aff_relu = aff->relu;
+  }
   W3ReduceArgs r;
   r.slab = a.slab; r.dw = dw; r.nslabs = p.grid; r.Kw = Kw > 0 ? Kw : g.K; r.Nw = Nw > 0 ? Nw : g.Nn;
   for (int i = 0; i < 27; ++i) r.tapw[i] = -1;
   for (int t = 0; t < g.ntaps; ++t) r.tapw[(g.tap_d[t][0] + 1) * 9 + (g.tap_d[t][1] + 1) * 3 + (g.tap_d[t][2] + 1)] = g.tap_w[t];
   ursn_note_kernel("b3wgrad_bf16");
-  if (g.K == 8) return w3_launch<8, 8>(p, a, r, s);
-  if (g.Nn == 8) return w3_launch<16, 8>(p, a, r, s);
-  return w3_launch<16, 16>(p, a, r, s);
+  if (aff) {
+    if (g.K == 8) return w3_launch<8, 8, true>(p, a, r, s);
+    if (g.Nn == 8) return w3_launch<16, 8, true>(p, a, r, s);
+    return w3_launch<16, 16, true>(p, a, r, s);
+  }
+  if (g.K == 8) return w3_launch<8, 8, false>(p, a, r, s);
+  if (g.Nn == 8) return w3_launch<16, 8, false>(p, a, r, s);
+  return w3_launch<16, 16, false>(p, a, r, s);
 }

@@ -35,6 +35,9 @@ struct BAct {              // activation view + its gradient view (same layout)
   bf16_t* p = nullptr;
   bf16_t* g = nullptr;
   int C = 0, cs = 0, lvl = 0, flag = -1;
+  // virtual activation (never written): value = [relu] bn(z of layer aff_layer), applied by the consuming kernels while they
+  // stage it (B3Affine); p stays null
+  int aff_layer = -1, aff_relu = 0;
 };
 
 struct BLayer {
@@ -194,13 +197,24 @@ int plan(ursn_bnet* n, Arena& A) {
   n->conv0 = add_layer(n, A, "conv0", 0, 3, 1, c.cin, F, 0, 0, poff);
   n->skip0_own = F == 8 && !(getenv("URSN_BF16_SKIP0_OWN") && getenv("URSN_BF16_SKIP0_OWN")[0] == '0');
   n->a_conv0 = n->skip0_own ? make_act(n, A, 0, F, tr) : fmap_view(0);
+  // can the consumer layer L (k3 s1, C -> C) apply its producer's BatchNorm while staging (forward and weight gradient)?
+  auto virtual_ok = [&](const BLayer& L) {
+    static const bool off = getenv("URSN_BF16_NORM_ON_LOAD") && getenv("URSN_BF16_NORM_ON_LOAD")[0] == '0';
+    if (off) return false;
+    GatherGeom g[8];
+    if (layer_geoms(n, L, PASS_FWD, c.max_batch, L.kin, L.kout, g) != 1 || !b3conv_aff_ok(g[0])) return false;
+    if (tr && (layer_geoms(n, L, PASS_WGRAD, c.max_batch, L.kin, L.kout, g) != 1 || !b3wgrad_ok(g[0]))) return false;
+    return true;
+  };
   auto add_unit = [&](const std::string& scope, const BAct& in, int co, int s, int lout, const BAct* out_view) {
     BUnit u;
     u.in = in;
     if (!(in.C == co && s == 1)) u.sc = add_layer(n, A, scope + "/shortcut", 0, 1, s, in.C, co, in.lvl, lout, poff);
     u.c1 = add_layer(n, A, scope + "/resnet_conv1", 0, 3, s, in.C, co, in.lvl, lout, poff);
-    u.a1 = make_act(n, A, lout, co, tr);
     u.c2 = add_layer(n, A, scope + "/resnet_conv2", 0, 3, 1, co, co, lout, lout, poff);
+    const bool virt = virtual_ok(n->layers[u.c2]);   // resnet_conv1's BatchNorm output feeds resnet_conv2 only
+    u.a1 = make_act(n, A, lout, co, tr, !virt);
+    if (virt) { u.a1.aff_layer = u.c1; u.a1.aff_relu = 0; }
     u.out = out_view ? *out_view : make_act(n, A, lout, co, tr);
     n->units.push_back(u);
     return u.out;
@@ -229,8 +243,12 @@ int plan(ursn_bnet* n, Arena& A) {
   }
   n->a_pre1 = net;
   n->conv1 = add_layer(n, A, "conv1", 0, 3, 1, net.C, F, 0, 0, poff);
-  n->a_conv1 = make_act(n, A, 0, F, tr);
   n->conv2 = add_layer(n, A, "conv2", 0, 3, 1, F, c.num_class, 0, 0, poff);
+  {
+    const bool virt = virtual_ok(n->layers[n->conv2]);   // conv1's activation feeds conv2 only (lib/uresnet.py:84-100)
+    n->a_conv1 = make_act(n, A, 0, F, tr, !virt);
+    if (virt) { n->a_conv1.aff_layer = n->conv1; n->a_conv1.aff_relu = 1; }
+  }
 
   const int64_t V0 = (int64_t)c.max_batch * n->lvox[0];
   n->dlog = tr ? (bf16_t*)A.take((size_t)V0 * 8 * sizeof(bf16_t)) : nullptr;
@@ -285,6 +303,7 @@ int plan(ursn_bnet* n, Arena& A) {
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------------------
+const float* beta_of(ursn_bnet* n, const BLayer& L);
 int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
   BLayer& L = n->layers[li];
   GatherGeom g[8];
@@ -295,6 +314,16 @@ int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
   if (bdeconv_ok(g, cnt)) {   // transposed conv 16 -> 8: the eight parity classes in one launch
     total = bdeconv_grid_blocks(g, cnt);
     URSN_TRY(launch_bdeconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, n->wpack, L.z, n->stats, 0, s));
+    return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
+  }
+  if (in.aff_layer >= 0) {   // virtual input: BatchNorm of the producer applied while staging
+    const BLayer& P = n->layers[in.aff_layer];
+    const int cnt2 = layer_geoms(n, L, PASS_FWD, N, P.kout, L.kout, g);
+    URSN_REQUIRE(cnt2 == 1 && b3conv_aff_ok(g[0]), "bf16 forward: %s cannot normalise its input on load", L.name.c_str());
+    B3Affine af = {P.mean, P.rstd, beta_of(n, P), in.aff_relu};
+    total = bconv_grid_blocks(g[0]);
+    g[0].accumulate = 0;
+    URSN_TRY(launch_b3conv(g[0], P.z, n->params + L.w_off, Kw, Nw, n->wpack, L.z, n->stats, 0, total, s, nullptr, 0, nullptr, nullptr, &af));
     return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
   for (int i = 0; i < cnt; ++i) total += bconv_grid_blocks(g[i]);
@@ -326,7 +355,7 @@ int bn_out(ursn_bnet* n, int li, const BAct& out, int relu, int N, int li2, cons
 int unit_fwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s) {
   if (u.sc >= 0) URSN_TRY(conv_stats(n, u.sc, u.in, N, s));
   URSN_TRY(conv_stats(n, u.c1, u.in, N, s));
-  URSN_TRY(bn_out(n, u.c1, u.a1, 0, N, -1, nullptr, s));
+  if (u.a1.aff_layer < 0) URSN_TRY(bn_out(n, u.c1, u.a1, 0, N, -1, nullptr, s));
   URSN_TRY(conv_stats(n, u.c2, u.a1, N, s));
   if (u.sc >= 0) return bn_out(n, u.c2, u.out, 1, N, u.sc, nullptr, s);
   return bn_out(n, u.c2, u.out, 1, N, -1, &u.in, s);
@@ -365,7 +394,7 @@ int forward(ursn_bnet* n, const float* data, int N, hipStream_t s) {
     URSN_TRY(unit_fwd(n, n->units[ui++], N, s));
   }
   URSN_TRY(conv_stats(n, n->conv1, n->a_pre1, N, s));
-  URSN_TRY(bn_out(n, n->conv1, n->a_conv1, 1, N, -1, nullptr, s));
+  if (n->a_conv1.aff_layer < 0) URSN_TRY(bn_out(n, n->conv1, n->a_conv1, 1, N, -1, nullptr, s));
   return conv_stats(n, n->conv2, n->a_conv1, N, s);
 }
 
@@ -415,9 +444,16 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
       URSN_HIP(hipStreamWaitEvent(n->s2, e, 0));
       ws = n->s2;
     }
-    const bf16_t* S = L.kind ? L.dz : in.p;
-    const bf16_t* Cq = L.kind ? in.p : L.dz;
-    URSN_TRY(launch_bwgrad(g[0], S, Cq, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, ws));
+    if (in.aff_layer >= 0) {
+      const BLayer& P = n->layers[in.aff_layer];
+      URSN_REQUIRE(!L.kind && layer_geoms(n, L, PASS_WGRAD, N, P.kout, L.kout, g) == 1 && b3wgrad_ok(g[0]), "bf16 backward: %s cannot normalise its input on load", L.name.c_str());
+      B3Affine af = {P.mean, P.rstd, beta_of(n, P), in.aff_relu};
+      URSN_TRY(launch_b3wgrad(g[0], P.z, L.dz, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, ws, &af));
+    } else {
+      const bf16_t* S = L.kind ? L.dz : in.p;
+      const bf16_t* Cq = L.kind ? in.p : L.dz;
+      URSN_TRY(launch_bwgrad(g[0], S, Cq, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, ws));
+    }
   }
   if (!need_dgrad) return 0;
   const bool acc = take_flag(n, in);
