@@ -367,7 +367,7 @@ def main():
         # conv-like layers (BatchNorm / join / head assumed fused = 0 bytes, as the model prices them) over the step time.
         fl, by, t_roof = step_roofline(dims, base, ncls, batch, 2, PEAK_BF16_TFLOPS * 1e12, PEAK_HBM_GBS * 1e9)
         ach = by / (ms_per_step * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "whole step (bconv_bf16 / bwgrad_bf16 / bf16 BatchNorm kernels)",
+        roofline = {"bound": "hbm", "kernel": "whole step (b3conv / b3wgrad / bdeconv / bpw / bconv / bwgrad / bf16 BatchNorm kernels)",
                     "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
                     "traffic": None, "traffic_source": None,
                     "algorithmic_bytes_per_step": round(by), "step_algorithmic_TFLOPs": round(fl / 1e12, 3),

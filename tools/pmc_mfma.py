@@ -8,7 +8,7 @@ n = collections.Counter()
 for f in glob.glob("gpurun_out/pmc_mfma/*counter_collection.csv") + glob.glob("gpurun_out/pmc_mfma/*/*counter_collection.csv"):
     seen = set()
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if (r["Dispatch_Id"], k) not in seen:
             seen.add((r["Dispatch_Id"], k)); n[k] += 1
