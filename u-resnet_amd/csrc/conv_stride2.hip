@@ -478,7 +478,8 @@ static bool make_s2plan(const ursn_conv_desc& d, S2Plan& p) {
   g.IZ = hi[0]; g.IY = hi[1]; g.IX = hi[2];
   g.OZ = lo[0]; g.OY = lo[1]; g.OX = lo[2];
   g.pz = pb[0]; g.py = pb[1]; g.px = pb[2];
-  if (g.OX < 8 && d.algo != 6) return false;   // 16-wide lo-res x tiles: below that the gather kernel wastes less
+  static const int minx = getenv("URSN_S2_MINX") ? atoi(getenv("URSN_S2_MINX")) : 8;
+  if (g.OX < minx && d.algo != 6) return false;   // 16-wide lo-res x tiles: below that the gather kernel wastes less
   const int BZ = p.mode == 3 ? 2 : 1, BY = p.mode == 3 ? 4 : 16, BX = 16;
   g.nbz = (g.OZ + BZ - 1) / BZ;
   g.nby = (g.OY + BY - 1) / BY;
