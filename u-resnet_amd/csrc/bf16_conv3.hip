@@ -61,9 +61,12 @@ struct B3Args {
   int aff_relu;
 };
 
-template <int CI, int CO, bool STATS, bool PW = false, int BS = 0, bool AFF = false>
-__global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ? 3 : 2) void b3conv_kernel(B3Args a) {
+// PF2: two input planes in flight per workgroup (second register set).  A plane iteration is memory-latency-bound (its MFMA
+// block is ~0.5 us of ~5.8 us at 256^3), so the bytes in flight per CU, not the bandwidth, set the rate with one plane ahead.
+template <int CI, int CO, bool STATS, bool PW = false, int BS = 0, bool AFF = false, bool PF2 = false>
+__global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS == 0))) ? 3 : 2) void b3conv_kernel(B3Args a) {
   static_assert(!AFF || (!PW && BS == 0), "normalise-on-load: plain forward instantiations");
+  static_assert(!PF2 || (!AFF && !PW), "two planes in flight: plain instantiations");
   using G = B3<CI, CO>;
   static_assert(!PW || (CI == 8 && CO == 16 && !STATS), "fused shortcut term: the 8 -> 16 data gradient");
   static_assert(BS == 0 || (CO == 8 && !STATS && !PW), "fused BatchNorm-backward reductions: data gradients producing 8 channels");
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
       }
     }
   }
-  u32x4 st[G::NST], stpw = {0u, 0u, 0u, 0u};
+  u32x4 st[G::NST], st2[PF2 ? G::NST : 1], stpw = {0u, 0u, 0u, 0u};
   unsigned stin = 0;   // AFF: which staged pieces are real voxels
   float asc[8], ash[8];
 #pragma unroll
@@ -122,14 +125,14 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
   const int pwy = tid >> 5, pwx = tid & 31;
   const bool pwok = PW && y0 + pwy < a.Y && x0 + pwx < a.X;
   const int pwrel = PW ? ((y0 + pwy) * a.X + x0 + pwx) * a.pw_cs : 0;
-  auto stage_load = [&](int p) {
+  auto stage_load = [&](int p, u32x4 (&arr)[G::NST]) {
     const bool pz = p >= 0 && p < a.Z;
     const bf16_t* base = a.in + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
 #pragma unroll
     for (int i = 0; i < G::NST; ++i) {
       u32x4 v = {0u, 0u, 0u, 0u};
       if (pz && ((sval >> i) & 1u)) v = *(const u32x4*)(base + srel[i]);
-      st[i] = v;
+      arr[i] = v;
     }
     if constexpr (AFF) stin = pz ? sval : 0u;
     if constexpr (PW) {
@@ -137,23 +140,23 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
       if (pz && pwok) stpw = *(const u32x4*)(a.pw + ((size_t)n * a.Z + p) * a.Y * a.X * a.pw_cs + pwrel);
     }
   };
-  auto stage_store = [&](int slot) {
+  auto stage_store = [&](int slot, u32x4 (&arr)[G::NST]) {
 #pragma unroll
     for (int i = 0; i < G::NST; ++i) {
       const int idx = tid + 256 * i;
       if constexpr (AFF) {   // applied at the store: the loads stay in flight during the MFMA block
         if ((stin >> i) & 1u) {
           float f[8];
-          unpack8(st[i], f);
+          unpack8(arr[i], f);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             f[j] = fmaf(f[j], asc[j], ash[j]);
             if (a.aff_relu) f[j] = fmaxf(f[j], 0.f);
           }
-          st[i] = pack8(f);
+          arr[i] = pack8(f);
         }
       }
-      if (idx < G::PIECES) *(u32x4*)(lds + slot * SLOT + idx * 16) = st[i];
+      if (idx < G::PIECES) *(u32x4*)(lds + slot * SLOT + idx * 16) = arr[i];
     }
     if constexpr (PW) *(u32x4*)(lds + slot * SLOT + G::PLANE + ((pwy + 1) * PX + pwx + 1) * 16) = stpw;
   };
@@ -190,12 +193,7 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
     }
   }
 
-  stage_load(z0 - 1);
-  stage_store(0);
-  __syncthreads();
-  int slot = 0;
-  for (int p = z0 - 1; p <= z1; ++p) {
-    if (p < z1) stage_load(p + 1);
+  auto plane_step = [&](int p, int slot) {
     const unsigned char* L = lds + slot * SLOT;
 #pragma unroll
     for (int nt = 0; nt < RPW; ++nt) {
@@ -293,9 +291,39 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
         }
       }
     }
-    if (p < z1) stage_store(slot ^ 1);
+  };
+
+  stage_load(z0 - 1, st);
+  stage_store(0, st);
+  if constexpr (!PF2) {
     __syncthreads();
-    slot ^= 1;
+    int slot = 0;
+    for (int p = z0 - 1; p <= z1; ++p) {
+      if (p < z1) stage_load(p + 1, st);
+      plane_step(p, slot);
+      if (p < z1) stage_store(slot ^ 1, st);
+      __syncthreads();
+      slot ^= 1;
+    }
+  } else {
+    // planes z0 and z0 + 1 are requested before the first MFMA; a register set is stored to LDS one iteration before its plane
+    // is needed and re-armed with the plane three ahead, so every load has two iterations to land
+    stage_load(z0, st);
+    stage_load(z0 + 1, st2);
+    __syncthreads();
+    int slot = 0, p = z0 - 1;
+    while (true) {
+      plane_step(p, slot);
+      if (p < z1) { stage_store(slot ^ 1, st); if (p + 3 <= z1) stage_load(p + 3, st); }
+      __syncthreads();
+      slot ^= 1;
+      if (++p > z1) break;
+      plane_step(p, slot);
+      if (p < z1) { stage_store(slot ^ 1, st2); if (p + 3 <= z1) stage_load(p + 3, st2); }
+      __syncthreads();
+      slot ^= 1;
+      if (++p > z1) break;
+    }
   }
 
   if constexpr (BS != 0) {   // [block][3][8] doubles: the layout bn_bwd_final_kernel reads
@@ -476,11 +504,17 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
     URSN_HIP(hipGetLastError());
     return 0;
   }
+  // measured at cfg5: 75.5 images/s with two planes in flight (196-207 VGPRs, two workgroups per CU) against 77.6 with one
+  // (156-160 VGPRs, three per CU) on the same box: the extra registers cost more occupancy than the deeper prefetch returns
+  static const bool pf2 = getenv("URSN_B3CONV_PF2") && getenv("URSN_B3CONV_PF2")[0] == '1';
 #define B3GO(ci, co, label)                                                                                              \
   if (g.K == ci && g.Nn == co) {                                                                                          \
     hipLaunchKernelGGL((b3conv_pack_kernel<ci, co>), dim3((B3<ci, co>::WPACK + 255) / 256), dim3(256), 0, s, k);          \
     ursn_note_kernel(label);                                                                                              \
-    if (stats_partial) hipLaunchKernelGGL((b3conv_kernel<ci, co, true>), dim3(p.grid), dim3(256), 0, s, a);               \
+    if (pf2) {                                                                                                            \
+      if (stats_partial) hipLaunchKernelGGL((b3conv_kernel<ci, co, true, false, 0, false, true>), dim3(p.grid), dim3(256), 0, s, a);  \
+      else hipLaunchKernelGGL((b3conv_kernel<ci, co, false, false, 0, false, true>), dim3(p.grid), dim3(256), 0, s, a);   \
+    } else if (stats_partial) hipLaunchKernelGGL((b3conv_kernel<ci, co, true>), dim3(p.grid), dim3(256), 0, s, a);        \
     else hipLaunchKernelGGL((b3conv_kernel<ci, co, false>), dim3(p.grid), dim3(256), 0, s, a);                            \
   }
   B3GO(8, 8, "b3conv_bf16<8,8>")
