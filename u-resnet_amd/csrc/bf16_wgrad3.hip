@@ -247,11 +247,191 @@ __global__ __launch_bounds__(1024) void b3wgrad_reduce_kernel(W3ReduceArgs a) {
   a.dw[((size_t)tw * a.Kw + ci) * a.Nw + col] += (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
 }
 
+// ---- 8 -> 8: plane-PAIR form ---------------------------------------------------------------------------------------------
+// With 8 produced channels the 16 MFMA columns are half empty.  As the fp32 twgradz kernel does, columns 0..7 take dz of plane
+// q and columns 8..15 dz of plane q + 1 while the A operand (a tap pair of x plane q - 1 + s, s = 0..3) is shared: rows of x
+// plane slot s are tap plane s for the first half and tap plane s - 1 for the second.  4 x 5 = 20 tiles serve two planes instead
+// of 2 x 15, i.e. 2/3 of the LDS reads and MFMAs per voxel (the kernel above is bound by its transposing LDS reads).
+// 32 x 8 tiles, ring of six x planes (four in use, two arriving) and four dz planes: 49 KB, three workgroups per CU.
+struct WZ {
+  static constexpr int TY = 8, PX = 34, PY = TY + 2;
+  static constexpr int XPIECES = PX * PY, XPLANE = XPIECES * 16;        // 340 pieces
+  static constexpr int DPIECES = 32 * TY, DPLANE = DPIECES * 16;         // 256 pieces
+  static constexpr int NXS = (XPIECES + 255) / 256;                      // 2
+  static constexpr int TPD = 5, NT = 4 * TPD, MTW = NT / 4;              // 20 tiles, 5 per wave
+  static constexpr int LDS = 6 * XPLANE + 4 * DPLANE;
+};
+
+template <bool AFF>
+__global__ __launch_bounds__(256, 3) void b3wgradz_kernel(W3Args a) {
+  using G = WZ;
+  constexpr int PX = G::PX, TY = G::TY, MTW = G::MTW, TPD = G::TPD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xring = smem;
+  unsigned char* dbuf = smem + 6 * G::XPLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Gk = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int tx = bid % a.ntx;
+  int r_ = bid / a.ntx;
+  const int ty = r_ % a.nty;
+  r_ /= a.nty;
+  const int zs = r_ % a.nzseg, n = r_ / a.nzseg;
+  const int x0 = tx * 32, y0 = ty * TY, z0 = zs * a.zseg;
+  const int z1 = z0 + a.zseg < a.Z ? z0 + a.zseg : a.Z;
+
+  int xrel[G::NXS], drel;
+  unsigned xval = 0;
+  bool dval = false;
+#pragma unroll
+  for (int i = 0; i < G::NXS; ++i) {
+    const int idx = tid + 256 * i;
+    xrel[i] = 0;
+    if (idx < G::XPIECES) {
+      const int yy = idx / PX, xx = idx - yy * PX;
+      const int gy = y0 + yy - 1, gx = x0 + xx - 1;
+      if (gy >= 0 && gy < a.Y && gx >= 0 && gx < a.X) { xval |= 1u << i; xrel[i] = (gy * a.X + gx) * a.in_cs; }
+    }
+  }
+  {
+    const int gy = y0 + (tid >> 5), gx = x0 + (tid & 31);
+    dval = gy < a.Y && gx < a.X;
+    drel = dval ? (gy * a.X + gx) * a.out_cs : 0;
+  }
+  float asc[8], ash[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    asc[j] = 1.f; ash[j] = 0.f;
+    if constexpr (AFF) { asc[j] = a.aff_rstd[j]; ash[j] = a.aff_beta[j] - a.aff_mean[j] * asc[j]; }
+  }
+  u32x4 xs[2][G::NXS], ds[2];
+  unsigned xin[2] = {0u, 0u};
+  auto load_x = [&](int p, int k) {
+    const bool pz = p >= 0 && p < a.Z;
+    const bf16_t* base = a.S + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
+#pragma unroll
+    for (int i = 0; i < G::NXS; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (pz && ((xval >> i) & 1u)) v = *(const u32x4*)(base + xrel[i]);
+      xs[k][i] = v;
+    }
+    xin[k] = pz ? xval : 0u;
+  };
+  auto store_x = [&](int p, int k) {   // plane p lives in ring slot (p + 1) % 6
+    unsigned char* dst = xring + ((p + 7) % 6) * G::XPLANE;
+#pragma unroll
+    for (int i = 0; i < G::NXS; ++i) {
+      const int idx = tid + 256 * i;
+      if constexpr (AFF) {
+        if ((xin[k] >> i) & 1u) {
+          float f[8];
+          unpack8(xs[k][i], f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            f[j] = fmaf(f[j], asc[j], ash[j]);
+            if (a.aff_relu) f[j] = fmaxf(f[j], 0.f);
+          }
+          xs[k][i] = pack8(f);
+        }
+      }
+      if (idx < G::XPIECES) *(u32x4*)(dst + idx * 16) = xs[k][i];
+    }
+  };
+  auto load_d = [&](int q, int k) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (q < z1 && dval) v = *(const u32x4*)(a.C + ((size_t)n * a.Z + q) * a.Y * a.X * a.out_cs + drel);
+    ds[k] = v;
+  };
+  auto store_d = [&](int q, int k) { *(u32x4*)(dbuf + (q & 3) * G::DPLANE + tid * 16) = ds[k]; };
+
+  // this wave's tiles u = wave + 4 m: x plane slot sm = u / 5, tap pair i = u % 5 of that plane
+  int sm[MTW];
+  unsigned aoff[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const int u = wave + 4 * m;
+    sm[m] = u / TPD;
+    const int i = u - sm[m] * TPD;
+    int j = 2 * i + (tp >> 1);
+    if (j > 8) j = 8;
+    aoff[m] = (unsigned)(((j / 3) * PX + (j % 3) + 8 * Gk + tq) * 16 + (tp & 1) * 8);
+  }
+  const unsigned boff = (unsigned)((8 * Gk + tq) * 16 + (tp & 1) * 8);
+  const int bhalf = tp >> 1;   // column chunks 0, 1: plane q; 2, 3: plane q + 1
+
+  bf_f32x4 acc[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) acc[m] = (bf_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // prologue: x planes z0-1 .. z0+2, dz planes z0, z0+1
+  for (int p = z0 - 1; p <= z0 + 2; p += 2) { load_x(p, 0); load_x(p + 1, 1); store_x(p, 0); store_x(p + 1, 1); }
+  load_d(z0, 0); load_d(z0 + 1, 1); store_d(z0, 0); store_d(z0 + 1, 1);
+  __syncthreads();
+  for (int q = z0; q < z1; q += 2) {
+    load_x(q + 3, 0); load_x(q + 4, 1);
+    load_d(q + 2, 0); load_d(q + 3, 1);
+    const unsigned char* db = dbuf + ((q + bhalf) & 3) * G::DPLANE + boff;
+    unsigned sb[MTW];
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) sb[m] = (unsigned)(((q + sm[m] + 6) % 6) * G::XPLANE) + aoff[m];   // plane q - 1 + s -> slot (q + s) % 6
+#pragma unroll 2
+    for (int r = 0; r < TY; ++r) {
+      const unsigned char* bp = db + r * (32 * 16);
+      const bfx8 B = w3_tr_pair(bp, bp + 4 * 16);
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        const unsigned char* ap = xring + sb[m] + r * (PX * 16);
+        const bfx8 A = w3_tr_pair(ap, ap + 4 * 16);
+        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, acc[m], 0, 0, 0);
+      }
+    }
+    store_x(q + 3, 0); store_x(q + 4, 1);
+    store_d(q + 2, 0); store_d(q + 3, 1);
+    __syncthreads();
+  }
+  float* sl = a.slab + (size_t)blockIdx.x * (G::NT * 256);
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const int u = wave + 4 * m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sl[(size_t)u * 256 + (4 * Gk + r) * 16 + li] = acc[m][r];
+  }
+}
+
+// dw element (tap plane dzt, in-plane tap j, ci, co) = slab tile (s = dzt, i)[row][co] + tile (s = dzt + 1, i)[row][8 + co]
+__global__ __launch_bounds__(1024) void b3wgradz_reduce_kernel(W3ReduceArgs a) {
+  __shared__ float part[4][128];
+  const int blk = blockIdx.x;               // (dzt, i): 3 x 5
+  const int dzt = blk / WZ::TPD, i = blk - dzt * WZ::TPD;
+  const int el = threadIdx.x, sl = threadIdx.y;   // el: (row 0..15, co 0..7)
+  const int row = el >> 3, co = el & 7;
+  const size_t per = (size_t)WZ::NT * 256;
+  const float* p0 = a.slab + (size_t)(dzt * WZ::TPD + i) * 256 + row * 16 + co;
+  const float* p1 = a.slab + (size_t)((dzt + 1) * WZ::TPD + i) * 256 + row * 16 + 8 + co;
+  const int qn = (a.nslabs + 3) / 4, k0 = sl * qn, k1 = k0 + qn < a.nslabs ? k0 + qn : a.nslabs;
+  float s0 = 0.f, s1 = 0.f;
+  for (int k = k0; k < k1; ++k) { s0 += p0[(size_t)k * per]; s1 += p1[(size_t)k * per]; }
+  part[sl][el] = s0 + s1;
+  __syncthreads();
+  if (sl != 0) return;
+  const int j = 2 * i + (row >> 3), ci = row & 7;
+  if (j > 8 || ci >= a.Kw || co >= a.Nw) return;
+  const int tw = a.tapw[dzt * 9 + j];
+  if (tw < 0) return;
+  a.dw[((size_t)tw * a.Kw + ci) * a.Nw + co] += (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+}
+
 struct W3Plan { int zseg, nzseg, nty, ntx, grid; };
+static bool w3_pair(const GatherGeom& g) {
+  static const bool off = getenv("URSN_B3WGRAD_PAIR") && getenv("URSN_B3WGRAD_PAIR")[0] == '0';
+  return !off && g.K == 8 && g.Nn == 8;
+}
 W3Plan w3_plan(const GatherGeom& g) {
   W3Plan p;
   const int Z = g.in_d[0], Y = g.in_d[1], X = g.in_d[2];
-  const int TY = g.K == 8 ? 16 : 8;
+  const int TY = (g.K == 8 && !w3_pair(g)) ? 16 : 8;
   p.ntx = (X + 31) / 32;
   p.nty = (Y + TY - 1) / TY;
   const int64_t tiles = (int64_t)g.N * p.nty * p.ntx;
@@ -282,7 +462,7 @@ bool b3wgrad_ok(const GatherGeom& g) {
 }
 
 size_t b3wgrad_scratch_bytes(const GatherGeom& g) {
-  const int nt = g.K == 8 ? 15 : 27;
+  const int nt = g.K == 8 ? (w3_pair(g) ? WZ::NT : 15) : 27;
   return (size_t)w3_plan(g).grid * nt * 256 * sizeof(float) + 256;
 }
 
@@ -321,6 +501,20 @@ int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float*
   for (int i = 0; i < 27; ++i) r.tapw[i] = -1;
   for (int t = 0; t < g.ntaps; ++t) r.tapw[(g.tap_d[t][0] + 1) * 9 + (g.tap_d[t][1] + 1) * 3 + (g.tap_d[t][2] + 1)] = g.tap_w[t];
   ursn_note_kernel("b3wgrad_bf16");
+  if (w3_pair(g)) {
+    static bool attr = false;
+    if (!attr) {
+      URSN_HIP(hipFuncSetAttribute((const void*)b3wgradz_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WZ::LDS));
+      URSN_HIP(hipFuncSetAttribute((const void*)b3wgradz_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WZ::LDS));
+      attr = true;
+    }
+    if (aff) hipLaunchKernelGGL(b3wgradz_kernel<true>, dim3(p.grid), dim3(256), WZ::LDS, s, a);
+    else hipLaunchKernelGGL(b3wgradz_kernel<false>, dim3(p.grid), dim3(256), WZ::LDS, s, a);
+    URSN_HIP(hipGetLastError());
+    hipLaunchKernelGGL(b3wgradz_reduce_kernel, dim3(3 * WZ::TPD), dim3(128, 4), 0, s, r);
+    URSN_HIP(hipGetLastError());
+    return 0;
+  }
   if (aff) {
     if (g.K == 8) return w3_launch<8, 8, true>(p, a, r, s);
     if (g.Nn == 8) return w3_launch<16, 8, true>(p, a, r, s);
