@@ -108,6 +108,7 @@ struct BBnActArgs {   // y = act(bn(z) [+ bn(z2) | + res]); all tensors bf16, ch
   const bf16_t* res; int rescs;
   bf16_t* y; int ycs;
   int64_t V; int C; int relu;
+  unsigned char* mask_out;   // optional (relu): one byte per 16-byte piece of y, bit j = (channel j of the piece > 0)
   int cat;   // C = 8 only: y[v][0:8] = act(bn(z)), y[v][8:16] = act(bn2(z2)) -- both halves of a concat voxel in one 32-byte store
 };
 int launch_bbn_act(const BBnActArgs& a, hipStream_t s);
@@ -121,6 +122,7 @@ struct BBnBwdArgs {   // as BnBwdArgs (ursn_common.h) on bf16 tensors; the relu 
   void* scratch;
   int Cw;
   const double* pre_partial; int pre_nblocks;   // the reductions came out of the producing kernel's epilogue: [pre_nblocks][3][C]
+  const unsigned char* mask;                    // relu mask bytes written by launch_bbn_act (mask_out); replaces the y reads
   const bf16_t* dy2; int dy2cs;                 // second contribution to the output gradient (C = 8, mask = bn(z) > 0 only): g = dy + dy2
 };
 int launch_bbn_bwd(const BBnBwdArgs& a, hipStream_t s);

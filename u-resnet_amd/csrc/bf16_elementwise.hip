@@ -137,6 +137,12 @@ __global__ __launch_bounds__(256) void bbn_act_kernel(BBnActArgs a, int shift) {
           y[j] = t;
         }
         *(u32x4*)(a.y + v * a.ycs + c) = pack8(y);
+        if (a.mask_out) {
+          unsigned bits = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bits |= (y[j] > 0.f ? 1u : 0u) << j;
+          a.mask_out[v * (a.C >> 3) + (c >> 3)] = (unsigned char)bits;
+        }
       }
     };
     if ((ch + 1) * chunkv <= a.V) body(std::true_type{});
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256) void bbn_act_kernel(BBnActArgs a, int shift) {
 }
 
 // ---- BN backward ----------------------------------------------------------------------------------------------------
-// MASK: 0 no activation, 1 mask = y > 0 (y given), 2 mask = bn(z) > 0 (beta given).
+// MASK: 0 no activation, 1 mask = y > 0 (y given), 2 mask = bn(z) > 0 (beta given), 3 mask bytes of the forward pass.
 // Per-thread sums in fp32: a thread adds <= ~1e3 terms of bf16-rounded data (relative error ~1e-6 of its own partial sum);
 // everything across threads and blocks is fp64.
 template <bool C8, int MASK, bool HAS2, bool D2 = false>
@@ -167,6 +173,7 @@ __global__ __launch_bounds__(256) void bbn_bwd_reduce_kernel(BBnBwdArgs a, int s
       auto body = [&](auto FULL) {
         constexpr bool full = decltype(FULL)::value;
         u32x4 gp[U], zp[U], yp[U], z2p[U], g2p[U];
+        unsigned mk[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int64_t v = vb + (int64_t)u * VPB;
@@ -174,6 +181,7 @@ __global__ __launch_bounds__(256) void bbn_bwd_reduce_kernel(BBnBwdArgs a, int s
             gp[u] = ld16(a.dy + v * a.dycs + c);
             zp[u] = ld16(a.z + v * a.zcs + c);
             if constexpr (MASK == 1) yp[u] = ld16(a.y + v * a.ycs + c);
+            if constexpr (MASK == 3) mk[u] = a.mask[v * (a.C >> 3) + (c >> 3)];
             if constexpr (HAS2) z2p[u] = ld16(a.z2 + v * a.z2cs + c);
             if constexpr (D2) g2p[u] = ld16(a.dy2 + v * a.dy2cs + c);
           }
@@ -196,6 +204,7 @@ __global__ __launch_bounds__(256) void bbn_bwd_reduce_kernel(BBnBwdArgs a, int s
             float gj = g[j];
             if constexpr (MASK == 1) { if (!(y[j] > 0.f)) gj = 0.f; }
             if constexpr (MASK == 2) { if (!(fmaf(z[j], rs[j], be[j]) > 0.f)) gj = 0.f; }
+            if constexpr (MASK == 3) { if (!((mk[u] >> j) & 1u)) gj = 0.f; }
             acc[0][j] += gj;
             acc[1][j] = fmaf(gj, (z[j] - mu[j]) * rs[j], acc[1][j]);
             if constexpr (HAS2) acc[2][j] = fmaf(gj, (z2[j] - mu2[j]) * rs2[j], acc[2][j]);
@@ -228,11 +237,13 @@ __global__ __launch_bounds__(256) void bbn_bwd_apply_kernel(BBnBwdArgs a, int sh
     auto body = [&](auto FULL) {
       constexpr bool full = decltype(FULL)::value;
       u32x4 gp[U], zp[U], yp[U], z2p[U], drp[U], g2p[U];
+      unsigned mk[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t v = vb + (int64_t)u * VPB;
         if (full || v < a.V) {
           gp[u] = ld16(a.dy + v * a.dycs + c);
+          if constexpr (MASK == 3) mk[u] = a.mask[v * (a.C >> 3) + (c >> 3)];
           if constexpr (D2) g2p[u] = ld16(a.dy2 + v * a.dy2cs + c);
           zp[u] = ld16(a.z + v * a.zcs + c);
           if constexpr (MASK == 1) yp[u] = ld16(a.y + v * a.ycs + c);
@@ -260,6 +271,7 @@ __global__ __launch_bounds__(256) void bbn_bwd_apply_kernel(BBnBwdArgs a, int sh
           float gj = g[j];
           if constexpr (MASK == 1) { if (!(y[j] > 0.f)) gj = 0.f; }
           if constexpr (MASK == 2) { if (!(fmaf(z[j], rs[j], be[j]) > 0.f)) gj = 0.f; }
+          if constexpr (MASK == 3) { if (!((mk[u] >> j) & 1u)) gj = 0.f; }
           dz[j] = rs[j] * (gj - mg[j] - (z[j] - mu[j]) * rs[j] * mgx[j]);
           if constexpr (HAS2) dz2[j] = rs2[j] * (gj - mg[j] - (z2[j] - mu2[j]) * rs2[j] * mgx2[j]);
           if constexpr (DRES) dr[j] = dacc ? dr[j] + gj : gj;
@@ -397,19 +409,19 @@ int launch_bbn_act(const BBnActArgs& a, hipStream_t s) {
 }
 
 int launch_bbn_bwd(const BBnBwdArgs& a, hipStream_t s) {
-  URSN_REQUIRE(!a.relu || a.y || a.beta, "bf16 bn_bwd: relu mask needs y or beta");
-  URSN_REQUIRE(piece_ok(a.C, {a.dycs, (a.relu && a.y) ? a.ycs : 0, a.zcs, a.dzcs, a.z2 ? a.z2cs : 0, a.z2 ? a.dz2cs : 0, a.dres ? a.drescs : 0},
-                        {a.dy, a.relu ? a.y : nullptr, a.z, a.dz, a.z2, a.dz2, a.dres}),
+  URSN_REQUIRE(!a.relu || a.y || a.beta || a.mask, "bf16 bn_bwd: relu mask needs y, beta or the mask bytes");
+  URSN_REQUIRE(piece_ok(a.C, {a.dycs, (a.relu && a.y && !a.mask) ? a.ycs : 0, a.zcs, a.dzcs, a.z2 ? a.z2cs : 0, a.z2 ? a.dz2cs : 0, a.dres ? a.drescs : 0},
+                        {a.dy, (a.relu && !a.mask) ? a.y : nullptr, a.z, a.dz, a.z2, a.dz2, a.dres}),
                "bf16 bn_bwd: channels / strides must be multiples of 8 and pointers 16-byte aligned (C = %d)", a.C);
   const BMap m = make_bmap(a.V, a.C);   // m.grid: rows of the partial-sum scratch (bbn_scratch_bytes)
   const int rgrid = bew_grid(a.V, m.shift, m.grid), agrid = bew_grid(a.V, m.shift, 1 << 20);
   double* partial = (double*)a.scratch;
   double* finals = partial + (size_t)m.grid * 3 * a.C;
-  const int mask = !a.relu ? 0 : (a.y ? 1 : 2);
+  const int mask = !a.relu ? 0 : (a.mask ? 3 : (a.y ? 1 : 2));
   if (!a.pre_partial && m.shift > 2) URSN_HIP(hipMemsetAsync(partial, 0, (size_t)rgrid * 3 * a.C * sizeof(double), s));   // atomics path of the block reduce
 #define BRED(c8, mk, h2) hipLaunchKernelGGL((bbn_bwd_reduce_kernel<c8, mk, h2>), dim3(rgrid), dim3(256), 0, s, a, m.shift, partial)
 #define BRED2(c8, mk) do { if (a.z2) BRED(c8, mk, true); else BRED(c8, mk, false); } while (0)
-#define BRED3(c8) do { if (mask == 0) BRED2(c8, 0); else if (mask == 1) BRED2(c8, 1); else BRED2(c8, 2); } while (0)
+#define BRED3(c8) do { if (mask == 0) BRED2(c8, 0); else if (mask == 1) BRED2(c8, 1); else if (mask == 3) BRED2(c8, 3); else BRED2(c8, 2); } while (0)
   const bool d2 = a.dy2 != nullptr;
   if (d2) URSN_REQUIRE(a.C == 8 && mask == 2 && !a.z2 && !a.dres && !a.pre_partial && (a.dy2cs & 7) == 0, "bf16 bn_bwd: a second gradient operand is supported for 8-channel conv-BN-ReLU layers only");
   if (a.pre_partial) { /* sums taken by the kernel that produced dy */ }
@@ -422,7 +434,7 @@ int launch_bbn_bwd(const BBnBwdArgs& a, hipStream_t s) {
 #define BAPP(c8, mk, h2, dr) hipLaunchKernelGGL((bbn_bwd_apply_kernel<c8, mk, h2, dr>), dim3(agrid), dim3(256), 0, s, a, m.shift, (const double*)finals)
 #define BAPP1(c8, mk, h2) do { if (a.dres) BAPP(c8, mk, h2, true); else BAPP(c8, mk, h2, false); } while (0)
 #define BAPP2(c8, mk) do { if (a.z2) BAPP1(c8, mk, true); else BAPP1(c8, mk, false); } while (0)
-#define BAPP3(c8) do { if (mask == 0) BAPP2(c8, 0); else if (mask == 1) BAPP2(c8, 1); else BAPP2(c8, 2); } while (0)
+#define BAPP3(c8) do { if (mask == 0) BAPP2(c8, 0); else if (mask == 1) BAPP2(c8, 1); else if (mask == 3) BAPP2(c8, 3); else BAPP2(c8, 2); } while (0)
   if (d2) hipLaunchKernelGGL((bbn_bwd_apply_kernel<true, 2, false, false, true>), dim3(agrid), dim3(256), 0, s, a, m.shift, (const double*)finals);
   else if (a.C == 8) BAPP3(true); else BAPP3(false);
 #undef BAPP3

@@ -53,6 +53,7 @@ struct BLayer {
 struct BUnit {
   int sc = -1, c1 = -1, c2 = -1;
   BAct in, a1, out;
+  unsigned char* jmask = nullptr;   // relu mask of the join (one byte per 16-byte piece): both BatchNorm-backward passes read it instead of out
 };
 
 }  // namespace
@@ -216,6 +217,8 @@ int plan(ursn_bnet* n, Arena& A) {
     u.a1 = make_act(n, A, lout, co, tr, !virt);
     if (virt) { u.a1.aff_layer = u.c1; u.a1.aff_relu = 0; }
     u.out = out_view ? *out_view : make_act(n, A, lout, co, tr);
+    if (tr && !(getenv("URSN_BF16_RELU_MASK") && getenv("URSN_BF16_RELU_MASK")[0] == '0'))
+      u.jmask = (unsigned char*)A.take((size_t)c.max_batch * n->lvox[lout] * (pad8(co) / 8) + 256);
     n->units.push_back(u);
     return u.out;
   };
@@ -338,7 +341,8 @@ int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
 
 const float* beta_of(ursn_bnet* n, const BLayer& L) { return L.cout == L.kout ? n->params + L.b_off : n->beta_pad; }
 
-int bn_out(ursn_bnet* n, int li, const BAct& out, int relu, int N, int li2, const BAct* res, hipStream_t s) {
+int bn_out(ursn_bnet* n, int li, const BAct& out, int relu, int N, int li2, const BAct* res, hipStream_t s,
+           unsigned char* mask_out = nullptr) {
   BLayer& L = n->layers[li];
   BBnActArgs a;
   memset(&a, 0, sizeof(a));
@@ -349,6 +353,7 @@ int bn_out(ursn_bnet* n, int li, const BAct& out, int relu, int N, int li2, cons
   }
   if (res) { a.res = res->p; a.rescs = res->cs; }
   a.y = out.p; a.ycs = out.cs; a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.kout; a.relu = relu;
+  a.mask_out = relu ? mask_out : nullptr;
   return launch_bbn_act(a, s);
 }
 
@@ -357,8 +362,8 @@ int unit_fwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s) {
   URSN_TRY(conv_stats(n, u.c1, u.in, N, s));
   if (u.a1.aff_layer < 0) URSN_TRY(bn_out(n, u.c1, u.a1, 0, N, -1, nullptr, s));
   URSN_TRY(conv_stats(n, u.c2, u.a1, N, s));
-  if (u.sc >= 0) return bn_out(n, u.c2, u.out, 1, N, u.sc, nullptr, s);
-  return bn_out(n, u.c2, u.out, 1, N, -1, &u.in, s);
+  if (u.sc >= 0) return bn_out(n, u.c2, u.out, 1, N, u.sc, nullptr, s, u.jmask);
+  return bn_out(n, u.c2, u.out, 1, N, -1, &u.in, s, u.jmask);
 }
 
 int forward(ursn_bnet* n, const float* data, int N, hipStream_t s) {
@@ -499,11 +504,12 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
 }
 
 int bn_back(ursn_bnet* n, int li, const bf16_t* dy, int dycs, const bf16_t* y, int ycs, int relu, int li2, bf16_t* dres,
-            int drescs, int dres_acc, int N, hipStream_t s, const bf16_t* dy2 = nullptr, int dy2cs = 0) {
+            int drescs, int dres_acc, int N, hipStream_t s, const bf16_t* dy2 = nullptr, int dy2cs = 0,
+            const unsigned char* mask = nullptr) {
   BLayer& L = n->layers[li];
   BBnBwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.dy = dy; a.dycs = dycs; a.y = y; a.ycs = ycs; a.dy2 = dy2; a.dy2cs = dy2cs;
+  a.dy = dy; a.dycs = dycs; a.y = y; a.ycs = ycs; a.dy2 = dy2; a.dy2cs = dy2cs; a.mask = mask;
   a.z = L.z; a.zcs = L.kout; a.mean = L.mean; a.rstd = L.rstd; a.dz = L.dz; a.dzcs = L.kout;
   a.dbeta = n->grads + L.b_off; a.beta = beta_of(n, L);
   if (li2 >= 0) {
@@ -520,10 +526,10 @@ int bn_back(ursn_bnet* n, int li, const bf16_t* dy, int dycs, const bf16_t* y, i
 
 int unit_bwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s, const BBsTarget* in_target = nullptr) {
   if (u.sc >= 0) {
-    URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, u.sc, nullptr, 0, 0, N, s));
+    URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, u.sc, nullptr, 0, 0, N, s, nullptr, 0, u.jmask));
   } else {
     const bool acc = take_flag(n, u.in);
-    URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, -1, u.in.g, u.in.cs, acc ? 1 : 0, N, s));
+    URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, -1, u.in.g, u.in.cs, acc ? 1 : 0, N, s, nullptr, 0, u.jmask));
   }
   BBsTarget t1;   // conv2's data gradient IS d(a1): resnet_conv1's BatchNorm (no activation) consumes it
   t1.li = u.c1;
