@@ -876,3 +876,24 @@ def test_data_gradient_with_fused_bn_backward_reductions(S, co, split, relu, two
     dy2 = torch.zeros((N,) + S[1:] + (8,), dtype=torch.float32, device="cuda")
     w2 = torch.zeros((3, 3, 8, 8), dtype=torch.float32, device="cuda")
     assert lib.ursn_conv_backward_data(ctypes.byref(d2), P(dy2), P(w2), P(dxx), 0, stream()) != 0
+
+
+@pytest.mark.parametrize("S", [(10, 7, 70), (8, 12, 128)])
+def test_logits_layer_weight_gradient_on_the_vector_pipe(S):
+    """conv2 (lib/uresnet.py:94-100, 8 -> 3 channels): its weight gradient runs on v_pk_fma_f32 with a lane per voxel
+    (wgrad_valu.hip) when rows are >= 48 voxels wide; dz lives in the net's 4-padded logits buffers."""
+    N, ci, co = 2, 8, 3
+    rng = np.random.default_rng(S[2])
+    x = _rand(rng, (N,) + S + (ci,))
+    dy = _rand(rng, (N,) + S + (co,))
+    w = np.zeros((3, 3, 3, ci, co))
+    _, dw = O.conv_bwd(x, w, 1, dy)
+    dyp = np.zeros((N,) + S + (4,))
+    dyp[..., :co] = dy
+    dyp[..., 3] = 7.0   # the padding channel must not leak into the gradient
+    d = desc(3, N, S, ci, co, 3, 1, out_cs=4)
+    xg, dyg = dev(x), dev(dyp)
+    dwg = conv_backward_weight(d, xg, dyg, w.shape)
+    assert rel_err(dwg.cpu().numpy(), dw) < 5e-5
+    dwa = conv_backward_weight(d, xg, dyg, w.shape, dw_init=dwg)   # assign_add semantics
+    assert rel_err(dwa.cpu().numpy(), 2 * dw) < 5e-5

@@ -403,6 +403,10 @@ extern "C" int ursn_conv_backward_data(const ursn_conv_desc* d, const float* dy,
 
 int tiled_wgrad_supported(const ursn_conv_desc& d);
 size_t tiled_wgrad_scratch_bytes(const ursn_conv_desc& d);
+int valu_wgrad_supported(const ursn_conv_desc& d);
+size_t valu_wgrad_scratch_bytes(const ursn_conv_desc& d);
+int launch_valu_wgrad(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch, size_t scratch_bytes,
+                      hipStream_t s);
 int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
                        size_t scratch_bytes, hipStream_t s);
 
@@ -418,6 +422,8 @@ extern "C" size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d) {
   size_t c = igemm_wgrad_scratch_bytes(*d);
   size_t e = pointwise_wgrad_scratch_bytes(*d);
   size_t f = stride2_wgrad_scratch_bytes(*d);
+  size_t v = valu_wgrad_scratch_bytes(*d);
+  if (v > a) a = v;
   if (f > a) a = f;
   if (b > a) a = b;
   if (c > a) a = c;
@@ -442,6 +448,8 @@ int wgrad_dispatch(const ursn_conv_desc& d, const float* x, const float* dy, flo
   if ((d.algo == 0 || d.algo == 4) && igemm_wgrad_supported(d))
     return launch_igemm_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
   URSN_REQUIRE(d.algo != 4, "igemm wgrad kernel does not support this shape");
+  if (d.algo == 0 && valu_wgrad_supported(d))   // the 8 -> 3 logits layer: vector pipe, no padding of 3 channels to MFMA columns
+    return launch_valu_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
   if ((d.algo == 0 || d.algo == 3) && tiled_wgrad_supported(d))
     return launch_tiled_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
   URSN_REQUIRE(d.algo != 3, "tiled wgrad kernel does not support this shape");
