@@ -69,8 +69,9 @@ bool b3conv_pw_ok(const GatherGeom& g);
 struct B3BnRed {
   const bf16_t* z; int z_cs; const float* mean; const float* rstd; const float* beta;   // beta: mode 2
   const bf16_t* y; int y_cs;                                                           // mode 1: mask = y > 0
+  const unsigned char* maskb;                                                          // mode 3: relu mask bytes (bit j = channel j)
   const bf16_t* z2; int z2_cs; const float* mean2; const float* rstd2;                 // second BatchNorm of a join (optional)
-  int mode;                                                                            // 0 no mask, 1 y > 0, 2 bn(z) > 0
+  int mode;                                                                            // 0 no mask, 1 y > 0, 2 bn(z) > 0, 3 mask bytes
   double* partial;
 };
 // normalise-on-load (forward C -> C and the weight gradient): `in` / `S` is the raw z of the preceding conv, its BatchNorm
@@ -80,7 +81,8 @@ bool b3conv_aff_ok(const GatherGeom& g);
 bool b3conv_bs_ok(const GatherGeom& g);
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                   double* stats_partial, int stats_off, int stats_total, hipStream_t s, const bf16_t* pw = nullptr,
-                  int pw_cs = 0, const float* pw_w = nullptr, const B3BnRed* bs = nullptr, const B3Affine* aff = nullptr);
+                  int pw_cs = 0, const float* pw_w = nullptr, const B3BnRed* bs = nullptr, const B3Affine* aff = nullptr,
+                  bf16_t* out2 = nullptr, int out2_cs = 0);   // out2: produced channels 8..15 of a 16-channel result
 // 1x1 stride-1 conv between 8 / 16 channel tensors, operands straight from global memory (bf16_pointwise.hip)
 bool bpw_ok(const GatherGeom& g);
 int bpw_grid_blocks(const GatherGeom& g);

@@ -525,7 +525,7 @@ int launch_bconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, 
   }
   ursn_note_kernel("bconv_bf16");
   int rc = 3;
-#define BC(vt_, cot_) if (p.vt == vt_ && p.cot == cot_) rc = bconv_launch<vt_, cot_>(p, a, s);
+#define BC(vt_, cot_) if (p.vt == vt_ && p.cot == cot_) { ursn_note_kernel("bconv_bf16<" #vt_ "," #cot_ ">"); rc = bconv_launch<vt_, cot_>(p, a, s); }
   BC(8, 1) BC(8, 2) BC(4, 1) BC(4, 2) BC(2, 1) BC(2, 2) BC(1, 1) BC(1, 2)
 #undef BC
   return rc;
@@ -863,7 +863,7 @@ int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* 
   }
   ursn_note_kernel("bwgrad_bf16");
   int rc = 3;
-#define BW(m_, c_) if (p.mtw == m_ && p.cot == c_) rc = bwgrad_launch<m_, c_>(p, a, s);
+#define BW(m_, c_) if (p.mtw == m_ && p.cot == c_) { ursn_note_kernel("bwgrad_bf16<" #m_ "," #c_ ">"); rc = bwgrad_launch<m_, c_>(p, a, s); }
   BW(1, 1) BW(1, 2) BW(2, 1) BW(2, 2) BW(4, 1) BW(4, 2) BW(7, 1) BW(7, 2) BW(14, 1) BW(14, 2)
 #undef BW
   if (rc) return rc;

@@ -50,7 +50,7 @@ struct B3Args {
   // BS instantiations (data gradients producing 8 channels): the BatchNorm-backward reductions of the layer(s) whose output
   // gradient this launch completes, g = stored dx * mask: partial[block][0][c] = sum g, [1][c] = sum g * xhat(z),
   // [2][c] = sum g * xhat(z2) (BS = 2).  bs_mode: 0 no mask, 1 mask = y > 0 (bs_y), 2 mask = bn(z) > 0 (bs_beta)
-  const bf16_t* bs_z; const bf16_t* bs_y; const bf16_t* bs_z2;
+  const bf16_t* bs_z; const bf16_t* bs_y; const bf16_t* bs_z2; const unsigned char* bs_maskb;   // bs_mode 3: relu mask bytes
   const float* bs_mean; const float* bs_rstd; const float* bs_beta; const float* bs_mean2; const float* bs_rstd2;
   double* bs_partial;
   int bs_z_cs, bs_y_cs, bs_z2_cs, bs_mode;
@@ -59,6 +59,9 @@ struct B3Args {
   // activation is never written.  Padding stays zero.
   const float* aff_mean; const float* aff_rstd; const float* aff_beta;
   int aff_relu;
+  // CO = 16 only: produced channels 8..15 go to a second tensor (the two halves of a concat gradient have different consumers)
+  bf16_t* out2;
+  int out2_cs;
 };
 
 // PF2: two input planes in flight per workgroup (second register set).  A plane iteration is memory-latency-bound (its MFMA
@@ -195,6 +198,25 @@ __global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS
 
   auto plane_step = [&](int p, int slot) {
     const unsigned char* L = lds + slot * SLOT;
+    // BS: everything the epilogue of output plane p - 1 reads is requested here, a whole MFMA block ahead (loaded inside the
+    // epilogue the latency sat between the MFMAs and the plane barrier: measured slower than the separate reduce pass)
+    u32x2 pz[BS ? RPW : 1], pz2[BS == 2 ? RPW : 1];
+    unsigned pm[BS ? RPW : 1];
+    if constexpr (BS != 0) {
+      const int q = p - 1;
+      if (q >= z0 && q < z1) {
+#pragma unroll
+        for (int nt = 0; nt < RPW; ++nt) {
+          const int gy = y0 + RPW * wave + nt, gx = x0 + c;
+          if (gy < a.Y && gx < a.X) {
+            const size_t vox = (((size_t)n * a.Z + q) * a.Y + gy) * a.X + gx;
+            pz[nt] = *(const u32x2*)(a.bs_z + vox * a.bs_z_cs + 4 * h);
+            if constexpr (BS == 2) pz2[nt] = *(const u32x2*)(a.bs_z2 + vox * a.bs_z2_cs + 4 * h);
+            if (a.bs_mode == 3) pm[nt] = a.bs_maskb[vox];
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int nt = 0; nt < RPW; ++nt) {
       b3_f32x16 cc[MT];
@@ -238,6 +260,9 @@ __global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = CO == 8 ? acc[nt][0][8 + i] : acc[nt][1][4 * cb + i];
             u32x2* o = (u32x2*)(ob + 8 * cb);
+            if constexpr (CO == 16) {
+              if (cb == 1 && a.out2) o = (u32x2*)(a.out2 + ((((size_t)n * a.Z + q) * a.Y + gy) * a.X + gx) * a.out2_cs + h * 4);
+            }
             if (a.accumulate) {
               const u32x2 e = *o;
               v[0] += __uint_as_float(e[0] << 16); v[1] += __uint_as_float(e[0] & 0xffff0000u);
@@ -257,21 +282,17 @@ __global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS
               }
             }
             if constexpr (BS != 0) {   // g = the STORED gradient (what the BatchNorm backward will read) under the activation mask
-              const size_t vox = (((size_t)n * a.Z + q) * a.Y + gy) * a.X + gx;
               float gq[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
                              __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
-              const u32x2 zc = *(const u32x2*)(a.bs_z + vox * a.bs_z_cs + 4 * h);
+              const u32x2 zc = pz[nt];
               const float zf[4] = {__uint_as_float(zc[0] << 16), __uint_as_float(zc[0] & 0xffff0000u),
                                    __uint_as_float(zc[1] << 16), __uint_as_float(zc[1] & 0xffff0000u)};
-              if (a.bs_mode == 1) {
-                const u32x2 yc = *(const u32x2*)(a.bs_y + vox * a.bs_y_cs + 4 * h);
-                const float yf[4] = {__uint_as_float(yc[0] << 16), __uint_as_float(yc[0] & 0xffff0000u),
-                                     __uint_as_float(yc[1] << 16), __uint_as_float(yc[1] & 0xffff0000u)};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (!(yf[k] > 0.f)) gq[k] = 0.f;
-              } else if (a.bs_mode == 2) {
+              if (a.bs_mode == 2) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) if (!(fmaf(zf[k], brs[k], bsh[k]) > 0.f)) gq[k] = 0.f;   // same expression as bbn_bwd
+              } else if (a.bs_mode == 3) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (!((pm[nt] >> (4 * h + k)) & 1u)) gq[k] = 0.f;
               }
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
@@ -279,7 +300,7 @@ __global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS
                 bgx[k] = fmaf(gq[k], (zf[k] - bmu[k]) * brs[k], bgx[k]);
               }
               if constexpr (BS == 2) {
-                const u32x2 z2c = *(const u32x2*)(a.bs_z2 + vox * a.bs_z2_cs + 4 * h);
+                const u32x2 z2c = pz2[nt];
                 const float z2f[4] = {__uint_as_float(z2c[0] << 16), __uint_as_float(z2c[0] & 0xffff0000u),
                                       __uint_as_float(z2c[1] << 16), __uint_as_float(z2c[1] & 0xffff0000u)};
 #pragma unroll
@@ -439,8 +460,9 @@ size_t b3conv_pack_elems() { return (size_t)B3<16, 16>::WPACK + 8; }
 int b3conv_grid_blocks(const GatherGeom& g) { return b3_plan(g).grid; }
 
 // Off unless URSN_BF16_FUSE_BN_BWD_REDUCE=1: measured at cfg5 (256^3 x 4) the five fused launches cost more than the five
-// bbn_bwd_reduce passes they replace (65.1 vs 67.0 img/s) -- the epilogue's z / y loads sit between the MFMA block and the plane
-// barrier of an HBM-bound kernel.  Kept (and parity-tested) as the starting point for a prefetched version.
+// bbn_bwd_reduce passes they replace -- 65.1 vs 67.0 img/s with the z / y loads inside the epilogue, 75.9 vs 80.0 with the
+// operands (z, z2, mask bytes) requested a whole MFMA block ahead: 168 VGPRs + 84 bytes of spills at three waves per SIMD, or
+// 226 VGPRs at two, cost this latency-bound kernel more than the 16 bytes per voxel of the separate pass.  Parity-tested.
 bool b3conv_bs_ok(const GatherGeom& g) {
   static const bool on = getenv("URSN_BF16_FUSE_BN_BWD_REDUCE") && getenv("URSN_BF16_FUSE_BN_BWD_REDUCE")[0] == '1';
   return on && b3conv_ok(g) && g.Nn == 8 && g.K == 8;
@@ -448,7 +470,7 @@ bool b3conv_bs_ok(const GatherGeom& g) {
 
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                   double* stats_partial, int stats_off, int stats_total, hipStream_t s, const bf16_t* pw, int pw_cs,
-                  const float* pw_w, const B3BnRed* bs, const B3Affine* aff) {
+                  const float* pw_w, const B3BnRed* bs, const B3Affine* aff, bf16_t* out2, int out2_cs) {
   URSN_REQUIRE(b3conv_ok(g), "bf16 3x3x3 conv: unsupported geometry");
   URSN_REQUIRE(!pw || (b3conv_pw_ok(g) && pw_w && !stats_partial && (pw_cs & 7) == 0), "bf16 3x3x3 conv: the fused shortcut term needs the 8 -> 16 data gradient");
   B3PackArgs k;
@@ -468,6 +490,8 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
   a.pw = pw; a.pw_cs = pw_cs;
   a.bs_partial = nullptr;
   a.aff_mean = a.aff_rstd = a.aff_beta = nullptr; a.aff_relu = 0;
+  URSN_REQUIRE(!out2 || (g.Nn == 16 && (out2_cs & 7) == 0 && !stats_partial), "bf16 3x3x3 conv: a second output tensor needs 16 produced channels");
+  a.out2 = out2; a.out2_cs = out2_cs;
   if (aff) {
     URSN_REQUIRE(b3conv_aff_ok(g) && !pw && !bs && aff->mean && aff->rstd && aff->beta, "bf16 3x3x3 conv: normalise-on-load needs a C -> C forward shape");
     a.aff_mean = aff->mean; a.aff_rstd = aff->rstd; a.aff_beta = aff->beta; a.aff_relu = aff->relu;
@@ -485,9 +509,9 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
     return 0;
   }
   if (bs) {
-    URSN_REQUIRE(b3conv_bs_ok(g) && !pw && !stats_partial && bs->z && bs->mean && bs->rstd && bs->partial && (bs->mode != 1 || bs->y) &&
+    URSN_REQUIRE(b3conv_bs_ok(g) && !pw && !stats_partial && bs->z && bs->mean && bs->rstd && bs->partial && bs->mode != 1 && (bs->mode != 3 || bs->maskb) &&
                  (bs->mode != 2 || bs->beta) && (!bs->z2 || (bs->mean2 && bs->rstd2)), "bf16 3x3x3 conv: bad fused BatchNorm-backward arguments");
-    a.bs_z = bs->z; a.bs_y = bs->y; a.bs_z2 = bs->z2; a.bs_mean = bs->mean; a.bs_rstd = bs->rstd; a.bs_beta = bs->beta;
+    a.bs_z = bs->z; a.bs_y = bs->y; a.bs_z2 = bs->z2; a.bs_maskb = bs->maskb; a.bs_mean = bs->mean; a.bs_rstd = bs->rstd; a.bs_beta = bs->beta;
     a.bs_mean2 = bs->mean2; a.bs_rstd2 = bs->rstd2; a.bs_partial = bs->partial;
     a.bs_z_cs = bs->z_cs; a.bs_y_cs = bs->y_cs; a.bs_z2_cs = bs->z2_cs; a.bs_mode = bs->mode;
     hipLaunchKernelGGL((b3conv_pack_kernel<8, 8>), dim3((B3<8, 8>::WPACK + 255) / 256), dim3(256), 0, s, k);

@@ -500,7 +500,7 @@ int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float*
   r.slab = a.slab; r.dw = dw; r.nslabs = p.grid; r.Kw = Kw > 0 ? Kw : g.K; r.Nw = Nw > 0 ? Nw : g.Nn;
   for (int i = 0; i < 27; ++i) r.tapw[i] = -1;
   for (int t = 0; t < g.ntaps; ++t) r.tapw[(g.tap_d[t][0] + 1) * 9 + (g.tap_d[t][1] + 1) * 3 + (g.tap_d[t][2] + 1)] = g.tap_w[t];
-  ursn_note_kernel("b3wgrad_bf16");
+  ursn_note_kernel(g.K == 8 ? (w3_pair(g) ? "b3wgrad_bf16<8,8>(pair)" : "b3wgrad_bf16<8,8>") : (g.Nn == 8 ? "b3wgrad_bf16<16,8>" : "b3wgrad_bf16<16,16>"));
   if (w3_pair(g)) {
     static bool attr = false;
     if (!attr) {

@@ -1082,7 +1082,7 @@ extern "C" int ursn_tensor(const ursn_net* net, const char* name, float** ptr, i
 // ---- profiling C-ABI --------------------------------------------------------------------------
 extern "C" int ursn_profile_enable(ursn_net* net, int32_t on) {
   URSN_REQUIRE(net, "null handle");
-  if (net->bf) return 0;   // per-launch event records exist for the fp32 plan only
+  if (net->bf) return bnet_profile_enable(net->bf, on);
   net->profile = on != 0;
   net->prof.clear();
   net->ev_used = 0;
@@ -1091,6 +1091,7 @@ extern "C" int ursn_profile_enable(ursn_net* net, int32_t on) {
 
 extern "C" int ursn_profile_read(ursn_net* net, ursn_prof_rec* out, int64_t max_recs, int64_t* n_out) {
   URSN_REQUIRE(net && n_out, "null argument");
+  if (net->bf) return bnet_profile_read(net->bf, out, max_recs, n_out);
   int64_t cnt = 0;
   for (size_t i = 0; i < net->prof.size() && cnt < max_recs; ++i) {
     const ursn_net::ProfRec& r = net->prof[i];
@@ -1112,7 +1113,7 @@ extern "C" int ursn_profile_read(ursn_net* net, ursn_prof_rec* out, int64_t max_
 
 extern "C" int ursn_set_wgrad_overlap(ursn_net* net, int32_t on) {
   URSN_REQUIRE(net, "null handle");
-  if (net->bf) return 0;
+  if (net->bf) return bnet_set_wgrad_overlap(net->bf, on);
   if (net->s2_owned) (void)hipStreamSynchronize(net->s2_owned);
   net->s2 = on ? net->s2_owned : nullptr;
   return 0;

@@ -14,3 +14,7 @@ int bnet_param(const ursn_bnet* n, int64_t index, ursn_param_info* out);
 int bnet_step(ursn_bnet* n, const float* data, const float* label, const float* weight, int N, int mode, float* softmax_out,
               float* labels_out, hipStream_t s);
 int bnet_tensor(const ursn_bnet* n, const char* name, void** ptr, int64_t* voxels, int32_t* channels, int32_t* cstride);
+// per-launch HIP-event records (as ursn_profile_enable / ursn_profile_read of the fp32 plan) and the weight-gradient stream switch
+int bnet_profile_enable(ursn_bnet* n, int on);
+int bnet_profile_read(ursn_bnet* n, ursn_prof_rec* out, int64_t max_recs, int64_t* n_out);
+int bnet_set_wgrad_overlap(ursn_bnet* n, int on);

@@ -58,7 +58,13 @@ struct BUnit {
 
 }  // namespace
 
+struct BProfRec { int layer, pass; const char* kernel; double flops, bytes; hipEvent_t e0, e1; long l0; int launches; };
+
 struct ursn_bnet {
+  bool profile = false, s2_on = true;
+  std::vector<BProfRec> prof;
+  std::vector<hipEvent_t> pev;
+  size_t pev_used = 0;
   // BatchNorm-backward reductions taken in the epilogue of the data gradient that completed the layer's output gradient
   double* bs_scratch = nullptr;
   int bs_layer = -1, bs_blocks = 0;
@@ -77,6 +83,10 @@ struct ursn_bnet {
   // when the last transposed conv's BatchNorm runs (its half from z, the skip half recomputed from conv0's z): 16-byte
   // halves written one tensor pass apart were partial-sector writes (1.0 ms instead of 0.36 per pass at 256^3 x 4)
   bool skip0_own = false;
+  // ... and the gradient of that concat voxel is produced as two 8-channel tensors (the transposed conv's half and the skip's
+  // half have different consumers; read as 16-byte halves of a 32-byte voxel each cost a full pass of the other half)
+  bf16_t* dec0_g = nullptr; bf16_t* skip0_g = nullptr;
+  bool split0_done = false;   // this backward pass produced the two tensors (the fused 8 -> 16 data gradient ran)
   std::vector<int> ginit;
   float *params = nullptr, *grads = nullptr;
   bf16_t* dlog = nullptr;
@@ -198,6 +208,11 @@ int plan(ursn_bnet* n, Arena& A) {
   n->conv0 = add_layer(n, A, "conv0", 0, 3, 1, c.cin, F, 0, 0, poff);
   n->skip0_own = F == 8 && !(getenv("URSN_BF16_SKIP0_OWN") && getenv("URSN_BF16_SKIP0_OWN")[0] == '0');
   n->a_conv0 = n->skip0_own ? make_act(n, A, 0, F, tr) : fmap_view(0);
+  if (n->skip0_own && tr) {
+    const size_t bytes = (size_t)c.max_batch * n->lvox[0] * 8 * sizeof(bf16_t);
+    n->dec0_g = (bf16_t*)A.take(bytes);
+    n->skip0_g = (bf16_t*)A.take(bytes);
+  }
   // can the consumer layer L (k3 s1, C -> C) apply its producer's BatchNorm while staging (forward and weight gradient)?
   auto virtual_ok = [&](const BLayer& L) {
     static const bool off = getenv("URSN_BF16_NORM_ON_LOAD") && getenv("URSN_BF16_NORM_ON_LOAD")[0] == '0';
@@ -306,6 +321,48 @@ int plan(ursn_bnet* n, Arena& A) {
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------------------
+// ---- per-launch event records (bench.py --breakdown / --layers, roofline of the dominant kernel) ------------------------
+extern "C" const char* ursn_last_kernel_name();
+hipEvent_t bprof_event(ursn_bnet* n) {
+  if (n->pev_used == n->pev.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    n->pev.push_back(e);
+  }
+  return n->pev[n->pev_used++];
+}
+struct BProf {   // RAII: the conv paths return from several places
+  ursn_bnet* n; hipStream_t s; int idx = -1; const char* fixed;
+  BProf(ursn_bnet* n_, hipStream_t s_, int layer, int pass, double flops, double bytes, const char* name = nullptr)
+      : n(n_), s(s_), fixed(name) {
+    if (!n->profile || n->prof.size() > 200000) return;
+    BProfRec r{layer, pass, "", flops, bytes, bprof_event(n), bprof_event(n), ursn_kernel_launch_count(), 1};
+    if (!r.e0 || !r.e1) return;
+    hipEventRecord(r.e0, s);
+    n->prof.push_back(r);
+    idx = (int)n->prof.size() - 1;
+  }
+  ~BProf() {
+    if (idx < 0) return;
+    BProfRec& r = n->prof[idx];
+    r.kernel = fixed ? fixed : ursn_last_kernel_name();
+    const long nl = ursn_kernel_launch_count() - r.l0;
+    r.launches = nl > 0 ? (int)nl : 1;
+    hipEventRecord(r.e1, s);
+  }
+};
+// algorithmic work of a conv-like layer (SURVEY.md 8d conventions; bf16 tensors, fp32 weights)
+double blayer_flops(const ursn_bnet* n, const BLayer& L, int N) {
+  double taps = 1;
+  for (int j = 0; j < n->cfg.ndim; ++j) taps *= L.k;
+  return 2.0 * (double)N * (L.kind ? n->lvox[L.lin] : n->lvox[L.lout]) * taps * L.cin * L.cout;
+}
+double blayer_bytes(const ursn_bnet* n, const BLayer& L, int N) {
+  double taps = 1;
+  for (int j = 0; j < n->cfg.ndim; ++j) taps *= L.k;
+  return 2.0 * ((double)N * n->lvox[L.lin] * L.cin + (double)N * n->lvox[L.lout] * L.cout) + 4.0 * taps * L.cin * L.cout;
+}
+
 const float* beta_of(ursn_bnet* n, const BLayer& L);
 int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
   BLayer& L = n->layers[li];
@@ -313,6 +370,7 @@ int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
   const int cnt = layer_geoms(n, L, PASS_FWD, N, in.cs, L.kout, g);
   int Kw, Nw;
   real_extents(L, PASS_FWD, Kw, Nw);
+  BProf ps(n, s, li, 0, blayer_flops(n, L, N), blayer_bytes(n, L, N));
   int total = 0, off = 0;
   if (bdeconv_ok(g, cnt)) {   // transposed conv 16 -> 8: the eight parity classes in one launch
     total = bdeconv_grid_blocks(g, cnt);
@@ -354,6 +412,7 @@ int bn_out(ursn_bnet* n, int li, const BAct& out, int relu, int N, int li2, cons
   if (res) { a.res = res->p; a.rescs = res->cs; }
   a.y = out.p; a.ycs = out.cs; a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.kout; a.relu = relu;
   a.mask_out = relu ? mask_out : nullptr;
+  BProf ps(n, s, li, 4, 0.0, 2.0 * a.V * a.C * (2.0 + (li2 >= 0) + (res != nullptr)), "bbn_act");
   return launch_bbn_act(a, s);
 }
 
@@ -391,6 +450,7 @@ int forward(ursn_bnet* n, const float* data, int N, hipStream_t s) {
       a.z = L.z; a.zcs = L.kout; a.mean = L.mean; a.rstd = L.rstd; a.beta = beta_of(n, L);
       a.z2 = L0.z; a.z2cs = L0.kout; a.mean2 = L0.mean; a.rstd2 = L0.rstd; a.beta2 = beta_of(n, L0);
       a.y = n->cat[i].p; a.ycs = n->cat[i].cs; a.V = (int64_t)N * n->lvox[0]; a.C = 8; a.relu = 1; a.cat = 1;
+      BProf ps(n, s, n->deconv[i], 4, 0.0, 2.0 * a.V * 8 * 4.0, "bbn_act(concat)");
       URSN_TRY(launch_bbn_act(a, s));
     } else {
       URSN_TRY(bn_out(n, n->deconv[i], n->deconv_out[i], 1, N, -1, nullptr, s));
@@ -412,6 +472,7 @@ int head(ursn_bnet* n, const float* data, const float* label, const float* weigh
   a.data = data; a.data_cs = 1; a.label = label; a.weight = weight; a.n = N; a.pix = n->lvox[0]; a.ncls = n->cfg.num_class;
   a.softmax_out = softmax_out; a.dlogits = want_grad ? n->dlog : nullptr; a.dl_cs = 8; a.ana_out = ana_out;
   a.metrics = n->metrics; a.scratch = n->head_scratch;
+  BProf ps(n, s, n->conv2, 6, 0.0, (double)N * n->lvox[0] * (16.0 + 12.0 + (want_grad ? 16.0 : 0.0)), "bhead");
   return launch_bhead(a, s);
 }
 
@@ -424,8 +485,9 @@ bool take_flag(ursn_bnet* n, const BAct& a) {
 
 // The BatchNorm backward that consumes the gradient a data-gradient launch completes (as net.hip's BsTarget)
 struct BBsTarget {
-  int li = -1, li2 = -1, mode = 0;   // mode: 0 no activation, 1 mask = y > 0, 2 mask = bn(z) > 0
+  int li = -1, li2 = -1, mode = 0;   // mode: 0 no activation, 1 mask = y > 0, 2 mask = bn(z) > 0, 3 mask bytes
   const bf16_t* y = nullptr; int ycs = 0;
+  const unsigned char* maskb = nullptr;
 };
 
 // fused_sc >= 0: the data gradient also carries the term of that (1x1, stride-1) shortcut layer
@@ -438,7 +500,7 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
     URSN_REQUIRE(layer_geoms(n, L, PASS_WGRAD, N, in.cs, L.kout, g) == 1, "bf16 backward: bad weight-gradient geometry");
     real_extents(L, PASS_WGRAD, Kw, Nw);
     hipStream_t ws = s;
-    if (n->s2) {
+    if (n->s2 && n->s2_on) {
       if (n->ev_used == n->evs.size()) {
         hipEvent_t e;
         URSN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -449,6 +511,7 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
       URSN_HIP(hipStreamWaitEvent(n->s2, e, 0));
       ws = n->s2;
     }
+    BProf pw(n, ws, li, 2, blayer_flops(n, L, N), blayer_bytes(n, L, N));
     if (in.aff_layer >= 0) {
       const BLayer& P = n->layers[in.aff_layer];
       URSN_REQUIRE(!L.kind && layer_geoms(n, L, PASS_WGRAD, N, P.kout, L.kout, g) == 1 && b3wgrad_ok(g[0]), "bf16 backward: %s cannot normalise its input on load", L.name.c_str());
@@ -461,6 +524,7 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
     }
   }
   if (!need_dgrad) return 0;
+  BProf pd(n, s, li, 1, blayer_flops(n, L, N), blayer_bytes(n, L, N));
   const bool acc = take_flag(n, in);
   const int cnt = layer_geoms(n, L, PASS_DGRAD, N, in.cs, L.kout, g);
   real_extents(L, PASS_DGRAD, Kw, Nw);
@@ -468,14 +532,14 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
   for (int i = 0; i < cnt; ++i) empty = empty || g[i].ntaps == 0;
   URSN_REQUIRE(!empty || acc, "bf16 backward: %s would leave voxels of its input gradient unwritten", L.name.c_str());
   n->bs_layer = -1;
-  if (bs && bs->li >= 0 && fused_sc < 0 && cnt == 1 && b3conv_bs_ok(g[0]) && in.C == 8 && in.cs == 8) {
+  if (bs && bs->li >= 0 && bs->mode != 1 && fused_sc < 0 && cnt == 1 && b3conv_bs_ok(g[0]) && in.C == 8 && in.cs == 8) {
     const BLayer& T = n->layers[bs->li];
     const int blocks = bconv_grid_blocks(g[0]);
     if (T.kout == 8 && blocks <= 16384 && (bs->li2 < 0 || n->layers[bs->li2].kout == 8)) {
       B3BnRed r;
       memset(&r, 0, sizeof(r));
       r.z = T.z; r.z_cs = T.kout; r.mean = T.mean; r.rstd = T.rstd; r.beta = beta_of(n, T);
-      r.y = bs->y; r.y_cs = bs->ycs; r.mode = bs->mode;
+      r.y = bs->y; r.y_cs = bs->ycs; r.mode = bs->mode; r.maskb = bs->maskb;
       if (bs->li2 >= 0) {
         const BLayer& T2 = n->layers[bs->li2];
         r.z2 = T2.z; r.z2_cs = T2.kout; r.mean2 = T2.mean; r.rstd2 = T2.rstd;
@@ -491,6 +555,12 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
     const BLayer& S = n->layers[fused_sc];
     URSN_REQUIRE(cnt == 1 && b3conv_pw_ok(g[0]) && S.kin == 16 && S.cin == 16 && S.cout == 8 && S.kout == 8, "bf16 backward: no fused shortcut term for %s", L.name.c_str());
     g[0].accumulate = acc ? 1 : 0;
+    if (n->dec0_g && in.g == n->cat[n->cfg.num_strides - 1].g && !acc) {   // level-0 concat gradient: two 8-channel tensors
+      g[0].out_cs = 8;
+      n->split0_done = true;
+      return launch_b3conv(g[0], L.dz, n->params + L.w_off, Kw, Nw, n->wpack, n->dec0_g, nullptr, 0, 0, s, S.dz, S.kout, n->params + S.w_off,
+                           nullptr, nullptr, n->skip0_g, 8);
+    }
     return launch_b3conv(g[0], L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, 0, 0, s, S.dz, S.kout, n->params + S.w_off);
   }
   if (bdeconv_ok(g, cnt))   // stride-2 conv 8 -> 16: the eight parity classes of its data gradient in one launch
@@ -521,6 +591,8 @@ int bn_back(ursn_bnet* n, int li, const bf16_t* dy, int dycs, const bf16_t* y, i
   a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.kout; a.Cw = L.cout; a.relu = relu; a.scratch = n->bn_scratch;
   if (n->bs_layer == li && a.C == 8) { a.pre_partial = n->bs_scratch; a.pre_nblocks = n->bs_blocks; }
   n->bs_layer = -1;
+  // reduce: dy, z (+ y | z2); apply: the same again + dz (+ dz2 | dres); the mask bytes are 1/16 of a tensor
+  BProf ps(n, s, li, 5, 0.0, 2.0 * a.V * a.C * (2.0 * (2 + (relu && y && !mask) + (li2 >= 0)) + 1 + (li2 >= 0) + (dres != nullptr)), "bbn_bwd");
   return launch_bbn_bwd(a, s);
 }
 
@@ -552,13 +624,18 @@ int backward(ursn_bnet* n, int N, hipStream_t s) {
   const int ns = n->cfg.num_strides;
   for (size_t i = 0; i < n->ginit.size(); ++i) n->ginit[i] = 0;
   n->ev_used = 0;
+  n->split0_done = false;
   URSN_TRY(bn_back(n, n->conv2, n->dlog, 8, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
   BBsTarget tc;
   tc.li = n->conv1; tc.mode = 2;
   URSN_TRY(conv_bwd(n, n->conv2, n->a_conv1, true, N, s, -1, &tc));
   URSN_TRY(bn_back(n, n->conv1, n->a_conv1.g, n->a_conv1.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
   size_t ui = n->units.size();
-  auto join_of = [&](const BUnit& u) { BBsTarget t; t.li = u.c2; t.li2 = u.sc; t.mode = 1; t.y = u.out.p; t.ycs = u.out.cs; return t; };
+  auto join_of = [&](const BUnit& u) {
+    BBsTarget t;
+    t.li = u.c2; t.li2 = u.sc; t.mode = u.jmask ? 3 : 1; t.y = u.out.p; t.ycs = u.out.cs; t.maskb = u.jmask;
+    return t;
+  };
   tc = join_of(n->units[ui - 1]);
   URSN_TRY(conv_bwd(n, n->conv1, n->a_pre1, true, N, s, -1, &tc));
   for (int i = ns - 1; i >= 0; --i) {
@@ -566,7 +643,8 @@ int backward(ursn_bnet* n, int N, hipStream_t s) {
     URSN_TRY(unit_bwd(n, n->units[--ui], N, s, &tc));
     URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
     const BAct& dout = n->deconv_out[i];
-    URSN_TRY(bn_back(n, n->deconv[i], dout.g, dout.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
+    if (n->dec0_g && i == ns - 1 && n->split0_done) URSN_TRY(bn_back(n, n->deconv[i], n->dec0_g, 8, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
+    else URSN_TRY(bn_back(n, n->deconv[i], dout.g, dout.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
     URSN_TRY(conv_bwd(n, n->deconv[i], n->deconv_in[i], true, N, s));
   }
   for (int step = ns - 1; step >= 0; --step) {
@@ -577,7 +655,8 @@ int backward(ursn_bnet* n, int N, hipStream_t s) {
   const BAct& a0 = n->a_conv0;
   if (n->skip0_own) {   // d(conv0 activation) = the encoder's share (own tensor) + the skip's share (second half of the concat gradient)
     const BAct& cg = n->cat[ns - 1];
-    URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s, cg.g + cg.C / 2, cg.cs));
+    if (n->split0_done) URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s, n->skip0_g, 8));
+    else URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s, cg.g + cg.C / 2, cg.cs));
   } else {
     URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
   }
@@ -652,7 +731,39 @@ void bnet_destroy(ursn_bnet* n) {
   if (n->s2) { (void)hipStreamSynchronize(n->s2); (void)hipStreamDestroy(n->s2); }
   if (n->s2_done) (void)hipEventDestroy(n->s2_done);
   for (hipEvent_t e : n->evs) (void)hipEventDestroy(e);
+  for (hipEvent_t e : n->pev) (void)hipEventDestroy(e);
   delete n;
+}
+
+int bnet_profile_enable(ursn_bnet* n, int on) {
+  n->profile = on != 0;
+  n->prof.clear();
+  n->pev_used = 0;
+  return 0;
+}
+int bnet_profile_read(ursn_bnet* n, ursn_prof_rec* out, int64_t max_recs, int64_t* n_out) {
+  int64_t cnt = 0;
+  for (size_t i = 0; i < n->prof.size() && cnt < max_recs; ++i) {
+    const BProfRec& r = n->prof[i];
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    if (out) {
+      ursn_prof_rec& o = out[cnt];
+      memset(&o, 0, sizeof(o));
+      snprintf(o.kernel, sizeof(o.kernel), "%s", r.kernel);
+      snprintf(o.layer, sizeof(o.layer), "%s", n->layers[r.layer].name.c_str());
+      o.pass = r.pass; o.ms = ms; o.flops = r.flops; o.bytes = r.bytes; o.launches = r.launches;
+    }
+    ++cnt;
+  }
+  *n_out = cnt;
+  if (out) { n->prof.clear(); n->pev_used = 0; }
+  return 0;
+}
+int bnet_set_wgrad_overlap(ursn_bnet* n, int on) {
+  if (n->s2) (void)hipStreamSynchronize(n->s2);
+  n->s2_on = on != 0;
+  return 0;
 }
 
 const ursn_sizes* bnet_sizes(const ursn_bnet* n) { return &n->sizes; }
