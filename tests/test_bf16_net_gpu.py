@@ -197,3 +197,53 @@ def test_bf16_optional_kernel_paths_agree(tmp_path):
     errs = [l2_rel(outs["generic"][k], outs["no_pw"][k]) for k in ref if k.endswith("|weights") and np.abs(ref[k]).max() > 1e-12]
     print("generic vs dedicated kernels without the fused shortcut term: median %.2e worst %.2e" % (np.median(errs), max(errs)))
     assert np.median(errs) <= 0.2 and max(errs) <= 0.35
+
+
+_FULL_CHILD = r"""
+import sys, json, hashlib
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from uresnet_amd import uresnet
+from uresnet_amd import synthetic_io as sio
+dims, base, ncls, N = (256, 256, 256, 1), 8, 3, 2
+net = uresnet(dims=list(dims), num_class=ncls, base_num_outputs=base)
+net.construct(trainable=True, use_weight=True, learning_rate=1e-3, seed=99, precision='bf16')
+b = [sio.lartpc_sparse(dims, ncls, i) for i in range(N)]
+data, label, weight = (np.stack([x[j] for x in b]) for j in range(3))
+weight /= weight.sum(axis=1, keepdims=True)
+out = {"loss": [], "acc": [], "hash": []}
+for rep in range(2):
+    net.zero_gradients(None)
+    res, _ = net.accum_gradients(None, data, label, weight)
+    g = net.get_gradients()
+    h = hashlib.sha256()
+    for k in sorted(g):
+        h.update(np.ascontiguousarray(g[k]).tobytes())
+    out["loss"].append(res[1]); out["acc"].append(res[2:]); out["hash"].append(h.hexdigest())
+out["finite"] = bool(all(np.isfinite(v).all() for v in g.values()))
+sm = net.inference(None, data[:1])[0]
+out["softmax_rowsum_err"] = float(np.abs(sm.sum(-1) - 1.0).max())
+out["softmax_min"], out["softmax_max"] = float(sm.min()), float(sm.max())
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_bf16_cfg5_full_size_properties():
+    """BASELINE configs[4] at its real volume (3-D 256^3, F = 8, depth 5, bf16; batch 2 of the 4 to bound the test's time):
+    the plan the bench runs -- input-stationary kernels at levels 0 / 1, single-launch stride-2 scatter, packed concat pass,
+    BatchNorm-on-load, mask bytes, second stream.  Size-independent properties: finite loss and gradients, bitwise run-to-run
+    reproducibility of a training step (fixed-order slab reductions, no float atomics), accuracies in [0, 1], softmax rows
+    summing to 1."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _FULL_CHILD, root], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1100)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([x for x in p.stdout.split("\n") if x.startswith("RESULT ")][-1][7:])
+    assert all(np.isfinite(out["loss"])) and out["loss"][0] > 0 and out["finite"]
+    assert out["loss"][0] == out["loss"][1] and out["hash"][0] == out["hash"][1], "bf16 step is not bitwise reproducible"
+    for acc in out["acc"]:
+        assert 0.0 <= acc[0] <= 1.0 and 0.0 <= acc[1] <= 1.0
+    assert out["softmax_rowsum_err"] < 1e-5 and out["softmax_min"] >= 0.0 and out["softmax_max"] <= 1.0
