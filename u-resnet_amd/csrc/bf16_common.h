@@ -82,7 +82,8 @@ bool b3conv_bs_ok(const GatherGeom& g);
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                   double* stats_partial, int stats_off, int stats_total, hipStream_t s, const bf16_t* pw = nullptr,
                   int pw_cs = 0, const float* pw_w = nullptr, const B3BnRed* bs = nullptr, const B3Affine* aff = nullptr,
-                  bf16_t* out2 = nullptr, int out2_cs = 0);   // out2: produced channels 8..15 of a 16-channel result
+                  bf16_t* out2 = nullptr, int out2_cs = 0,    // out2: produced channels 8..15 of a 16-channel result
+                  const float* in_f32 = nullptr);             // in_f32 (K = 8): the input is one fp32 channel per voxel (`in` unused)
 // 1x1 stride-1 conv between 8 / 16 channel tensors, operands straight from global memory (bf16_pointwise.hip)
 bool bpw_ok(const GatherGeom& g);
 int bpw_grid_blocks(const GatherGeom& g);
@@ -95,9 +96,10 @@ size_t bdeconv_pack_elems();
 int launch_bdeconv(const GatherGeom* g, int cnt, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                    double* stats_partial, int accumulate, hipStream_t s);
 bool b3wgrad_ok(const GatherGeom& g);   // z-marching weight gradient of the same layers (bf16_wgrad3.hip)
+bool b3wgrad_scalar_ok(const GatherGeom& g);   // S may be one fp32 channel per voxel (S_f32)
 size_t b3wgrad_scratch_bytes(const GatherGeom& g);
 int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,
-                   size_t scratch_bytes, hipStream_t s, const B3Affine* aff = nullptr);
+                   size_t scratch_bytes, hipStream_t s, const B3Affine* aff = nullptr, const float* S_f32 = nullptr);
 // dW[t][m][n] += sum_q S[q*si+d_t][m] * C[q][n]   (fp32 accumulation, fp32 dW [t][Kw][Nw])
 size_t bwgrad_scratch_bytes(const GatherGeom& g);
 int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,

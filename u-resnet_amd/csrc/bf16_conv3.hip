@@ -62,6 +62,9 @@ struct B3Args {
   // CO = 16 only: produced channels 8..15 go to a second tensor (the two halves of a concat gradient have different consumers)
   bf16_t* out2;
   int out2_cs;
+  // CI = 8 only: the input is ONE fp32 channel per voxel (the network's data tensor, lib/uresnet.py:31-36); staged as
+  // (bf16(value), 0 x 7) -- no 8-channel bf16 copy of the input exists
+  const float* in_f32;
 };
 
 // PF2: two input planes in flight per workgroup (second register set).  A plane iteration is memory-latency-bound (its MFMA
@@ -131,11 +134,21 @@ __global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS
   auto stage_load = [&](int p, u32x4 (&arr)[G::NST]) {
     const bool pz = p >= 0 && p < a.Z;
     const bf16_t* base = a.in + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
+    if (CI == 8 && a.in_f32) {   // scalar fp32 input (in_cs = 1): uniform branch
+      const float* fb = a.in_f32 + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X;
 #pragma unroll
-    for (int i = 0; i < G::NST; ++i) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (pz && ((sval >> i) & 1u)) v = *(const u32x4*)(base + srel[i]);
-      arr[i] = v;
+      for (int i = 0; i < G::NST; ++i) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (pz && ((sval >> i) & 1u)) v[0] = (unsigned)f2bf(fb[srel[i]]);
+        arr[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < G::NST; ++i) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (pz && ((sval >> i) & 1u)) v = *(const u32x4*)(base + srel[i]);
+        arr[i] = v;
+      }
     }
     if constexpr (AFF) stin = pz ? sval : 0u;
     if constexpr (PW) {
@@ -470,7 +483,7 @@ bool b3conv_bs_ok(const GatherGeom& g) {
 
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                   double* stats_partial, int stats_off, int stats_total, hipStream_t s, const bf16_t* pw, int pw_cs,
-                  const float* pw_w, const B3BnRed* bs, const B3Affine* aff, bf16_t* out2, int out2_cs) {
+                  const float* pw_w, const B3BnRed* bs, const B3Affine* aff, bf16_t* out2, int out2_cs, const float* in_f32) {
   URSN_REQUIRE(b3conv_ok(g), "bf16 3x3x3 conv: unsupported geometry");
   URSN_REQUIRE(!pw || (b3conv_pw_ok(g) && pw_w && !stats_partial && (pw_cs & 7) == 0), "bf16 3x3x3 conv: the fused shortcut term needs the 8 -> 16 data gradient");
   B3PackArgs k;
@@ -492,6 +505,9 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
   a.aff_mean = a.aff_rstd = a.aff_beta = nullptr; a.aff_relu = 0;
   URSN_REQUIRE(!out2 || (g.Nn == 16 && (out2_cs & 7) == 0 && !stats_partial), "bf16 3x3x3 conv: a second output tensor needs 16 produced channels");
   a.out2 = out2; a.out2_cs = out2_cs;
+  URSN_REQUIRE(!in_f32 || (g.K == 8 && !pw && !bs && !aff), "bf16 3x3x3 conv: the scalar fp32 input form needs the 8-channel forward kernel");
+  a.in_f32 = in_f32;
+  if (in_f32) a.in_cs = 1;
   if (aff) {
     URSN_REQUIRE(b3conv_aff_ok(g) && !pw && !bs && aff->mean && aff->rstd && aff->beta, "bf16 3x3x3 conv: normalise-on-load needs a C -> C forward shape");
     a.aff_mean = aff->mean; a.aff_rstd = aff->rstd; a.aff_beta = aff->beta; a.aff_relu = aff->relu;

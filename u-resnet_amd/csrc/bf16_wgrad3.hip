@@ -37,6 +37,7 @@ struct W3Args {
   int zseg, nzseg, nty, ntx;
   const float* aff_mean; const float* aff_rstd; const float* aff_beta;   // AFF: S is a raw conv output, normalised while staged
   int aff_relu;
+  const float* S_f32;   // pair kernel only: S is one fp32 channel per voxel (the network input), staged as (bf16(value), 0 x 7)
 };
 
 __device__ __forceinline__ bfx8 w3_tr_pair(const unsigned char* p0, const unsigned char* p1) {
@@ -311,11 +312,21 @@ __global__ __launch_bounds__(256, 3) void b3wgradz_kernel(W3Args a) {
   auto load_x = [&](int p, int k) {
     const bool pz = p >= 0 && p < a.Z;
     const bf16_t* base = a.S + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
+    if (a.S_f32) {   // in_cs = 1
+      const float* fb = a.S_f32 + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X;
 #pragma unroll
-    for (int i = 0; i < G::NXS; ++i) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (pz && ((xval >> i) & 1u)) v = *(const u32x4*)(base + xrel[i]);
-      xs[k][i] = v;
+      for (int i = 0; i < G::NXS; ++i) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (pz && ((xval >> i) & 1u)) v[0] = (unsigned)f2bf(fb[xrel[i]]);
+        xs[k][i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < G::NXS; ++i) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (pz && ((xval >> i) & 1u)) v = *(const u32x4*)(base + xrel[i]);
+        xs[k][i] = v;
+      }
     }
     xin[k] = pz ? xval : 0u;
   };
@@ -461,6 +472,7 @@ bool b3wgrad_ok(const GatherGeom& g) {
   return w3_plan(g).grid <= (1 << 20);
 }
 
+bool b3wgrad_scalar_ok(const GatherGeom& g) { return b3wgrad_ok(g) && w3_pair(g); }
 size_t b3wgrad_scratch_bytes(const GatherGeom& g) {
   const int nt = g.K == 8 ? (w3_pair(g) ? WZ::NT : 15) : 27;
   return (size_t)w3_plan(g).grid * nt * 256 * sizeof(float) + 256;
@@ -483,7 +495,7 @@ static int w3_launch(const W3Plan& p, const W3Args& a, const W3ReduceArgs& r, hi
 }
 
 int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,
-                   size_t scratch_bytes, hipStream_t s, const B3Affine* aff) {
+                   size_t scratch_bytes, hipStream_t s, const B3Affine* aff, const float* S_f32) {
   URSN_REQUIRE(b3wgrad_ok(g), "bf16 3x3x3 wgrad: unsupported geometry");
   URSN_REQUIRE(scratch && scratch_bytes >= b3wgrad_scratch_bytes(g), "bf16 3x3x3 wgrad: scratch too small");
   const W3Plan p = w3_plan(g);
@@ -492,6 +504,9 @@ int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float*
   a.N = g.N; a.Z = g.in_d[0]; a.Y = g.in_d[1]; a.X = g.in_d[2]; a.in_cs = g.in_cs; a.out_cs = g.out_cs;
   a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
   a.aff_mean = a.aff_rstd = a.aff_beta = nullptr; a.aff_relu = 0;
+  URSN_REQUIRE(!S_f32 || (w3_pair(g) && !aff), "bf16 3x3x3 wgrad: the scalar fp32 input form needs the plane-pair kernel");
+  a.S_f32 = S_f32;
+  if (S_f32) a.in_cs = 1;
   if (aff) {
     URSN_REQUIRE(aff->mean && aff->rstd && aff->beta, "bf16 3x3x3 wgrad: incomplete normalise-on-load arguments");
     a.aff_mean = aff->mean; a.aff_rstd = aff->rstd; a.aff_beta = aff->beta; a.aff_relu = aff->relu;

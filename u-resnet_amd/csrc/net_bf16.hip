@@ -38,6 +38,7 @@ struct BAct {              // activation view + its gradient view (same layout)
   // virtual activation (never written): value = [relu] bn(z of layer aff_layer), applied by the consuming kernels while they
   // stage it (B3Affine); p stays null
   int aff_layer = -1, aff_relu = 0;
+  const float* in_f32 = nullptr;   // the network input, read as one fp32 channel per voxel by conv0's kernels (set per call)
 };
 
 struct BLayer {
@@ -83,6 +84,7 @@ struct ursn_bnet {
   // when the last transposed conv's BatchNorm runs (its half from z, the skip half recomputed from conv0's z): 16-byte
   // halves written one tensor pass apart were partial-sector writes (1.0 ms instead of 0.36 per pass at 256^3 x 4)
   bool skip0_own = false;
+  bool scalar_in = false;   // conv0 (forward and weight gradient) reads the fp32 input directly: no 8-channel bf16 copy of it
   // ... and the gradient of that concat voxel is produced as two 8-channel tensors (the transposed conv's half and the skip's
   // half have different consumers; read as 16-byte halves of a 32-byte voxel each cost a full pass of the other half)
   bf16_t* dec0_g = nullptr; bf16_t* skip0_g = nullptr;
@@ -206,6 +208,13 @@ int plan(ursn_bnet* n, Arena& A) {
 
   n->a_data = make_act(n, A, 0, 8, false);
   n->conv0 = add_layer(n, A, "conv0", 0, 3, 1, c.cin, F, 0, 0, poff);
+  {
+    GatherGeom g[8];
+    const BLayer& L0 = n->layers[n->conv0];
+    n->scalar_in = c.cin == 1 && !(getenv("URSN_BF16_SCALAR_IN") && getenv("URSN_BF16_SCALAR_IN")[0] == '0') &&
+                   layer_geoms(n, L0, PASS_FWD, c.max_batch, L0.kin, L0.kout, g) == 1 && b3conv_ok(g[0]) && g[0].K == 8 &&
+                   (!tr || (layer_geoms(n, L0, PASS_WGRAD, c.max_batch, L0.kin, L0.kout, g) == 1 && b3wgrad_scalar_ok(g[0])));
+  }
   n->skip0_own = F == 8 && !(getenv("URSN_BF16_SKIP0_OWN") && getenv("URSN_BF16_SKIP0_OWN")[0] == '0');
   n->a_conv0 = n->skip0_own ? make_act(n, A, 0, F, tr) : fmap_view(0);
   if (n->skip0_own && tr) {
@@ -377,6 +386,14 @@ int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
     URSN_TRY(launch_bdeconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, n->wpack, L.z, n->stats, 0, s));
     return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
+  if (in.in_f32) {   // conv0 on the raw fp32 input
+    URSN_REQUIRE(cnt == 1 && b3conv_ok(g[0]) && g[0].K == 8, "bf16 forward: %s cannot read a scalar fp32 input", L.name.c_str());
+    total = bconv_grid_blocks(g[0]);
+    g[0].accumulate = 0;
+    URSN_TRY(launch_b3conv(g[0], nullptr, n->params + L.w_off, Kw, Nw, n->wpack, L.z, n->stats, 0, total, s, nullptr, 0, nullptr, nullptr,
+                           nullptr, nullptr, 0, in.in_f32));
+    return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
+  }
   if (in.aff_layer >= 0) {   // virtual input: BatchNorm of the producer applied while staging
     const BLayer& P = n->layers[in.aff_layer];
     const int cnt2 = layer_geoms(n, L, PASS_FWD, N, P.kout, L.kout, g);
@@ -432,7 +449,8 @@ int forward(ursn_bnet* n, const float* data, int N, hipStream_t s) {
     URSN_HIP(hipMemsetAsync(n->beta_pad, 0, 8 * sizeof(float), s));
     URSN_HIP(hipMemcpyAsync(n->beta_pad, n->params + L2.b_off, L2.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
-  URSN_TRY(launch_bf16_input(data, n->a_data.p, (int64_t)N * n->lvox[0], s));
+  n->a_data.in_f32 = n->scalar_in ? data : nullptr;
+  if (!n->scalar_in) URSN_TRY(launch_bf16_input(data, n->a_data.p, (int64_t)N * n->lvox[0], s));
   URSN_TRY(conv_stats(n, n->conv0, n->a_data, N, s));
   URSN_TRY(bn_out(n, n->conv0, n->a_conv0, 1, N, -1, nullptr, s));
   size_t ui = 0;
@@ -512,7 +530,10 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
       ws = n->s2;
     }
     BProf pw(n, ws, li, 2, blayer_flops(n, L, N), blayer_bytes(n, L, N));
-    if (in.aff_layer >= 0) {
+    if (in.in_f32) {
+      URSN_REQUIRE(!L.kind && b3wgrad_scalar_ok(g[0]), "bf16 backward: %s cannot read a scalar fp32 input", L.name.c_str());
+      URSN_TRY(launch_b3wgrad(g[0], nullptr, L.dz, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, ws, nullptr, in.in_f32));
+    } else if (in.aff_layer >= 0) {
       const BLayer& P = n->layers[in.aff_layer];
       URSN_REQUIRE(!L.kind && layer_geoms(n, L, PASS_WGRAD, N, P.kout, L.kout, g) == 1 && b3wgrad_ok(g[0]), "bf16 backward: %s cannot normalise its input on load", L.name.c_str());
       B3Affine af = {P.mean, P.rstd, beta_of(n, P), in.aff_relu};
