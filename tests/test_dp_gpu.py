@@ -1,0 +1,69 @@
+"""Two data-parallel ranks on ONE MI355X (both processes on cuda:0, gloo process group -- RCCL refuses two ranks on one
+device): the product's own N > 1 path end to end.  Every rank builds the net from the same seed, takes its own minibatch through
+zero_gradients -> accum_gradients (HIP kernels) -> apply_gradients (all_reduce(SUM) of the flat gradient buffer, then Adam),
+and must end with weights that are bitwise equal on both ranks and bitwise equal to ONE process that accumulates the two
+minibatches (NUM_MINIBATCHES = 2: lib/ssnet.py:77 sums gradients, lib/ssnet_trainval.py:164-191) before its update -- the sum of
+two terms does not depend on who adds them.  The 8-GPU RCCL run itself is the driver's (bench.py --gpus N)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_RANK = r"""
+import os, sys
+import numpy as np
+root, out, mode = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path.insert(0, root); sys.path.insert(0, root + "/tests")
+import torch
+import torch.distributed as dist
+from _net import make_inputs
+from uresnet_amd import uresnet
+rank = int(os.environ.get("RANK", "0"))
+if mode == "dp":
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+dims, base, ncls, ns = (32, 32, 32, 1), 8, 3, 2
+net = uresnet(dims=list(dims), num_class=ncls, base_num_outputs=base, num_strides=ns)
+net.construct(trainable=True, use_weight=True, learning_rate=1e-2, seed=7)
+batches = [make_inputs(dims, ncls, 2, seed=60 + r) for r in range(2)]
+for it in range(2):
+    net.zero_gradients(None)
+    if mode == "dp":
+        net.accum_gradients(None, *batches[rank])
+    else:
+        for b in batches:
+            net.accum_gradients(None, *b)
+    net.apply_gradients(None)
+v = net.get_variables()
+np.savez(out, **{k.replace("/", "|"): a for k, a in v.items()})
+if mode == "dp":
+    dist.barrier()
+    dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_on_one_gpu_equal_two_minibatch_accumulation(tmp_path):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), WORLD_SIZE="2",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-c", _RANK, ROOT, outs[r], "dp"], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-2000:]
+    single = str(tmp_path / "single.npz")
+    p = subprocess.run([sys.executable, "-c", _RANK, ROOT, single, "single"], env=os.environ.copy(), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    a, b, s = np.load(outs[0]), np.load(outs[1]), np.load(single)
+    assert set(a.files) == set(s.files) and len(a.files) >= 40
+    moved = 0
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), ("ranks diverged", k)
+        assert np.array_equal(a[k], s[k]), ("data parallel != sequential accumulation", k)
+        moved += int(np.abs(a[k]).sum() > 0)
+    assert moved >= 40
