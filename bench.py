@@ -355,9 +355,11 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the per-launch figure
     # comes from the committed rocprofv3 --pmc passes of this same command (profiles/pmc_traffic.json), else null
     pmc = {}
+    pmc_file = {"cfg3_3d192_f8_b4": "pmc_traffic.json", "cfg5_3d256_f8_b4_bf16": "r02_pmc_traffic_cfg5_bf16.json"}.get(args.workload)
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pmc = json.load(f) if args.workload.startswith("cfg3") else {}
+        if pmc_file:
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
+                pmc = json.load(f)
     except Exception:
         pmc = {}
     roofline = None
@@ -373,6 +375,10 @@ def main():
         if convs:
             dom_name, dom = max(convs, key=lambda kv: kv[1]["ms"])
             ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            if dom_name in pmc:
+                roofline["traffic"] = round(pmc[dom_name]["hbm_bytes_per_launch"])
+                roofline["traffic_source"] = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; "
+                                              "not measured by this run)" % pmc_file)
             roofline.update({"kernel": dom_name, "achieved": round(ach, 1), "frac": round(ach / PEAK_HBM_GBS, 4),
                              "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                              "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
