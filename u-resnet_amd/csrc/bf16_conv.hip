@@ -478,12 +478,8 @@ int bconv_stats_finalize(const GatherGeom& g, const double* partial, int total_b
   if (bpw_ok(g) || b3conv_ok(g)) return launch_bn_stats_final(partial, total_blocks, g.Nn, 16, V, eps, mean, rstd, s);
   BPlan p;
   URSN_REQUIRE(bconv_plan(g, p), "bf16 conv: unsupported geometry");
-  for (int cb = 0; cb < p.ncob; ++cb) {
-    const int c0 = cb * 16 * p.cot;
-    const int cn = g.Nn - c0 < 16 * p.cot ? g.Nn - c0 : 16 * p.cot;
-    URSN_TRY(launch_bn_stats_final(partial + (size_t)cb * total_blocks * 2 * 16 * p.cot, total_blocks, cn, 16 * p.cot, V, eps,
-                                   mean + c0, rstd + c0, s));
-  }
+  URSN_TRY(launch_bn_stats_final_blocked(partial, total_blocks, g.Nn, 16 * p.cot, 16 * p.cot, (size_t)total_blocks * 2 * 16 * p.cot, V, eps,
+                                         mean, rstd, s));
   return 0;
 }
 

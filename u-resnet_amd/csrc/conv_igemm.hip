@@ -151,11 +151,7 @@ int launch_igemm_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, c
   URSN_TRY(p.mode == 3 ? dispatch_bm<3>(p, a, s) : dispatch_bm<2>(p, a, s));
   if (stats_partial) {
     const int64_t V = (int64_t)d.n * p.Z * p.Y * p.X;
-    for (int ct = 0; ct < p.gridy; ++ct) {
-      int cb = kcout - ct * p.bm < p.bm ? kcout - ct * p.bm : p.bm;
-      URSN_TRY(launch_bn_stats_final(stats_partial + (size_t)ct * p.gridx * 2 * p.bm, p.gridx, cb, p.bm, V, eps,
-                                     mean + ct * p.bm, rstd + ct * p.bm, s));
-    }
+    URSN_TRY(launch_bn_stats_final_blocked(stats_partial, p.gridx, kcout, p.bm, p.bm, (size_t)p.gridx * 2 * p.bm, V, eps, mean, rstd, s));
   }
   return 0;
 }

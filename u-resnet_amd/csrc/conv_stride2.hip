@@ -550,9 +550,7 @@ int launch_stride2_conv(const ursn_conv_desc& d, ConvPass pass, const float* in,
   if (rc) return rc;
   if (stats_partial) {
     const int64_t V = (int64_t)d.n * p.g.OZ * p.g.OY * p.g.OX;
-    for (int ct = 0; ct < p.Nn / 16; ++ct)
-      URSN_TRY(launch_bn_stats_final(stats_partial + (size_t)ct * p.gridx * 32, p.gridx, 16, 16, V, eps, mean + ct * 16,
-                                     rstd + ct * 16, s));
+    URSN_TRY(launch_bn_stats_final_blocked(stats_partial, p.gridx, p.Nn, 16, 16, (size_t)p.gridx * 32, V, eps, mean, rstd, s));
   }
   return 0;
 }

@@ -299,9 +299,7 @@ int launch_lds_scatter(const ursn_conv_desc& d, ConvPass pass, const float* in, 
   if (rc) return rc;
   if (stats_partial) {
     const int64_t V = (int64_t)d.n * p.IZ * p.IY * p.IX * (p.mode == 3 ? 8 : 4);
-    for (int ct = 0; ct < p.M / 16; ++ct)
-      URSN_TRY(launch_bn_stats_final(stats_partial + (size_t)ct * p.gridx * 32, p.gridx, 16, 16, V, eps, mean + ct * 16,
-                                     rstd + ct * 16, s));
+    URSN_TRY(launch_bn_stats_final_blocked(stats_partial, p.gridx, p.M, 16, 16, (size_t)p.gridx * 32, V, eps, mean, rstd, s));
   }
   return 0;
 }

@@ -169,10 +169,19 @@ __device__ inline void reduce_partials(const double* __restrict__ partial, int n
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ partial, int nblocks, int PC,
                                                              int64_t V, float eps, float* __restrict__ mean,
                                                              float* __restrict__ rstd, const float* __restrict__ z,
-                                                             int zcs) {
+                                                             int zcs, int CB, size_t blk_stride) {
+  // CB > 0: the partials of channel block ct = c / CB start at partial + ct * blk_stride (kernels whose grid.y walks
+  // blocks of produced channels): ONE launch finalises the whole layer (it took one per block: 174 instead of 58
+  // launches per cfg3 step)
   const int c = blockIdx.x;
+  int cc = c;
+  if (CB > 0) {
+    const int ct = c / CB;
+    cc = c - ct * CB;
+    partial += (size_t)ct * blk_stride;
+  }
   double s[2];
-  reduce_partials<2>(partial, nblocks, PC, c, s);
+  reduce_partials<2>(partial, nblocks, PC, cc, s);
   double mu = s[0] / (double)V;
   double var = s[1] / (double)V - mu * mu;   // every thread holds the same s[]
   if (z != nullptr && !(var > 0.0 && mu * mu <= 1e3 * var)) {
@@ -205,7 +214,15 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __res
 
 int launch_bn_stats_final(const double* partial, int nblocks, int C, int PC, int64_t V, float eps, float* mean,
                           float* rstd, hipStream_t s, const float* z, int zcs) {
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, partial, nblocks, PC, V, eps, mean, rstd, z, zcs);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, partial, nblocks, PC, V, eps, mean, rstd, z, zcs, 0, (size_t)0);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_bn_stats_final_blocked(const double* partial, int nblocks, int C, int CB, int PC, size_t blk_stride, int64_t V, float eps,
+                                  float* mean, float* rstd, hipStream_t s) {
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, partial, nblocks, PC, V, eps, mean, rstd, (const float*)nullptr, 0,
+                     CB, blk_stride);
   URSN_HIP(hipGetLastError());
   return 0;
 }
@@ -220,7 +237,7 @@ int launch_bn_stats(const float* z, int zcs, int64_t V, int C, float eps, float*
   else hipLaunchKernelGGL(bn_stats_partial_kernel<1>, dim3(m.grid), dim3(256), 0, s, z, zcs, V, C, m.shift, partial);
   URSN_HIP(hipGetLastError());
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, (const double*)partial, m.grid, C, V, eps, mean,
-                     rstd, (const float*)nullptr, 0);   // bn_stats_partial sums in fp64: exact enough as is
+                     rstd, (const float*)nullptr, 0, 0, (size_t)0);   // bn_stats_partial sums in fp64: exact enough as is
   URSN_HIP(hipGetLastError());
   return 0;
 }

@@ -142,6 +142,9 @@ int launch_bn_stats(const float* z, int zcs, int64_t V, int C, float eps, float*
 // whose one-pass variance is ill-conditioned (mean^2 > 1e3 var) are recomputed two-pass from z (channel stride zcs)
 int launch_bn_stats_final(const double* partial, int nblocks, int C, int PC, int64_t V, float eps, float* mean,
                           float* rstd, hipStream_t s, const float* z = nullptr, int zcs = 0);
+// partials of channel block ct (CB channels each, PC columns per partial row) start at partial + ct * blk_stride: one launch for all blocks
+int launch_bn_stats_final_blocked(const double* partial, int nblocks, int C, int CB, int PC, size_t blk_stride, int64_t V, float eps,
+                                  float* mean, float* rstd, hipStream_t s);
 // tiled small-channel conv (conv_tiled.hip): forward with fused BN-statistics partials
 int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass);
 size_t tiled_conv_stats_scratch_doubles(const ursn_conv_desc& d);
