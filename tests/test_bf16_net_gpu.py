@@ -41,7 +41,8 @@ CASES = [
     ("3d_f8_ns2", (32, 32, 64, 1), 8, 3, 2, 2),
     ("3d_f8_ns3_c5", (32, 64, 64, 1), 8, 5, 1, 3),
     ("2d_f16_ns3", (64, 128, 1), 16, 3, 2, 3),
-    ("2d_f8_ns2", (32, 64, 1), 8, 3, 2, 2),                       # 8-channel level 0 in 2-D: own skip tensor + packed concat pass, generic convs
+    ("2d_f8_ns2", (32, 64, 1), 8, 3, 2, 2),
+    ("2d_f16_ns5", (64, 64, 1), 16, 3, 2, 5),                     # 512 channels at the bottom: 64 pieces per voxel in the BatchNorm reductions                       # 8-channel level 0 in 2-D: own skip tensor + packed concat pass, generic convs
     ("cfg5_model_3d64_f8_ns5", (64, 64, 64, 1), 8, 3, 2, 5),      # BASELINE configs[4]'s model at reduced size
 ]
 

@@ -33,39 +33,49 @@ BMap make_bmap(int64_t V, int C) {
 __device__ __forceinline__ u32x4 ld16(const bf16_t* p) { return __builtin_nontemporal_load((const u32x4*)p); }
 
 // NS x 8 per-thread fp32 sums -> partial[block][NS][C] doubles.  Lanes that share a channel piece (lane & (CP - 1)) are summed
-// with shuffles in fp64, the four waves through 3 KB of LDS (a [24][257]-double staging array held the kernel to three
-// workgroups per CU).
+// with shuffles in fp64, then the four waves (CP <= 32) or the 256 / CP threads of a piece (CP >= 64) through LDS in a FIXED
+// order: no atomics (an earlier form added the waves' sums with fp64 atomics for CP > 4 -- order-dependent in the last bit and
+// one memset per launch), 24 KB of LDS (a [24][257]-double staging array once held the kernel to three workgroups per CU).
 template <int NS>
 __device__ inline void block_reduce_store8(const float (&acc)[NS][8], int CP, int C, double* partial_blk) {
-  __shared__ double sm[4][NS * 8 * 4];   // [wave][sum][piece slot < 4 when CP <= 4 .. see below]
+  __shared__ double sm[4 * NS * 8 * 32];   // [wave][sum * 8 + j][piece < 32]  |  CP >= 64: [sum * 8 + j][thread] in two halves
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (CP <= 64) {
+  if (CP <= 32) {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         double v = (double)acc[s][j];
         for (int o = 32; o >= CP; o >>= 1) v += __shfl_xor(v, o);
-        // lanes 0 .. CP-1 of every wave now hold the wave's sum for piece = lane
-        if (CP <= 4) { if (lane < CP) sm[wave][(s * 8 + j) * 4 + lane] = v; }
-        else if (lane < CP) atomicAdd(&partial_blk[s * C + lane * 8 + j], lane * 8 < C ? v : 0.0);
+        if (lane < CP) sm[(wave * NS * 8 + s * 8 + j) * 32 + lane] = v;   // lanes 0 .. CP-1 hold the wave's sum for piece = lane
       }
-    if (CP <= 4) {
+    __syncthreads();
+    for (int e = tid; e < NS * 8 * CP; e += 256) {
+      const int k = e / CP, piece = e - k * CP;   // k = s * 8 + j
+      if (piece * 8 < C)
+        partial_blk[(k >> 3) * C + piece * 8 + (k & 7)] = (sm[k * 32 + piece] + sm[(NS * 8 + k) * 32 + piece]) +
+                                                          (sm[(2 * NS * 8 + k) * 32 + piece] + sm[(3 * NS * 8 + k) * 32 + piece]);
+    }
+  } else {   // CP = 64 | 128 | 256: a piece is held by 4 | 2 | 1 threads of the block; 12 of the NS * 8 sums per LDS pass
+    const int piece = tid & (CP - 1), rep = 256 / CP;
+    for (int k0 = 0; k0 < NS * 8; k0 += 12) {
       __syncthreads();
-      if (tid < NS * 8 * CP) {
-        const int k = tid / CP, piece = tid - k * CP;   // k = s * 8 + j
-        if (piece * 8 < C)
-          partial_blk[(k >> 3) * C + piece * 8 + (k & 7)] = (sm[0][k * 4 + piece] + sm[1][k * 4 + piece]) + (sm[2][k * 4 + piece] + sm[3][k * 4 + piece]);
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = s * 8 + j;
+          if (k >= k0 && k < k0 + 12) sm[(k - k0) * 256 + tid] = (double)acc[s][j];
+        }
+      __syncthreads();
+      if (tid < CP && piece * 8 < C) {
+        for (int k = k0; k < k0 + 12 && k < NS * 8; ++k) {
+          double v = 0.0;
+          for (int r = 0; r < rep; ++r) v += sm[(k - k0) * 256 + r * CP + piece];
+          partial_blk[(k >> 3) * C + piece * 8 + (k & 7)] = v;
+        }
       }
     }
-  } else {   // CP = 128 | 256: a piece is held by 2 | 1 threads of the block
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int piece = tid & (CP - 1);
-        if (piece * 8 < C) atomicAdd(&partial_blk[s * C + piece * 8 + j], (double)acc[s][j]);
-      }
   }
 }
 
@@ -418,7 +428,6 @@ int launch_bbn_bwd(const BBnBwdArgs& a, hipStream_t s) {
   double* partial = (double*)a.scratch;
   double* finals = partial + (size_t)m.grid * 3 * a.C;
   const int mask = !a.relu ? 0 : (a.mask ? 3 : (a.y ? 1 : 2));
-  if (!a.pre_partial && m.shift > 2) URSN_HIP(hipMemsetAsync(partial, 0, (size_t)rgrid * 3 * a.C * sizeof(double), s));   // atomics path of the block reduce
 #define BRED(c8, mk, h2) hipLaunchKernelGGL((bbn_bwd_reduce_kernel<c8, mk, h2>), dim3(rgrid), dim3(256), 0, s, a, m.shift, partial)
 #define BRED2(c8, mk) do { if (a.z2) BRED(c8, mk, true); else BRED(c8, mk, false); } while (0)
 #define BRED3(c8) do { if (mask == 0) BRED2(c8, 0); else if (mask == 1) BRED2(c8, 1); else if (mask == 3) BRED2(c8, 3); else BRED2(c8, 2); } while (0)
