@@ -727,25 +727,46 @@ struct BWReduceArgs {
   int nslabs, U, ccn, cinc, nchunks, ncob, ntaps, K, Nn;   // K, Nn: extents of the STORED gradient tensor [t][K][Nn]
   int tap_w[URSN_MAX_TAPS];
 };
+// block = 64 consecutive elements x 4 slab quarters (threadIdx.y): a single thread walking several hundred slabs per element
+// was pure load latency (20 us per launch); the quarters are added in a fixed order
 __global__ __launch_bounds__(256) void bwgrad_reduce_kernel(BWReduceArgs a) {
+  __shared__ float part[4][64];
   const int cpb = a.cinc >> 3;
   const int64_t per = (int64_t)a.U * 16 * a.ccn, total = per * a.nchunks * a.ncob;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int pair = (int)(e / per);
-    const int64_t rc = e - (int64_t)pair * per;
-    const int row = (int)(rc / a.ccn), col = (int)(rc - (int64_t)row * a.ccn);
-    const int ch = pair % a.nchunks, cb_ = pair / a.nchunks;
-    const int slot = row >> 3, t = slot / cpb, cb = slot - t * cpb;
-    const int ci = ch * a.cinc + cb * 8 + (row & 7), co = cb_ * a.ccn + col;
-    if (t >= a.ntaps || ci >= a.K || co >= a.Nn) continue;
-    const float* p = a.slab + (size_t)pair * a.nslabs * per + rc;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 3 < a.nslabs; k += 4) {
-      s0 += p[(size_t)k * per]; s1 += p[(size_t)(k + 1) * per]; s2 += p[(size_t)(k + 2) * per]; s3 += p[(size_t)(k + 3) * per];
+  const int el = threadIdx.x, sl = threadIdx.y;
+  const int qn = (a.nslabs + 3) / 4, k0 = sl * qn, k1 = k0 + qn < a.nslabs ? k0 + qn : a.nslabs;
+  for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < total; e0 += (int64_t)gridDim.x * 64) {
+    const int64_t e = e0 + el;
+    float sum = 0.f;
+    int t = 0, ci = 0, co = 0;
+    bool ok = e < total;
+    if (ok) {
+      const int pair = (int)(e / per);
+      const int64_t rc = e - (int64_t)pair * per;
+      const int row = (int)(rc / a.ccn), col = (int)(rc - (int64_t)row * a.ccn);
+      const int ch = pair % a.nchunks, cb_ = pair / a.nchunks;
+      const int slot = row >> 3;
+      t = slot / cpb;
+      const int cb = slot - t * cpb;
+      ci = ch * a.cinc + cb * 8 + (row & 7);
+      co = cb_ * a.ccn + col;
+      ok = t < a.ntaps && ci < a.K && co < a.Nn;
+      if (ok) {
+        const float* p = a.slab + (size_t)pair * a.nslabs * per + rc;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = k0;
+        for (; k + 3 < k1; k += 4) {
+          s0 += p[(size_t)k * per]; s1 += p[(size_t)(k + 1) * per]; s2 += p[(size_t)(k + 2) * per]; s3 += p[(size_t)(k + 3) * per];
+        }
+        for (; k < k1; ++k) s0 += p[(size_t)k * per];
+        sum = (s0 + s1) + (s2 + s3);
+      }
     }
-    for (; k < a.nslabs; ++k) s0 += p[(size_t)k * per];
-    a.dw[(size_t)a.tap_w[t] * a.K * a.Nn + (size_t)ci * a.Nn + co] += (s0 + s1) + (s2 + s3);
+    part[sl][el] = sum;
+    __syncthreads();
+    if (sl == 0 && ok)
+      a.dw[(size_t)a.tap_w[t] * a.K * a.Nn + (size_t)ci * a.Nn + co] += (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+    __syncthreads();
   }
 }
 
@@ -868,8 +889,8 @@ int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* 
   r.nchunks = p.nchunks; r.ncob = p.ncob; r.ntaps = g.ntaps; r.K = Kw > 0 ? Kw : g.K; r.Nn = Nw > 0 ? Nw : g.Nn;
   for (int t = 0; t < g.ntaps; ++t) r.tap_w[t] = g.tap_w[t];
   const int64_t total = (int64_t)p.U * 16 * 16 * p.cot * p.nchunks * p.ncob;
-  int blocks = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
-  hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, r);
+  int blocks = (int)(cdiv64(total, 64) < 8192 ? cdiv64(total, 64) : 8192);
+  hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3(blocks), dim3(64, 4), 0, s, r);
   URSN_HIP(hipGetLastError());
   return 0;
 }
