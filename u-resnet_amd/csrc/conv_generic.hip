@@ -10,6 +10,8 @@
 //
 // These are the "any shape" path (deep levels, strided / transposed layers).  The dominant
 // small-channel full-resolution layers use the LDS-tiled kernels in conv_tiled.hip.
+#include <stdlib.h>
+
 #include "ursn_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -231,6 +233,11 @@ int launch_gconv_mfma(const GatherGeom& g, const float* in, const float* w, floa
   if (Q == 0) return 0;
   int bn = g.Nn > 32 ? 4 : (g.Nn > 16 ? 2 : 1);
   int64_t vtiles = cdiv64(Q, 16);
+  {  // few voxel tiles (the 6^3 level: 54 tiles x 4 column blocks on 256 CUs): 32-column blocks double the workgroups and halve
+     // each one's serial k loop -- 0.83 -> 0.62 ms per cfg3 step (16 columns: 0.68); URSN_GCONV_BN=4 restores the wide blocks
+    static const int narrow = getenv("URSN_GCONV_BN") ? atoi(getenv("URSN_GCONV_BN")) : 2;
+    if (narrow > 0 && narrow < bn && vtiles * ((g.Nn + 16 * bn - 1) / (16 * bn)) < 256) bn = narrow;
+  }
   int gy = (g.Nn + 16 * bn - 1) / (16 * bn);
   int64_t blocks_ks1 = cdiv64(vtiles, 16) * gy;
   int steps = g.ntaps * ((g.K + 3) / 4);
