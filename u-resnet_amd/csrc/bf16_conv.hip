@@ -429,7 +429,8 @@ static bool bconv_plan(const GatherGeom& g, BPlan& p) {
         c.gridx = (int)((boxes + c.per - 1) / c.per);
         fit = c;
         have = true;
-        if (boxes * c.ncob >= 512) { p = c; return true; }
+        static const int64_t minwg = getenv("URSN_BCONV_MINWG") ? atoi(getenv("URSN_BCONV_MINWG")) : 256;   // one workgroup per CU is enough to take the larger box (512: 77.7, 256: 78.6 img/s at cfg5)
+        if (boxes * c.ncob >= minwg) { p = c; return true; }
       }
     if (have) { p = fit; return true; }
   }
@@ -817,7 +818,8 @@ static bool bwgrad_plan(const GatherGeom& g, BWPlan& p) {
       const int64_t boxes = (int64_t)g.N * p.nb[0] * p.nb[1] * p.nb[2];
       if (p.lds > limit || boxes <= 0 || boxes >= (1ll << 30)) continue;
       // smaller boxes when the problem is small, so that more than a handful of workgroups take part
-      if (boxes * p.nchunks * p.ncob < 256 && ci + 1 < ncand) continue;
+      static const int64_t wminwg = getenv("URSN_BWGRAD_MINWG") ? atoi(getenv("URSN_BWGRAD_MINWG")) : 256;   // A/B
+      if (boxes * p.nchunks * p.ncob < wminwg && ci + 1 < ncand) continue;
       p.nboxes = (int)boxes;
       int64_t occ = (int64_t)(160 * 1024) / (p.lds + 2048);
       if (occ > 4) occ = 4;
