@@ -438,7 +438,8 @@ B3Plan b3_plan(const GatherGeom& g) {
   // two halo planes per z segment: long segments, but enough workgroups to fill 256 CUs x 2 a few times over
   int zseg = Z;
   const int64_t tiles = (int64_t)g.N * p.nty * p.ntx;
-  while (zseg > 16 && tiles * ((Z + zseg - 1) / zseg) < 2048) zseg = (zseg + 1) / 2;
+  static const int64_t minwg = getenv("URSN_B3_MINWG") ? atoi(getenv("URSN_B3_MINWG")) : 2048;   // A/B
+  while (zseg > 16 && tiles * ((Z + zseg - 1) / zseg) < minwg) zseg = (zseg + 1) / 2;
   p.zseg = zseg;
   p.nzseg = (Z + zseg - 1) / zseg;
   p.grid = (int)(tiles * p.nzseg);

@@ -447,7 +447,8 @@ W3Plan w3_plan(const GatherGeom& g) {
   p.nty = (Y + TY - 1) / TY;
   const int64_t tiles = (int64_t)g.N * p.nty * p.ntx;
   // long columns (three prologue planes each, one slab each), but at least ~2 workgroups per CU slot
-  int nz = (int)((1024 + tiles - 1) / tiles);
+  static const int64_t minwg = getenv("URSN_B3W_MINWG") ? atoi(getenv("URSN_B3W_MINWG")) : 1024;   // A/B
+  int nz = (int)((minwg + tiles - 1) / tiles);
   if (nz < 1) nz = 1;
   if (nz > (Z + 7) / 8) nz = (Z + 7) / 8;
   p.zseg = (Z + nz - 1) / nz;
