@@ -404,7 +404,8 @@ int launch_bbn_act(const BBnActArgs& a, hipStream_t s) {
   URSN_REQUIRE(piece_ok(a.C, {a.zcs, a.ycs, a.z2 ? a.z2cs : 0, a.res ? a.rescs : 0}, {a.z, a.y, a.z2, a.res}),
                "bf16 bn_act: channels / strides must be multiples of 8 and pointers 16-byte aligned (C = %d)", a.C);
   const BMap m = make_bmap(a.V, a.C);
-  const int grid = bew_grid(a.V, m.shift, 1 << 20);
+  static const int acap = getenv("URSN_BEW_AGRID") ? atoi(getenv("URSN_BEW_AGRID")) : (1 << 20);   // A/B
+  const int grid = bew_grid(a.V, m.shift, acap);
 #define BACT(c8, h2, hr) hipLaunchKernelGGL((bbn_act_kernel<c8, h2, hr>), dim3(grid), dim3(256), 0, s, a, m.shift)
 #define BACT2(c8) do { if (a.z2 && a.res) BACT(c8, true, true); else if (a.z2) BACT(c8, true, false); \
                        else if (a.res) BACT(c8, false, true); else BACT(c8, false, false); } while (0)
@@ -424,7 +425,8 @@ int launch_bbn_bwd(const BBnBwdArgs& a, hipStream_t s) {
                         {a.dy, (a.relu && !a.mask) ? a.y : nullptr, a.z, a.dz, a.z2, a.dz2, a.dres}),
                "bf16 bn_bwd: channels / strides must be multiples of 8 and pointers 16-byte aligned (C = %d)", a.C);
   const BMap m = make_bmap(a.V, a.C);   // m.grid: rows of the partial-sum scratch (bbn_scratch_bytes)
-  const int rgrid = bew_grid(a.V, m.shift, m.grid), agrid = bew_grid(a.V, m.shift, 1 << 20);
+  static const int acap = getenv("URSN_BEW_AGRID") ? atoi(getenv("URSN_BEW_AGRID")) : (1 << 20);   // A/B
+  const int rgrid = bew_grid(a.V, m.shift, m.grid), agrid = bew_grid(a.V, m.shift, acap);
   double* partial = (double*)a.scratch;
   double* finals = partial + (size_t)m.grid * 3 * a.C;
   const int mask = !a.relu ? 0 : (a.mask ? 3 : (a.y ? 1 : 2));
