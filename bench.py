@@ -93,6 +93,29 @@ def step_roofline(dims, F, ncls, batch, elem, peak_flops, peak_bw):
     return fl, by, t
 
 
+def kernel_family(name):
+    """'b3conv_bf16<8,8>+bn' -> 'b3conv', 'b3wgrad_bf16<8,8>(pair)' -> 'b3wgrad', 'twgradz_kernel<3>' -> 'twgradz'."""
+    base = name.split("<")[0].split("(")[0].split("+")[0].strip()
+    for suf in ("_bf16", "_kernel"):
+        if base.endswith(suf):
+            base = base[:-len(suf)]
+    return base
+
+
+def group_families(by_kernel):
+    """Per-launch HIP-event records grouped by kernel family; roof_ms = sum over launches of max(F / P, B / BW)."""
+    fam = {}
+    for k, v in by_kernel.items():
+        f = kernel_family(k)
+        if not f or v["ms"] <= 0:
+            continue
+        e = fam.setdefault(f, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, roof_ms=0.0, conv=v["conv"], members=[]))
+        e["ms"] += v["ms"]; e["flops"] += v["flops"]; e["bytes"] += v["bytes"]; e["launches"] += v["launches"]
+        e["roof_ms"] += v.get("roof_ms", 0.0)
+        e["members"].append(k)
+    return fam
+
+
 def cpu_baseline_child(kind, size, reps, warm):
     """Runs in a child process: the torch-CPU oracle, fwd + loss + bwd (one accum_gradients-equivalent).
     kind '3d': ONE image of size^3 x1 with cfg3's model (F=8, 3 classes, lartpc_sparse);
@@ -195,6 +218,11 @@ def main():
     ap.add_argument("--host-feed", action="store_true",
                     help="feed host (numpy) batches through the pinned copy-stream path every step; value stays the "
                          "device-resident rate, the PCIe-inclusive rate is reported beside it")
+    ap.add_argument("--backend", default=os.environ.get("URSN_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI, the production path) or gloo "
+                         "(lets several ranks share ONE GPU: the N > 1 code path rehearsed on a one-GPU box)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary workload (cfg5 bf16) that the default cfg3 run appends to its JSON line")
     ap.add_argument("--cpu-baseline-child", default="")
     ap.add_argument("--cpu-size", type=int, default=192)
     ap.add_argument("--cpu-reps", type=int, default=5)
@@ -217,10 +245,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback for the product path)"
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)   # gloo: ranks may share a device
+    torch.cuda.set_device(dev_index)
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")   # RCCL over xGMI
+        dist.init_process_group(backend=args.backend)   # "nccl" IS RCCL over xGMI on ROCm
+        ranks_seen = dist.get_world_size()
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node == --gpus\n" % (args.gpus, world))
         sys.exit(2)
@@ -241,7 +273,7 @@ def main():
     for i in range(batch):
         d, l, w = g(dims, ncls, rank * batch + i)
         data[i], label[i], weight[i] = d, l, w / w.sum()   # lib/ssnet_trainval.py:173
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
     data_d, label_d, weight_d = (torch.from_numpy(a).to(dev) for a in (data, label, weight))
 
     def step():
@@ -337,14 +369,16 @@ def main():
                      "note": "pinned source buffers, copy stream, H2D of step k+1 overlaps the kernels of step k"}
 
     by_kernel, t_roof_ms, conv_flops, conv_bytes, all_ms = {}, 0.0, 0.0, 0.0, 0.0
+    peak_flops_step = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS   # TFLOP/s the conv kernels of this plan are priced against
     by_layer = {}
     for i in range(cnt.value):
         r = recs[i]
         k = r.kernel.decode()
         le = by_layer.setdefault((r.layer.decode(), r.pass_, k), [0.0, r.flops, r.bytes])
         le[0] += r.ms
-        e = by_kernel.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, conv=r.pass_ <= 2))
+        e = by_kernel.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, conv=r.pass_ <= 2, roof_ms=0.0))
         e["ms"] += r.ms; e["flops"] += r.flops; e["bytes"] += r.bytes; e["launches"] += max(int(r.launches), 1)
+        e["roof_ms"] += max(r.flops / (peak_flops_step * 1e9), r.bytes / (PEAK_HBM_GBS * 1e6))
         all_ms += r.ms
         if r.pass_ <= 2:
             t_roof_ms += max(r.flops / (PEAK_FP32_TFLOPS * 1e9), r.bytes / (PEAK_HBM_GBS * 1e6))
@@ -371,21 +405,37 @@ def main():
         ach_step = by / (ms_per_step * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "whole step", "achieved": round(ach_step, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach_step / PEAK_HBM_GBS, 4), "traffic": None, "traffic_source": None}
-        convs = [(k, v) for k, v in by_kernel.items() if v["conv"] and v["ms"] > 0]
+        # kernels grouped by FAMILY (b3conv*, bconv*, b3wgrad*, bwgrad*, ...): the finer per-variant labels would otherwise let a
+        # family of many small launches hide behind its largest member, or a variant stand in for the family
+        fam = group_families(by_kernel)
+        convs = [(k, v) for k, v in fam.items() if v["conv"]]
         if convs:
             dom_name, dom = max(convs, key=lambda kv: kv[1]["ms"])
             ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-            if dom_name in pmc:
-                roofline["traffic"] = round(pmc[dom_name]["hbm_bytes_per_launch"])
+            pm = [(pmc[k]["hbm_bytes_per_launch"], pmc[k]["launches"]) for k in pmc if not k.startswith("_") and kernel_family(k) == dom_name]
+            if pm:
+                roofline["traffic"] = round(sum(b * l for b, l in pm) / sum(l for _, l in pm))
                 roofline["traffic_source"] = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; "
-                                              "not measured by this run)" % pmc_file)
-            roofline.update({"kernel": dom_name, "achieved": round(ach, 1), "frac": round(ach / PEAK_HBM_GBS, 4),
+                                              "launch-weighted over the family's kernels; not measured by this run)" % pmc_file)
+            roofline.update({"kernel": dom_name + "* (family: %s)" % ", ".join(sorted(dom["members"])),
+                             "achieved": round(ach, 1), "frac": round(ach / PEAK_HBM_GBS, 4),
                              "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                              "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
                              "kernel_share_of_step": round(dom["ms"] / max(all_ms, 1e-9), 3),
+                             "frac_of_own_roofline": round(dom["roof_ms"] / dom["ms"], 4),
                              "achieved_TFLOPs": round(dom["flops"] / (dom["ms"] * 1e-3) / 1e12, 1),
                              "kernel_timing": "HIP events per launch, %d steps with the weight-gradient stream serialised "
                                               "(%.1f ms/step serial vs %.1f overlapped)" % (prof_steps, serial_ms_per_step, ms_per_step)})
+            # ... and the conv family furthest below its own roofline among those worth >= 2 % of the step
+            low = [(k, v) for k, v in convs if v["ms"] >= 0.02 * all_ms]
+            if low:
+                ln, lv = min(low, key=lambda kv: kv[1]["roof_ms"] / kv[1]["ms"])
+                roofline["furthest_below_roofline"] = {
+                    "kernel": ln + "*", "ms_per_step": round(lv["ms"] / prof_steps, 3), "launches_per_step": lv["launches"] // prof_steps,
+                    "frac_of_own_roofline": round(lv["roof_ms"] / lv["ms"], 4),
+                    "achieved_GBs_algorithmic": round(lv["bytes"] / (lv["ms"] * 1e-3) / 1e9, 1),
+                    "achieved_TFLOPs": round(lv["flops"] / (lv["ms"] * 1e-3) / 1e12, 1)}
+            roofline["families_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         roofline.update({"algorithmic_bytes_per_step": round(by), "step_algorithmic_TFLOPs": round(fl / 1e12, 3),
                          "step_T_roof_ms": round(t_roof * 1e3, 3), "step_frac_of_roofline": round(t_roof * 1e3 / ms_per_step, 4),
                          "step_HBM_GBs_algorithmic": round(ach_step, 1),
@@ -410,6 +460,16 @@ def main():
                     "step_HBM_GBs_algorithmic": round(conv_bytes / prof_steps / 1e9 / (ms_per_step * 1e-3), 1),
                     "kernel_timing": "HIP events per launch, %d steps with the weight-gradient stream serialised "
                                      "(%.1f ms/step serial vs %.1f overlapped)" % (prof_steps, serial_ms_per_step, ms_per_step)}
+    if by_kernel and not bf16 and roofline is not None:
+        fam = group_families(by_kernel)
+        low = [(k, v) for k, v in fam.items() if v["conv"] and v["ms"] >= 0.02 * all_ms]
+        if low:
+            ln, lv = min(low, key=lambda kv: kv[1]["roof_ms"] / kv[1]["ms"])
+            roofline["furthest_below_roofline"] = {
+                "kernel": ln + "*", "ms_per_step": round(lv["ms"] / prof_steps, 3), "launches_per_step": lv["launches"] // prof_steps,
+                "frac_of_own_roofline": round(lv["roof_ms"] / lv["ms"], 4),
+                "achieved_TFLOPs": round(lv["flops"] / (lv["ms"] * 1e-3) / 1e12, 1)}
+        roofline["families_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
     if rank == 0 and args.breakdown:
         for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"]):
             tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 and v["flops"] else 0.0
@@ -432,6 +492,26 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and len(dims) == 4:
         cpu = run_cpu_baseline(int(dims[0]))
 
+    secondary = None
+    if rank == 0 and world == 1 and args.workload == "cfg3_3d192_f8_b4" and not args.no_secondary:
+        # BASELINE.json configs[4] (3-D 256^3 bf16) timed by the same invocation: a CHILD process started after this one has
+        # released its workspace (never an exec from a process that holds the GPU); the headline above is untouched
+        del net
+        torch.cuda.empty_cache()
+        try:
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "cfg5_3d256_f8_b4_bf16", "--steps", str(args.steps),
+                                 "--warmup", str(args.warmup), "--no-cpu-baseline"], stdout=subprocess.PIPE, text=True, timeout=900)
+            line = [x for x in cp.stdout.strip().split("\n") if x.startswith("{")]
+            if cp.returncode == 0 and line:
+                c5 = json.loads(line[-1])
+                secondary = {"workload": c5["config"]["workload"], "dtype": c5["dtype"], "metric": c5["metric"], "value": c5["value"],
+                             "unit": c5["unit"], "steps": c5["steps"], "warmup": c5["warmup"], "ms_per_step": c5["ms_per_step"],
+                             "config": c5["config"], "last_metrics": c5["last_metrics"], "roofline": c5["roofline"]}
+            else:
+                secondary = {"workload": "cfg5_3d256_f8_b4_bf16", "error": "child exited with %d" % cp.returncode}
+        except Exception as e:   # the headline must survive a failing secondary leg
+            secondary = {"workload": "cfg5_3d256_f8_b4_bf16", "error": repr(e)}
+
     if rank == 0:
         out = {
             "metric": "fwd+bwd images/sec on 3D 192^3x1 U-ResNet" if args.workload.startswith("cfg3")
@@ -442,10 +522,11 @@ def main():
             "config": {"workload": args.workload, "dims": list(dims), "base_filters": base, "num_class": ncls,
                        "batch_per_gpu": batch, "global_batch": batch * world,
                        "step": "zero_gradients+accum_gradients(fwd+loss+bwd)+allreduce+adam",
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world, "backend": (args.backend if world > 1 else None)},
+            "ranks_seen": ranks_seen,
             "last_metrics": {"loss": metrics[0], "acc_all": metrics[1], "acc_nonzero": metrics[2]},
             "step_parts": parts, "host_feed": host_feed,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(out))
     if world > 1:

@@ -248,3 +248,47 @@ def test_bf16_cfg5_full_size_properties():
     for acc in out["acc"]:
         assert 0.0 <= acc[0] <= 1.0 and 0.0 <= acc[1] <= 1.0
     assert out["softmax_rowsum_err"] < 1e-5 and out["softmax_min"] >= 0.0 and out["softmax_max"] <= 1.0
+
+
+def test_bf16_driver_call_sequence_checkpoint_and_resume(tmp_path, capsys):
+    """PRECISION 'bf16' in the cfg file reaches construct(): override_config -> initialize -> batch_process -> reset
+    (run_ssnet.py:11-19) trains, snapshots and resumes the mixed-precision plan, and ana_step serves the device labels."""
+    from uresnet_amd.ssnet_trainval import ssnet_trainval
+    inp = tmp_path / "input.cfg"
+    inp.write_text("Dims [32, 32, 64, 1]\nNumClass 3\nGenerator 'lartpc_sparse'\nNumEntries 64\n"
+                   "Keys {'data': 'data', 'label': 'label', 'weight': 'weight'}\n")
+    cfg = tmp_path / "train.cfg"
+    cfg.write_text("NUM_CLASS 3\nBASE_NUM_FILTERS 8\nMAIN_INPUT_CONFIG '%s'\nLOGDIR '%s'\nSAVE_FILE '%s'\n"
+                   "ITERATIONS 3\nMINIBATCH_SIZE 2\nNUM_MINIBATCHES 2\nLEARNING_RATE 0.001\nTRAIN True\n"
+                   "USE_WEIGHTS True\nREPORT_STEPS 1\nSUMMARY_STEPS 2\nCHECKPOINT_STEPS 2\nPRECISION 'bf16'\n"
+                   % (inp, tmp_path / "log", tmp_path / "ckpt" / "uresnet"))
+    t = ssnet_trainval()
+    t.override_config(str(cfg))
+    t.initialize()
+    assert t._net._precision == 'bf16' and t._net._cfg.act_dtype == 1
+    t.batch_process()
+    out = capsys.readouterr().out
+    assert out.count("@ iteration") == 3 and "Train set: loss=" in out and "saved @" in out
+    snap = tmp_path / "ckpt" / "uresnet-1.npz"
+    assert snap.is_file()
+    with np.load(str(snap)) as f:
+        saved = {k: f[k] for k in f.files}
+    assert set(saved) == set(t._net.variable_names()) and all(v.dtype == np.float32 for v in saved.values())
+    t.reset()
+    cfg2 = tmp_path / "ana.cfg"
+    cfg2.write_text("NUM_CLASS 3\nBASE_NUM_FILTERS 8\nMAIN_INPUT_CONFIG '%s'\nLOGDIR ''\nSAVE_FILE ''\n"
+                    "LOAD_FILE '%s'\nITERATIONS 2\nMINIBATCH_SIZE 2\nTRAIN False\nUSE_WEIGHTS False\n"
+                    "SUMMARY_STEPS 0\nCHECKPOINT_STEPS 0\nPRECISION 'bf16'\n" % (inp, tmp_path / "ckpt" / "uresnet-1"))
+    a = ssnet_trainval()
+    a.override_config(str(cfg2))
+    a.initialize()
+    assert a.current_iteration() == 1 and a._net._precision == 'bf16'
+    got = a._net.get_variables()
+    assert all(np.array_equal(got[k], saved[k]) for k in saved)
+    r = a.ana_step()
+    assert r['softmax'].shape == (2, 32, 32, 64, 3) and np.isfinite(r['softmax']).all()
+    a.reset()
+    bad = tmp_path / "bad.cfg"
+    bad.write_text("PRECISION 'fp16'\n")
+    with pytest.raises(TypeError):
+        ssnet_trainval().override_config(str(bad))

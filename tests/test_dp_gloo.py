@@ -82,7 +82,7 @@ class _StubNet(object):
         self._dims, self._num_class = list(dims), num_class
         self._device = "cpu"
 
-    def construct(self, trainable=True, use_weight=True, learning_rate=None, seed=1234):
+    def construct(self, trainable=True, use_weight=True, learning_rate=None, seed=1234, precision="fp32"):
         import uresnet_amd.ssnet as S
         self._opt = S._Adam(learning_rate if learning_rate and learning_rate > 0 else 1e-3)
         self._trainable = trainable

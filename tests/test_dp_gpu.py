@@ -67,3 +67,23 @@ def test_two_ranks_on_one_gpu_equal_two_minibatch_accumulation(tmp_path):
         assert np.array_equal(a[k], s[k]), ("data parallel != sequential accumulation", k)
         moved += int(np.abs(a[k]).sum() > 0)
     assert moved >= 40
+
+
+def test_bench_n2_path_two_ranks_on_one_gpu_over_gloo():
+    """bench.py's world > 1 path (barrier + max-over-ranks timing, all-reduce inside apply_gradients, rank-0 JSON line) end to
+    end as the driver launches it (`python bench.py --gpus 2` -> torch.distributed.run, one process per rank), here with both
+    ranks on the one GPU over gloo (--backend gloo; RCCL refuses two ranks on one device).  The 8-GPU RCCL run is the driver's."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--workload", "tiny_3d64_f8_b2", "--backend", "gloo"], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [x for x in p.stdout.split("\n") if x.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]           # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2" and out["config"]["backend"] == "gloo"
+    assert out["scaling"] == "weak" and out["value"] > 0 and abs(out["value"] - 4 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-2 * out["value"]
+    assert out["step_parts"]["allreduce_ms"] > 0
+    assert out["roofline"] is not None and out["secondary"] is None and out["cpu_baseline"] is None

@@ -44,6 +44,9 @@ class ssnet_config(object):
     KEYWORD_TEST_DATA = ''
     KEYWORD_TEST_LABEL = ''
     KEYWORD_TEST_WEIGHT = ''
+    # not in the reference (fp32 TensorFlow): 'fp32' | 'bf16' -- bf16 = mixed precision of BASELINE.json configs[4]
+    # (activations / gradient tensors bf16 in HBM, fp32 parameters, statistics, accumulators and Adam)
+    PRECISION = 'fp32'
 
     def __init__(self):
         pass
@@ -82,6 +85,9 @@ class ssnet_config(object):
                 raise TypeError(line)
             if key != 'LEARNING_RATE' and type(getattr(self, key)) != type(value):
                 print('Incompatible type: %s' % line)
+                raise TypeError(line)
+            if key == 'PRECISION' and value not in ('fp32', 'bf16'):
+                print('Incompatible value: %s' % line)
                 raise TypeError(line)
             setattr(self, key, value)
 

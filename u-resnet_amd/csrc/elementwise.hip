@@ -184,7 +184,9 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __res
   reduce_partials<2>(partial, nblocks, PC, cc, s);
   double mu = s[0] / (double)V;
   double var = s[1] / (double)V - mu * mu;   // every thread holds the same s[]
-  if (z != nullptr && !(var > 0.0 && mu * mu <= 1e3 * var)) {
+  // s[1] == 0: every z of the channel is exactly 0 (an empty event batch, zero-padded inference) -- mean = var = 0 are exact
+  // already, and walking a whole 192^3 x 4 tensor with one block per channel here would stall every layer of such a step
+  if (z != nullptr && s[1] != 0.0 && !(var > 0.0 && mu * mu <= 1e3 * var)) {
     __shared__ double sm2[2][256];
     double d1 = 0.0, d2 = 0.0;
     for (int64_t v = threadIdx.x; v < V; v += 256) {

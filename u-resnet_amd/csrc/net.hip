@@ -1051,7 +1051,7 @@ extern "C" int ursn_tensor(const ursn_net* net, const char* name, float** ptr, i
   URSN_REQUIRE(net && name && ptr && voxels && channels && cstride, "tensor: null argument");
   if (net->bf) return bnet_tensor(net->bf, name, (void**)ptr, voxels, channels, cstride);
   std::string s(name);
-  bool want_z = false, want_g = false, want_dz = false;
+  bool want_z = false, want_g = false, want_dz = false, want_mean = false, want_rstd = false;
   auto strip = [&](const char* suf, bool& f) {
     size_t L = strlen(suf);
     if (s.size() > L && s.compare(s.size() - L, L, suf) == 0) { f = true; s = s.substr(0, s.size() - L); }
@@ -1059,12 +1059,21 @@ extern "C" int ursn_tensor(const ursn_net* net, const char* name, float** ptr, i
   strip(":dz", want_dz);
   strip(":z", want_z);
   strip(":grad", want_g);
-  if (want_z || want_dz) {
+  strip(":mean", want_mean);
+  strip(":rstd", want_rstd);
+  if (want_g && s == "logits") {   // d loss / d logits as the head wrote it (input of conv2's BatchNorm backward)
+    URSN_REQUIRE(net->dlog, "tensor: net is not trainable");
+    const Layer& L = net->layers[net->conv2];
+    *ptr = net->dlog; *voxels = net->lvox[0]; *channels = L.cout; *cstride = L.zcs;
+    return 0;
+  }
+  if (want_z || want_dz || want_mean || want_rstd) {
     auto it = net->named_z.find(s);
     URSN_REQUIRE(it != net->named_z.end(), "tensor: no layer named %s", s.c_str());
     const Layer& L = net->layers[it->second];
-    *ptr = want_z ? L.z : L.dz;
-    *voxels = net->lvox[L.lout];
+    *ptr = want_z ? L.z : want_dz ? L.dz : want_mean ? L.mean : L.rstd;
+    URSN_REQUIRE(*ptr, "tensor: %s does not exist (net is not trainable)", name);
+    *voxels = (want_mean || want_rstd) ? 0 : net->lvox[L.lout];   // 0: a per-channel fp32 vector, not a per-voxel tensor
     *channels = L.cout;
     *cstride = L.zcs;
     return 0;

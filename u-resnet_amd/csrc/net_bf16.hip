@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -104,6 +105,7 @@ struct ursn_bnet {
   hipEvent_t s2_done = nullptr;
   std::vector<hipEvent_t> evs;
   size_t ev_used = 0;
+  std::map<std::string, BAct> named;   // debug lookup (ursn_tensor): materialised activations and their gradient tensors
 };
 
 namespace {
@@ -201,7 +203,7 @@ int plan(ursn_bnet* n, Arena& A) {
   }
   int64_t poff = 0;
   n->layers.clear(); n->units.clear(); n->deconv.clear(); n->cat.clear(); n->deconv_in.clear(); n->deconv_out.clear();
-  n->ginit.clear();
+  n->ginit.clear(); n->named.clear();
   n->cat.resize(ns);
   for (int i = 0; i < ns; ++i) n->cat[i] = make_act(n, A, ns - 1 - i, 2 * (F << (ns - 1 - i)), tr);
   auto fmap_view = [&](int lvl) { const BAct& full = n->cat[ns - 1 - lvl]; return sub_act(full, full.C / 2, full.C / 2); };
@@ -244,8 +246,11 @@ int plan(ursn_bnet* n, Arena& A) {
     if (tr && !(getenv("URSN_BF16_RELU_MASK") && getenv("URSN_BF16_RELU_MASK")[0] == '0'))
       u.jmask = (unsigned char*)A.take((size_t)c.max_batch * n->lvox[lout] * (pad8(co) / 8) + 256);
     n->units.push_back(u);
+    n->named["UResNet/" + scope] = u.out;
+    n->named[n->layers[u.c1].name] = u.a1;
     return u.out;
   };
+  n->named["UResNet/conv0"] = n->a_conv0;
   BAct net = n->a_conv0;
   char sc[64];
   for (int step = 0; step < ns; ++step) {
@@ -263,6 +268,7 @@ int plan(ursn_bnet* n, Arena& A) {
     n->deconv.push_back(li);
     n->deconv_in.push_back(net);
     n->deconv_out.push_back(sub_act(n->cat[i], 0, co));
+    n->named[n->layers[li].name] = n->deconv_out.back();
     snprintf(sc, sizeof(sc), "resnet_module%d/module1", i + 5);
     BAct u1 = add_unit(sc, n->cat[i], co, 1, lvl, nullptr);
     snprintf(sc, sizeof(sc), "resnet_module%d/module2", i + 5);
@@ -275,6 +281,7 @@ int plan(ursn_bnet* n, Arena& A) {
     const bool virt = virtual_ok(n->layers[n->conv2]);   // conv1's activation feeds conv2 only (lib/uresnet.py:84-100)
     n->a_conv1 = make_act(n, A, 0, F, tr, !virt);
     if (virt) { n->a_conv1.aff_layer = n->conv1; n->a_conv1.aff_relu = 1; }
+    n->named["UResNet/conv1"] = n->a_conv1;
   }
 
   const int64_t V0 = (int64_t)c.max_batch * n->lvox[0];
@@ -821,20 +828,56 @@ int bnet_step(ursn_bnet* n, const float* data, const float* label, const float* 
 }
 
 int bnet_tensor(const ursn_bnet* n, const char* name, void** ptr, int64_t* voxels, int32_t* channels, int32_t* cstride) {
+  // <scope>:z / :dz raw conv output and its gradient (bf16), <scope>:mean / :rstd the BatchNorm statistics (fp32, voxels = 0),
+  // <scope> / <scope>:grad a materialised activation and the gradient tensor of the same layout (bf16), logits:grad the head's
+  // output; at F = 8 the level-0 concat gradient lives in two 8-channel tensors: UResNet/deconv<last>:grad and
+  // UResNet/conv0:grad2 (the skip's share; UResNet/conv0:grad is the encoder's share)
   std::string s(name);
-  bool want_z = false, want_dz = false;
+  bool want_z = false, want_dz = false, want_g = false, want_g2 = false, want_mean = false, want_rstd = false;
   auto strip = [&](const char* suf, bool& f) {
     const size_t L = strlen(suf);
     if (s.size() > L && s.compare(s.size() - L, L, suf) == 0) { f = true; s = s.substr(0, s.size() - L); }
   };
   strip(":dz", want_dz);
   strip(":z", want_z);
-  for (const BLayer& L : n->layers)
-    if (L.name == s && (want_z || want_dz)) {
-      *ptr = want_z ? (void*)L.z : (void*)L.dz;
-      *voxels = n->lvox[L.lout]; *channels = L.cout; *cstride = L.kout;
-      return 0;
-    }
-  ursn_set_error("tensor: the bf16 plan exposes raw conv outputs only (<scope>:z, <scope>:dz), not %s", name);
-  return 2;
+  strip(":grad2", want_g2);
+  strip(":grad", want_g);
+  strip(":mean", want_mean);
+  strip(":rstd", want_rstd);
+  const int ns = n->cfg.num_strides;
+  if (want_g && s == "logits") {
+    URSN_REQUIRE(n->dlog, "tensor: net is not trainable");
+    *ptr = n->dlog; *voxels = n->lvox[0]; *channels = n->cfg.num_class; *cstride = 8;
+    return 0;
+  }
+  if (want_z || want_dz || want_mean || want_rstd) {
+    for (const BLayer& L : n->layers)
+      if (L.name == s) {
+        *ptr = want_z ? (void*)L.z : want_dz ? (void*)L.dz : want_mean ? (void*)L.mean : (void*)L.rstd;
+        URSN_REQUIRE(*ptr, "tensor: %s does not exist (net is not trainable)", name);
+        *voxels = (want_mean || want_rstd) ? 0 : n->lvox[L.lout]; *channels = L.cout; *cstride = L.kout;
+        return 0;
+      }
+    ursn_set_error("tensor: no layer named %s", s.c_str());
+    return 2;
+  }
+  if (want_g2) {
+    URSN_REQUIRE(s == "UResNet/conv0" && n->skip0_own && n->cfg.trainable, "tensor: %s has no second gradient tensor", s.c_str());
+    const BAct& cg = n->cat[ns - 1];
+    if (n->split0_done) { *ptr = n->skip0_g; *cstride = 8; }
+    else { *ptr = cg.g + cg.C / 2; *cstride = cg.cs; }
+    *voxels = n->lvox[0]; *channels = 8;
+    return 0;
+  }
+  auto it = n->named.find(s);
+  URSN_REQUIRE(it != n->named.end(), "tensor: no activation named %s", s.c_str());
+  const BAct& a = it->second;
+  *voxels = n->lvox[a.lvl]; *channels = a.C; *cstride = a.cs;
+  if (want_g && n->split0_done && n->dec0_g && s == n->layers[n->deconv[ns - 1]].name) {
+    *ptr = n->dec0_g; *cstride = 8;
+    return 0;
+  }
+  *ptr = want_g ? (void*)a.g : (void*)a.p;
+  URSN_REQUIRE(*ptr, "tensor: %s is not materialised (its BatchNorm is applied while the consuming convolution stages it)", name);
+  return 0;
 }

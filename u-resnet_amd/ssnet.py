@@ -303,6 +303,10 @@ class ssnet_base(object):
         if slot.dev[i] is None or slot.dev[i].shape[0] < n:
             slot.dev[i] = torch.empty((n, cols), dtype=torch.float32, device=self._device)
             slot.consumed[i] = None
+            # the caching allocator hands out blocks in compute-stream order: a block freed with kernels still pending on
+            # the compute stream may come back here, and the copy stream must not write it before they have finished
+            cs.wait_stream(torch.cuda.current_stream(self._device))
+            slot.dev[i].record_stream(cs)
         dst = slot.dev[i][:n]
         src = torch.from_numpy(host)
         if not src.is_pinned():
@@ -505,6 +509,12 @@ class ssnet_base(object):
         ptr, vox, ch, cs = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
         _lib.check(_lib.load().ursn_tensor(self._handle, name.encode(), ctypes.byref(ptr), ctypes.byref(vox),
                                            ctypes.byref(ch), ctypes.byref(cs)))
+        from . import hiprt
+        if vox.value == 0:   # <scope>:mean / :rstd -- a per-channel fp32 vector in both precisions
+            torch.cuda.synchronize(self._device)
+            buf = (ctypes.c_float * ch.value)()
+            hiprt.memcpy_d2h(buf, ptr.value, ch.value * 4)
+            return np.frombuffer(buf, dtype=np.float32).copy()
         n = self._last_feed['input_data'].shape[0]
         total = int(n * vox.value * cs.value)
         valid = total - (cs.value - ch.value)  # a channel-slice view ends `ch` floats into its last voxel

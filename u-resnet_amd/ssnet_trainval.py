@@ -148,7 +148,8 @@ class ssnet_trainval(object):
         dims = self._input_main.fetch_data(cfg.KEYWORD_DATA).dim()[1:]
         self._net = uresnet(dims=dims, num_class=cfg.NUM_CLASS, base_num_outputs=cfg.BASE_NUM_FILTERS, debug=cfg.DEBUG)
         extra = {'learning_rate': cfg.LEARNING_RATE} if cfg.TRAIN else {}
-        self._net.construct(trainable=cfg.TRAIN, use_weight=cfg.USE_WEIGHTS, seed=cfg.TF_RANDOM_SEED, **extra)
+        self._net.construct(trainable=cfg.TRAIN, use_weight=cfg.USE_WEIGHTS, seed=cfg.TF_RANDOM_SEED,
+                            precision=cfg.PRECISION, **extra)
         self._sess = HipSession()
 
         self._saved = collections.deque()
