@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define URSN_ABI_VERSION 5
+#define URSN_ABI_VERSION 6
 
 typedef struct ursn_net ursn_net; /* opaque */
 
@@ -186,9 +186,12 @@ typedef struct ursn_conv_desc {
   const float* pw_dy;  /* [voxels][cout] gradient at the shortcut conv's output                                       */
   const float* pw_w;   /* [cin][cout] shortcut weights                                                                 */
   int32_t pw_dy_cstride; /* 0 = compact (= cout)                                                                       */
-  int32_t dtype;         /* 0: fp32 tensors.  1: x / y / dx / dy are bf16 (uint16 bit patterns), channel counts and strides
-                          * multiples of 8, weights and dw stay fp32 (BASELINE configs[4] mixed precision); in_split, pw_dy and
-                          * in_mean are fp32-only                                                                                */
+  int32_t dtype;         /* 0: fp32 tensors.  1: x / y / dx / dy (and pw_dy, dx2) are bf16 (uint16 bit patterns), channel counts and
+                          * strides multiples of 8, weights and dw stay fp32 (BASELINE configs[4] mixed precision).  The fused forms
+                          * of the bf16 plan are reachable here on the shapes its dedicated kernels take (3-D k3 s1, 8 / 16 channels):
+                          * in_mean / in_rstd / in_beta / in_relu (forward C -> C and weight gradient), pw_dy / pw_w (data gradient of a
+                          * 16 -> 8 layer), in_split = 8 with dx2 (that data gradient written as two 8-channel tensors), and cin = 1:
+                          * x is ONE fp32 channel per voxel (the network input read by conv0's forward and weight gradient)         */
   /* Normalise-on-load (forward and weight gradient): x is the RAW output z of the preceding conv whose BatchNorm has no
    * activation (resnet_conv1 inside a residual unit, lib/resnet_module.py:43-51); the kernel stages
    * (z - in_mean) * in_rstd + in_beta per input channel (zero padding stays zero), so that activation is never
@@ -215,7 +218,8 @@ typedef struct ursn_conv_desc {
   int32_t bs_z_cstride;  /* 0 = compact */
   int32_t bs_z2_cstride;
   int32_t bs_relu;
-  int32_t reserved2_;
+  int32_t in_relu;       /* normalise-on-load with the producer's ReLU: stages max(bn(z), 0) (dtype 1 only: conv1 -> conv2,
+                          * lib/uresnet.py:103-121)                                                                              */
 } ursn_conv_desc;
 
 /* y = conv(x, w).  w layout [k..,Cin,Cout] (transposed: [k..,Cout,Cin]). */
@@ -244,6 +248,35 @@ int ursn_bn_backward(const float* dy, const float* y, const float* z, float* dz,
                      int64_t voxels, int32_t channels, float eps, int32_t relu, void* scratch,
                      size_t scratch_bytes, void* stream);
 size_t ursn_bn_scratch_bytes(int64_t voxels, int32_t channels);
+
+/* BatchNorm passes of the bf16 plan at op level (slim.batch_norm forward / backward at lib/resnet_module.py:31,49,64 and
+ * lib/uresnet.py:42,75,85,109,119 on bf16 tensors; bf16_elementwise.hip) with every optional operand the plan uses.  Tensors
+ * are bf16 bit patterns with channel counts / strides multiples of 8; statistics, beta and d(beta) are fp32.
+ *   forward : y = act(bn(z) [+ bn2(z2) | + res]); mask_out (relu): one byte per 16-byte piece of y, bit j = (channel j > 0);
+ *             cat != 0 (8 channels): y[v] = [act(bn(z)) | act(bn2(z2))], both halves of a concat voxel in one store
+ *   backward: g = (dy [+ dy2]) * mask, mask = the bytes `mask` | y > 0 | bn(z) > 0 (first that is given; relu != 0);
+ *             dz = r (g - mean g - xhat mean(g xhat)), d(beta) += sum g; with z2: the join's second BatchNorm gets dz2 /
+ *             dbeta2 from the same g; dres (=|+=) g is the identity shortcut's share (lib/resnet_module.py:22-23,68)     */
+typedef struct ursn_bn_bf16_desc {
+  int64_t voxels;
+  int32_t channels, relu;
+  const void* z;   int32_t z_cstride;   const float *mean, *rstd, *beta;
+  const void* z2;  int32_t z2_cstride;  const float *mean2, *rstd2, *beta2;
+  const void* res; int32_t res_cstride;
+  void* y;         int32_t y_cstride;   /* forward output; backward: optional mask source (y > 0) */
+  uint8_t* mask_out;
+  int32_t cat;
+  const void* dy;  int32_t dy_cstride;
+  const void* dy2; int32_t dy2_cstride;
+  const uint8_t* mask;
+  void* dz;        int32_t dz_cstride;
+  void* dz2;       int32_t dz2_cstride;
+  float *dbeta, *dbeta2;
+  void* dres;      int32_t dres_cstride; int32_t dres_accumulate;
+} ursn_bn_bf16_desc;
+int ursn_bn_bf16_forward(const ursn_bn_bf16_desc* d, void* stream);
+int ursn_bn_bf16_backward(const ursn_bn_bf16_desc* d, void* scratch, size_t scratch_bytes, void* stream);
+size_t ursn_bn_bf16_scratch_bytes(int64_t voxels, int32_t channels);
 
 /* Fused head (lib/ssnet.py:57-71): softmax / weighted CE / accuracies / dlogits.
  * logits [n*pix, ncls]; data [n*pix] (cin==1); out3 = {loss, acc_all, acc_nonzero};

@@ -55,6 +55,19 @@ def topology(F, ns):
     return ops, width
 
 
+def staged_bn(z, mean, rstd, beta, relu):
+    """What a normalise-on-load consumer of the bf16 plan stages for a never-written activation (bf16_conv3.hip /
+    bf16_wgrad3.hip AFF): bf16(max?(fma(z, r, fma(-mu, r, beta)))) in fp32.  The fp64 product of two fp32 numbers is exact, so
+    float32(float64 expression) is the fused multiply-add up to a 2^-29 double-rounding chance."""
+    z = np.asarray(z, np.float32).astype(np.float64)
+    r = np.asarray(rstd, np.float32).astype(np.float64)
+    sh = (np.asarray(beta, np.float32).astype(np.float64) - np.asarray(mean, np.float32).astype(np.float64) * r).astype(np.float32)
+    y = (z * r + sh.astype(np.float64)).astype(np.float32)
+    if relu:
+        y = np.maximum(y, np.float32(0))
+    return O.bf16_round(y.astype(np.float64))
+
+
 def bf16_ulp(b):
     """Spacing of bf16 numbers at |b| (8 significant bits)."""
     a = np.maximum(np.abs(b), 1e-30)
@@ -133,11 +146,8 @@ class InSitu(object):
         if a is not None:
             return a.astype(np.float64)
         kind = self._producer[name]
-        assert kind[0] == "layer", "only single conv-BN(-ReLU) activations can be virtual: %s" % name
-        y = self.bn_apply(name)
-        if kind[1]:
-            y = np.maximum(y, 0.0)
-        return self.q(y)
+        assert self.bf16 and kind[0] == "layer", "only single conv-BN(-ReLU) activations of the bf16 plan can be virtual: %s" % name
+        return staged_bn(self.t(name + ":z"), self.t(name + ":mean"), self.t(name + ":rstd"), self.P[name + "/BatchNorm/beta"], kind[1])
 
     def x_of(self, ins):
         xs = [self.act(i) for i in ins]
@@ -315,6 +325,9 @@ class FullSize(object):
         mu, r = self.stats(lname)
         y = (self.t(lname + ":z")[n, a:b].astype(np.float64) - mu) * r + self.beta(lname)
         return np.maximum(y, 0.0) if relu else y
+
+    def staged(self, lname, n, a, b, relu):
+        return staged_bn(self.t(lname + ":z")[n, a:b], self.t(lname + ":mean"), self.t(lname + ":rstd"), self.beta(lname), relu)
 
     def check_stats(self, lname):
         z = self.t(lname + ":z")

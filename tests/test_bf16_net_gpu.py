@@ -225,8 +225,50 @@ out["finite"] = bool(all(np.isfinite(v).all() for v in g.values()))
 sm = net.inference(None, data[:1])[0]
 out["softmax_rowsum_err"] = float(np.abs(sm.sum(-1) - 1.0).max())
 out["softmax_min"], out["softmax_max"] = float(sm.min()), float(sm.max())
+if len(sys.argv) > 2:   # a few rows of six layers' raw outputs of the LAST accumulate call, for the dispatch-consistency leg
+    zs = {}
+    for name in Z_LAYERS:
+        t = net.debug_tensor("UResNet/" + name + ":z")
+        r0 = t.shape[1] // 2 - 2
+        zs[name.replace("/", "|")] = t[0, r0:r0 + 4].copy()
+        zs["max|" + name.replace("/", "|")] = np.float32(np.abs(t).max())
+    np.savez(sys.argv[2], **zs)
 print("RESULT " + json.dumps(out))
 """
+Z_LAYERS = ["conv0", "resnet_module0/module1/resnet_conv1", "resnet_module2/module2/resnet_conv2", "deconv4",
+            "resnet_module9/module1/resnet_conv1", "conv2"]
+_FULL_CHILD = _FULL_CHILD.replace("Z_LAYERS", repr(Z_LAYERS))
+
+
+def _full_child(extra_env, npz=None):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _FULL_CHILD, root] + ([npz] if npz else []), env=dict(os.environ, **extra_env),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1100)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads([x for x in p.stdout.split("\n") if x.startswith("RESULT ")][-1][7:])
+
+
+def test_bf16_cfg5_full_size_dispatch_consistency(tmp_path):
+    """bf16 twin of test_configs_gpu.py::test_full_size_properties_and_dispatch_consistency at 256^3 x 2: the default plan
+    (input-stationary kernels, single-launch stride-2 scatter, 1x1 from global memory, channel-block kernels) against the
+    generic box kernels on the same weights and batch -- 524,288-workgroup XCD remaps, z-segment splitting and tensors above
+    2^31 bytes checked against an independent kernel set.  Loss within 2e-3 relative; the raw outputs z of six layers
+    (level 0 .. level 3, first and last layer) within 2^-6 of the tensor's max on the compared rows."""
+    a = _full_child({}, str(tmp_path / "fast.npz"))
+    b = _full_child({"URSN_B3CONV": "0", "URSN_B3WGRAD": "0", "URSN_BDECONV": "0", "URSN_BPW": "0", "URSN_BCB": "0"},
+                    str(tmp_path / "generic.npz"))
+    assert abs(a["loss"][0] - b["loss"][0]) <= 2e-3 * abs(b["loss"][0]), (a["loss"], b["loss"])
+    fa, fb = np.load(str(tmp_path / "fast.npz")), np.load(str(tmp_path / "generic.npz"))
+    for name in Z_LAYERS:
+        k = name.replace("/", "|")
+        scale = float(max(fa["max|" + k], fb["max|" + k]))
+        e = float(np.abs(fa[k].astype(np.float64) - fb[k]).max()) / scale
+        print("%s:z default vs generic kernels: max |diff| / max = %.2e" % (name, e))
+        assert e <= 2.0 ** -6, (name, e)
 
 
 def test_bf16_cfg5_full_size_properties():

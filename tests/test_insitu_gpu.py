@@ -60,13 +60,14 @@ def _full_size_checks(net, P, bf16, ns=5):
     q = fs.q
 
     def stored_or_bn(name, relu):
-        """rows of activation `name`; when the plan never writes it, what its consumers stage: q([relu](bn(z_stored)))"""
+        """rows of activation `name`; when the bf16 plan never writes it, what its consumers stage (_insitu.staged_bn)"""
         try:
             a = fs.t(name)
             return lambda n, lo, hi: a[n, lo:hi].astype(np.float64)
         except Exception as e:
             assert "not materialised" in str(e), e
-            return lambda n, lo, hi: q(fs.bn_value(name, n, lo, hi, relu))
+            assert bf16
+            return lambda n, lo, hi: fs.staged(name, n, lo, hi, relu)
 
     # A: module2/resnet_conv2 of the last decoder unit (8 -> 8), x = bn(z of resnet_conv1), g = the join's masked gradient
     c1, c2, sc = m9 + "/module2/resnet_conv1", m9 + "/module2/resnet_conv2", None

@@ -39,7 +39,19 @@ class ursn_conv_desc(C.Structure):
                 ("bs_z", C.c_void_p), ("bs_mean", C.c_void_p), ("bs_rstd", C.c_void_p), ("bs_beta", C.c_void_p),
                 ("bs_z2", C.c_void_p), ("bs_mean2", C.c_void_p), ("bs_rstd2", C.c_void_p), ("bs_mask", C.c_void_p),
                 ("bs_partial", C.c_void_p), ("bs_z_cstride", C.c_int32), ("bs_z2_cstride", C.c_int32),
-                ("bs_relu", C.c_int32), ("reserved2_", C.c_int32)]
+                ("bs_relu", C.c_int32), ("in_relu", C.c_int32)]
+
+
+class ursn_bn_bf16_desc(C.Structure):
+    _fields_ = [("voxels", C.c_int64), ("channels", C.c_int32), ("relu", C.c_int32),
+                ("z", C.c_void_p), ("z_cstride", C.c_int32), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("beta", C.c_void_p),
+                ("z2", C.c_void_p), ("z2_cstride", C.c_int32), ("mean2", C.c_void_p), ("rstd2", C.c_void_p), ("beta2", C.c_void_p),
+                ("res", C.c_void_p), ("res_cstride", C.c_int32),
+                ("y", C.c_void_p), ("y_cstride", C.c_int32), ("mask_out", C.c_void_p), ("cat", C.c_int32),
+                ("dy", C.c_void_p), ("dy_cstride", C.c_int32), ("dy2", C.c_void_p), ("dy2_cstride", C.c_int32),
+                ("mask", C.c_void_p), ("dz", C.c_void_p), ("dz_cstride", C.c_int32), ("dz2", C.c_void_p), ("dz2_cstride", C.c_int32),
+                ("dbeta", C.c_void_p), ("dbeta2", C.c_void_p), ("dres", C.c_void_p), ("dres_cstride", C.c_int32),
+                ("dres_accumulate", C.c_int32)]
 
 
 class ursn_prof_rec(C.Structure):
@@ -83,6 +95,9 @@ _SIGS = {
     "ursn_bn_backward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, C.c_int32, _P,
                                    C.c_size_t, _P]),
     "ursn_bn_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "ursn_bn_bf16_forward": (C.c_int, [C.POINTER(ursn_bn_bf16_desc), _P]),
+    "ursn_bn_bf16_backward": (C.c_int, [C.POINTER(ursn_bn_bf16_desc), _P, C.c_size_t, _P]),
+    "ursn_bn_bf16_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "ursn_softmax_ce": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int64, C.c_int32, _P, _P,
                                   C.POINTER(C.c_float), _P, C.c_size_t, _P]),
     "ursn_adam": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
@@ -91,7 +106,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS.keys())
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS
     if constexpr (AFF) {   // a thread always stages the same channel half (256 is even)
       const int ch = (CI == 16 ? (tid & 1) * 8 : 0) + j;
       asc[j] = a.aff_rstd[ch];
-      ash[j] = a.aff_beta[ch] - a.aff_mean[ch] * asc[j];
+      ash[j] = fmaf(-a.aff_mean[ch], asc[j], a.aff_beta[ch]);   // ONE rounding: the staged value is bf16(fma(z, r, fma(-mu, r, beta)))
     }
   }
   // shortcut plane (PW): interior voxels only, one piece per thread (32 x 8 tile), kept at the x plane's coordinates

@@ -1,0 +1,364 @@
+// bf16 3x3x3 stride-1 convolution with 16 / 32 contraction channels and 16 .. 64 produced channels (the residual units of
+// spatial levels 1 and 2 of an F = 8 network: lib/resnet_module.py:43-66 as built by lib/uresnet.py:56-64,95-100; forward
+// and data gradient) -- CHANNEL-BLOCK, INPUT-STATIONARY, Z-MARCHING on v_mfma_f32_32x32x16_bf16.
+//
+// The generic box kernel (bf16_conv.hip) stages a halo BOX per (box, channel chunk): 2.7x the input bytes of its 512 voxels,
+// one buffer only (two do not fit beside 55 KB of weights), and every tap re-reads its B operand from LDS -- 4-5x over its
+// roofline at 64^3 / 128^3.  Here a workgroup owns a 16 x 32 voxel column and walks it through z:
+//   * the packed weights of its block of 32 produced channels, all 27 taps (27 | 54 KB), are DMA'd into LDS ONCE;
+//   * every input plane (+ 1 halo ring in y / x: 1.2x) is DMA'd into LDS exactly once, into one of two slots, while the
+//     previous plane computes (global_load_lds, per-lane source address: padding voxels read a zero piece);
+//   * a staged input plane p feeds the THREE output planes p + 1, p, p - 1 (tap planes dz = -1, 0, +1): a B operand (32
+//     voxels x 16 channels of one in-plane tap) is read from LDS once and used by three MFMAs whose A operands are the three
+//     tap planes' weights; the three accumulator sets rotate roles (new / middle / complete) by unrolling the plane loop three
+//     times -- no register copies; a complete plane is rounded to bf16 once and stored;
+//   * MFMA rows = 32 produced channels, columns = 32 voxels of one x row; LDS images are piece-major ([16-byte channel piece]
+//     [y][x]) so that a lane's B address is a per-lane base plus a compile-time immediate and 16-lane groups read 256
+//     contiguous bytes (conflict-free); BatchNorm moments of the STORED tensor ride in the epilogue (per-lane pivots).
+// LDS reads per MFMA: (3 A + 4 B) KB per 12 MFMAs = 0.58 KB against 2 KB in the box kernel.
+#include <stdlib.h>
+
+#include "bf16_common.h"
+
+namespace {
+
+typedef float cb_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CI>
+struct CB {
+  static constexpr int CPV = CI / 8;                    // 16-byte pieces per voxel
+  static constexpr int KS = CI / 16;                    // k steps of 16 channels per tap
+  static constexpr int TY = 16, RPW = TY / 4;           // tile rows (32 columns); rows per wave
+  static constexpr int PX = 34, PY = TY + 2;
+  static constexpr int PVOX = PX * PY;                  // staged voxels per plane
+  static constexpr int PIECES = PVOX * CPV;
+  static constexpr int NST = (PIECES + 255) / 256;      // DMA instructions per thread per plane
+  static constexpr int PLANE = NST * 256 * 16;          // bytes of one slot (padded to whole wave instructions)
+  static constexpr int WBYTES = 27 * KS * 1024;         // one block of 32 produced channels: [tap][k step][lane][8] bf16
+  static constexpr int LDS = 2 * PLANE + WBYTES;
+};
+
+struct CBArgs {
+  const bf16_t* in;
+  const bf16_t* wp;        // [cout block][27 taps][KS][64 lanes][8], then one zero piece
+  const bf16_t* zero;      // 16 zero bytes in device memory (source of the padding pieces)
+  bf16_t* out;
+  double* stats_partial;   // [grid.y][stats_total][2][32] doubles or null
+  int N, Z, Y, X;
+  int in_cs, out_cs, Cout;
+  int zseg, nzseg, nty, ntx;
+  int accumulate;
+  int stats_total;
+};
+
+// One input plane (LDS slot L) against the three tap planes.  accN / accM / accO: the accumulator sets of output planes
+// p + 1 (first contribution: starts from zero), p, p - 1 (last contribution).  NEW / MID / OLD: which of them exist inside the
+// z segment (uniform; instantiated, not branched on, so that the MFMA stream stays one basic block).
+template <int CI, bool NEW, bool MID, bool OLD>
+__device__ __forceinline__ void cb_plane(const unsigned char* __restrict__ L, const unsigned char* __restrict__ W, unsigned boff,
+                                         unsigned aoff, cb_f32x16 (&accN)[CB<CI>::RPW], cb_f32x16 (&accM)[CB<CI>::RPW],
+                                         cb_f32x16 (&accO)[CB<CI>::RPW]) {
+  using G = CB<CI>;
+  constexpr int KS = G::KS, RPW = G::RPW;
+  if constexpr (NEW) {
+#pragma unroll
+    for (int nt = 0; nt < RPW; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accN[nt][i] = 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int dy = t / 3, dx = t % 3;   // in-plane tap (dy - 1, dx - 1)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      // tap plane tz of the weights multiplies input plane p into output plane p + 1 - tz
+      bfx8 A0, A1, A2;
+      if constexpr (NEW) A0 = *(const bfx8*)(W + aoff + ((0 * 9 + t) * KS + ks) * 1024);
+      if constexpr (MID) A1 = *(const bfx8*)(W + aoff + ((1 * 9 + t) * KS + ks) * 1024);
+      if constexpr (OLD) A2 = *(const bfx8*)(W + aoff + ((2 * 9 + t) * KS + ks) * 1024);
+#pragma unroll
+      for (int nt = 0; nt < RPW; ++nt) {
+        const bfx8 b = *(const bfx8*)(L + boff + (((2 * ks) * G::PY + nt + dy) * G::PX + dx) * 16);
+        if constexpr (NEW) accN[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, b, accN[nt], 0, 0, 0);
+        if constexpr (MID) accM[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, b, accM[nt], 0, 0, 0);
+        if constexpr (OLD) accO[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, b, accO[nt], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int CI, bool STATS>
+__global__ __launch_bounds__(256, 1) void bcbconv_kernel(CBArgs a) {
+  using G = CB<CI>;
+  constexpr int RPW = G::RPW, PX = G::PX, PY = G::PY, CPV = G::CPV;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* const W = lds + 2 * G::PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // neighbouring columns (shared halos) on one XCD's L2
+  const int tx = bid % a.ntx;
+  int r_ = bid / a.ntx;
+  const int ty = r_ % a.nty;
+  r_ /= a.nty;
+  const int zs = r_ % a.nzseg, n = r_ / a.nzseg;
+  const int x0 = tx * 32, y0 = ty * G::TY, z0 = zs * a.zseg;
+  const int z1 = z0 + a.zseg < a.Z ? z0 + a.zseg : a.Z;
+  const int cob = blockIdx.y;
+
+  // ---- weights of this block of produced channels: global (L2-resident) -> LDS, once ----
+  {
+    const bf16_t* wsrc = a.wp + (size_t)cob * (G::WBYTES / 2);
+    for (int base = 0; base < G::WBYTES / 16; base += 256)   // WBYTES / 16 pieces, a multiple of 64
+      if (base + wave * 64 < G::WBYTES / 16)
+        __builtin_amdgcn_global_load_lds((const void*)(wsrc + (size_t)(base + tid) * 8),
+                                         (__attribute__((address_space(3))) void*)(W + (size_t)(base + wave * 64) * 16), 16, 0, 0);
+  }
+
+  // ---- staging geometry of this thread's pieces of a plane (fixed over z): LDS piece index i * 256 + tid = (piece, y, x) ----
+  int srel[G::NST];
+  unsigned sval = 0;
+#pragma unroll
+  for (int i = 0; i < G::NST; ++i) {
+    const int idx = tid + 256 * i;
+    srel[i] = 0;
+    if (idx < G::PIECES) {
+      const int hp = idx / G::PVOX, vi = idx - hp * G::PVOX;
+      const int yy = vi / PX, xx = vi - yy * PX;
+      const int gy = y0 + yy - 1, gx = x0 + xx - 1;
+      if (gy >= 0 && gy < a.Y && gx >= 0 && gx < a.X) {
+        sval |= 1u << i;
+        srel[i] = (gy * a.X + gx) * a.in_cs + hp * 8;
+      }
+    }
+  }
+  const size_t plane_stride = (size_t)a.Y * a.X * a.in_cs;
+  auto stage = [&](int p, int slot) {   // plane p -> LDS slot; planes outside the tensor are zero planes
+    const bool pz = p >= 0 && p < a.Z;
+    const bf16_t* base = a.in + ((size_t)n * a.Z + (pz ? p : 0)) * plane_stride;
+    unsigned char* dst = lds + slot * G::PLANE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < G::NST; ++i) {
+      const bf16_t* src = (pz && ((sval >> i) & 1u)) ? base + srel[i] : a.zero;
+      __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+    }
+  };
+
+  // B operand of lane (column c, k half h): piece 2 ks + h of voxel (row RPW * wave + nt + dy, column c + dx) of the halo plane
+  const unsigned boff = (unsigned)(((h * PY + RPW * wave) * PX + c) * 16);
+  const unsigned aoff = (unsigned)(lane * 16);
+
+  cb_f32x16 accX[RPW], accY[RPW], accZ[RPW];
+  // per-lane BatchNorm moments: channels 8 q + 4 h + r (q = 0..3, r = 0..3) over this lane's voxels
+  float piv[16], s1[16], s2[16], nacc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) piv[k] = s1[k] = s2[k] = 0.f;
+
+  auto store_plane = [&](int q, cb_f32x16 (&acc)[RPW]) {   // output plane q is complete
+#pragma unroll
+    for (int nt = 0; nt < RPW; ++nt) {
+      const int gy = y0 + RPW * wave + nt, gx = x0 + c;
+      if (gy < a.Y && gx < a.X) {
+        bf16_t* ob = a.out + ((((size_t)n * a.Z + q) * a.Y + gy) * a.X + gx) * a.out_cs + cob * 32 + 4 * h;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {   // accumulator registers 4 qd .. 4 qd + 3 = rows (produced channels) 8 qd + 4 h + (0..3)
+          if (cob * 32 + 8 * qd + 4 * h < a.Cout) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = acc[nt][4 * qd + i];
+            u32x2* o = (u32x2*)(ob + 8 * qd);
+            if (a.accumulate) {
+              const u32x2 e = *o;
+              v[0] += __uint_as_float(e[0] << 16); v[1] += __uint_as_float(e[0] & 0xffff0000u);
+              v[2] += __uint_as_float(e[1] << 16); v[3] += __uint_as_float(e[1] & 0xffff0000u);
+            }
+            u32x2 pk;
+            pk[0] = pack_bf2(v[0], v[1]);
+            pk[1] = pack_bf2(v[2], v[3]);
+            *o = pk;
+            if constexpr (STATS) {   // moments of the STORED (rounded) tensor: that is what BatchNorm will normalise
+              const float rv[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
+                                   __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (nacc == 0.f) piv[4 * qd + k] = rv[k];
+                ursn_sacc(piv[4 * qd + k], s1[4 * qd + k], s2[4 * qd + k], rv[k]);
+              }
+            }
+          }
+        }
+        if constexpr (STATS) nacc += 1.f;
+      }
+    }
+  };
+
+  // one plane iteration: the next plane's DMA is issued first and lands during the MFMA block
+  auto iterate = [&](int p, int slot, cb_f32x16 (&aN)[RPW], cb_f32x16 (&aM)[RPW], cb_f32x16 (&aO)[RPW]) {
+    if (p < z1) stage(p + 1, slot ^ 1);
+    const unsigned char* L = lds + slot * G::PLANE;
+    const bool nw = p + 1 < z1, md = p >= z0 && p < z1, od = p - 1 >= z0;   // uniform
+    if (nw && md && od) cb_plane<CI, true, true, true>(L, W, boff, aoff, aN, aM, aO);
+    else if (nw && md) cb_plane<CI, true, true, false>(L, W, boff, aoff, aN, aM, aO);
+    else if (nw && od) cb_plane<CI, true, false, true>(L, W, boff, aoff, aN, aM, aO);
+    else if (md && od) cb_plane<CI, false, true, true>(L, W, boff, aoff, aN, aM, aO);
+    else if (nw) cb_plane<CI, true, false, false>(L, W, boff, aoff, aN, aM, aO);
+    else if (md) cb_plane<CI, false, true, false>(L, W, boff, aoff, aN, aM, aO);
+    else if (od) cb_plane<CI, false, false, true>(L, W, boff, aoff, aN, aM, aO);
+    if (od) store_plane(p - 1, aO);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next plane has landed (and this plane's stores are out)
+    __syncthreads();
+  };
+
+  stage(z0 - 1, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int slot = 0;
+  for (int p = z0 - 1; p <= z1;) {   // roles rotate: what was "new" becomes "middle", "middle" becomes "complete"
+    iterate(p, slot, accX, accY, accZ); slot ^= 1; if (++p > z1) break;
+    iterate(p, slot, accZ, accX, accY); slot ^= 1; if (++p > z1) break;
+    iterate(p, slot, accY, accZ, accX); slot ^= 1; ++p;
+  }
+
+  if constexpr (STATS) {
+    __shared__ double red[4][64];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      double u, w2;
+      ursn_sacc_final(piv[k], s1[k], s2[k], nacc, u, w2);
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
+      if (c == 0) {
+        const int ch = 8 * (k >> 2) + 4 * h + (k & 3);
+        red[wave][ch] = u;
+        red[wave][32 + ch] = w2;
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int ch = tid & 31;
+      double t = 0.0;
+      if (cob * 32 + ch < a.Cout) t = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      a.stats_partial[((size_t)cob * a.stats_total + blockIdx.x) * 64 + tid] = t;
+    }
+  }
+}
+
+struct CBPackArgs {
+  const float* w;
+  bf16_t* wp;
+  int tapw[27];   // weight tap index by displacement (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)
+  int Kw, Nw, w_tap_stride, w_sk, w_sn, ncob;
+};
+
+// fp32 master weights -> A operands [cout block][tap plane tz][in-plane tap][k step][lane][8]: lane (row = l & 31, k half
+// h = l >> 5) holds contraction channels 16 ks + 8 h + (0..7) of produced channel 32 cob + row.  Tap plane tz multiplies input
+// plane p into output plane p + 1 - tz, i.e. it is the tap with displacement dz = tz - 1 ... of the OUTPUT: out[z] =
+// sum_dz in[z + dz] W[dz]  =>  in[p] W[dz] lands in out[p - dz]: tz = dz + 1.
+template <int CI>
+__global__ void bcbconv_pack_kernel(CBPackArgs k) {
+  using G = CB<CI>;
+  const int total = k.ncob * 27 * G::KS * 512;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < 8) k.wp[total + e] = 0;   // the zero piece
+  if (e >= total) return;
+  const int j = e & 7, lane = (e >> 3) & 63;
+  int r = e >> 9;
+  const int ks = r % G::KS; r /= G::KS;
+  const int t = r % 9; r /= 9;
+  const int tz = r % 3, cob = r / 3;
+  const int co = cob * 32 + (lane & 31), ci = 16 * ks + 8 * (lane >> 5) + j;
+  float v = 0.f;
+  if (ci < k.Kw && co < k.Nw) {
+    const int tw = k.tapw[tz * 9 + t];
+    if (tw >= 0) v = k.w[(size_t)tw * k.w_tap_stride + (size_t)ci * k.w_sk + (size_t)co * k.w_sn];
+  }
+  k.wp[e] = f2bf(v);
+}
+
+struct CBPlan { int zseg, nzseg, nty, ntx, ncob, grid; };
+CBPlan cb_plan(const GatherGeom& g) {
+  CBPlan p;
+  const int Z = g.in_d[0], Y = g.in_d[1], X = g.in_d[2];
+  p.ntx = (X + 31) / 32;
+  p.nty = (Y + 15) / 16;
+  p.ncob = (g.Nn + 31) / 32;
+  // one workgroup per CU: segments as long as possible (two halo planes each) while every CU still gets a column
+  const int64_t cols = (int64_t)g.N * p.nty * p.ntx * p.ncob;
+  static const int64_t minwg = getenv("URSN_BCB_MINWG") ? atoi(getenv("URSN_BCB_MINWG")) : 256;   // A/B
+  int zseg = Z;
+  while (zseg > 4 && cols * ((Z + zseg - 1) / zseg) < minwg) zseg = (zseg + 1) / 2;
+  p.zseg = zseg;
+  p.nzseg = (Z + zseg - 1) / zseg;
+  p.grid = (int)((int64_t)g.N * p.nty * p.ntx * p.nzseg);
+  return p;
+}
+
+}  // namespace
+
+bool bcbconv_ok(const GatherGeom& g) {
+  static const bool off = getenv("URSN_BCB") && getenv("URSN_BCB")[0] == '0';
+  if (off) return false;
+  if ((g.K != 16 && g.K != 32) || g.Nn < 16 || (g.Nn & 7) || g.ntaps != 27 || (g.in_cs & 7) || (g.out_cs & 7)) return false;
+  if (b3conv_ok(g)) return false;   // 16 -> 16 and below: all weights in registers
+  for (int j = 0; j < 3; ++j) {
+    if (g.so[j] != 1 || g.si[j] != 1 || g.po[j] != 0) return false;
+    if (g.in_d[j] != g.out_d[j] || g.in_d[j] != g.q_d[j]) return false;
+  }
+  for (int t = 0; t < 27; ++t)
+    for (int j = 0; j < 3; ++j)
+      if (g.tap_d[t][j] < -1 || g.tap_d[t][j] > 1) return false;
+  if (g.in_d[0] < 2 || g.in_d[2] < 24 || g.in_d[1] < 12) return false;   // narrow volumes idle most of a 16 x 32 tile: box kernel
+  if ((int64_t)g.in_d[1] * g.in_d[2] * (g.in_cs > g.out_cs ? g.in_cs : g.out_cs) >= ((int64_t)1 << 31)) return false;   // int plane offsets
+  const CBPlan p = cb_plan(g);
+  return (int64_t)p.grid * p.ncob < ((int64_t)1 << 30);
+}
+
+size_t bcbconv_pack_elems(const GatherGeom& g) { return (size_t)((g.Nn + 31) / 32) * 27 * (g.K / 16) * 512 + 8; }
+int bcbconv_grid_blocks(const GatherGeom& g) { return cb_plan(g).grid; }   // rows of the statistics partials PER cout block
+size_t bcbconv_stats_scratch_doubles(const GatherGeom& g) { const CBPlan p = cb_plan(g); return (size_t)p.grid * p.ncob * 64; }
+
+template <int CI, bool STATS>
+static int cb_launch(const CBPlan& p, const CBArgs& a, hipStream_t s) {
+  auto kern = bcbconv_kernel<CI, STATS>;
+  static bool attr = false;
+  if (!attr) {
+    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CB<CI>::LDS));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.grid, p.ncob), dim3(256), CB<CI>::LDS, s, a);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_bcbconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
+                   double* stats_partial, hipStream_t s) {
+  URSN_REQUIRE(bcbconv_ok(g), "bf16 channel-block conv: unsupported geometry");
+  const CBPlan p = cb_plan(g);
+  CBPackArgs k;
+  k.w = w; k.wp = wpack; k.Kw = Kw > 0 ? Kw : g.K; k.Nw = Nw > 0 ? Nw : g.Nn;
+  k.w_tap_stride = g.w_tap_stride; k.w_sk = g.w_sk; k.w_sn = g.w_sn; k.ncob = p.ncob;
+  for (int i = 0; i < 27; ++i) k.tapw[i] = -1;
+  // in[q + d_t] W_t lands in out[q]: the staged plane p = q + dz feeds output plane p - dz, tap plane tz = dz + 1
+  for (int t = 0; t < g.ntaps; ++t) k.tapw[(g.tap_d[t][0] + 1) * 9 + (g.tap_d[t][1] + 1) * 3 + (g.tap_d[t][2] + 1)] = g.tap_w[t];
+  const int total = p.ncob * 27 * (g.K / 16) * 512;
+  if (g.K == 16) hipLaunchKernelGGL(bcbconv_pack_kernel<16>, dim3((total + 255) / 256), dim3(256), 0, s, k);
+  else hipLaunchKernelGGL(bcbconv_pack_kernel<32>, dim3((total + 255) / 256), dim3(256), 0, s, k);
+  URSN_HIP(hipGetLastError());
+  CBArgs a;
+  a.in = in; a.wp = wpack; a.zero = wpack + total; a.out = out; a.stats_partial = stats_partial;
+  a.N = g.N; a.Z = g.in_d[0]; a.Y = g.in_d[1]; a.X = g.in_d[2];
+  a.in_cs = g.in_cs; a.out_cs = g.out_cs; a.Cout = g.Nn;
+  a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
+  a.accumulate = g.accumulate;
+  a.stats_total = p.grid;
+  ursn_note_kernel(g.K == 16 ? "bcbconv_bf16<16>" : "bcbconv_bf16<32>");
+  if (g.K == 16) return stats_partial ? cb_launch<16, true>(p, a, s) : cb_launch<16, false>(p, a, s);
+  return stats_partial ? cb_launch<32, true>(p, a, s) : cb_launch<32, false>(p, a, s);
+}
+
+int bcbconv_stats_finalize(const GatherGeom& g, const double* partial, int64_t V, float eps, float* mean, float* rstd, hipStream_t s) {
+  const CBPlan p = cb_plan(g);
+  // partials [cout block][grid][2][32]: one finalise launch walks the blocks of 32 channels
+  return launch_bn_stats_final_blocked(partial, p.grid, g.Nn, 32, 32, (size_t)p.grid * 64, V, eps, mean, rstd, s);
+}

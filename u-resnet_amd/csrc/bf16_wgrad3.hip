@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void b3wgrad_kernel(W3Args a) {
     if constexpr (AFF) {
       const int ch = (K == 16 ? (tid & 1) * 8 : 0) + j;
       asc[j] = a.aff_rstd[ch];
-      ash[j] = a.aff_beta[ch] - a.aff_mean[ch] * asc[j];
+      ash[j] = fmaf(-a.aff_mean[ch], asc[j], a.aff_beta[ch]);   // as b3conv: bf16(fma(z, r, fma(-mu, r, beta)))
     }
   }
   auto load_x = [&](int p) {
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 3) void b3wgradz_kernel(W3Args a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     asc[j] = 1.f; ash[j] = 0.f;
-    if constexpr (AFF) { asc[j] = a.aff_rstd[j]; ash[j] = a.aff_beta[j] - a.aff_mean[j] * asc[j]; }
+    if constexpr (AFF) { asc[j] = a.aff_rstd[j]; ash[j] = fmaf(-a.aff_mean[j], asc[j], a.aff_beta[j]); }
   }
   u32x4 xs[2][G::NXS], ds[2];
   unsigned xin[2] = {0u, 0u};

@@ -1,5 +1,7 @@
 // Geometry construction (TF SAME semantics) and the op-level C-ABI.
+#include <dlfcn.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -20,6 +22,37 @@ void ursn_relabel_kernel(const char* name) { g_kernel = name; }
 long ursn_kernel_launch_count() { return g_kernel_launches; }
 extern "C" const char* ursn_last_kernel_name() { return g_kernel; }
 extern "C" int ursn_abi_version(void) { return URSN_ABI_VERSION; }
+
+// ---- roctx ranges ---------------------------------------------------------------------------------------------------
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+struct Roctx {
+  roctx_push_fn push = nullptr;
+  roctx_pop_fn pop = nullptr;
+  Roctx() {
+    const char* e = getenv("URSN_ROCTX");
+    if (!(e && e[0] == '1')) return;
+    void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { fprintf(stderr, "URSN_ROCTX=1 but no roctx library could be opened: %s\n", dlerror()); return; }
+    push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+    pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+    if (!push || !pop) { push = nullptr; pop = nullptr; fprintf(stderr, "URSN_ROCTX=1: roctxRangePushA / roctxRangePop not found\n"); }
+  }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+bool ursn_roctx_on() { return roctx().push != nullptr; }
+void ursn_roctx_push(const char* scope, int pass) {
+  if (!roctx().push) return;
+  static const char* pn[] = {"fwd", "dgrad", "wgrad", "bn_stats", "bn_act", "bn_bwd", "head"};
+  char buf[160];
+  snprintf(buf, sizeof(buf), "%s:%s", scope, (pass >= 0 && pass < 7) ? pn[pass] : "?");
+  roctx().push(buf);
+}
+void ursn_roctx_pop() { if (roctx().pop) roctx().pop(); }
 
 // ---------------------------------------------------------------------------------------------
 // Spatial axes are padded to 3 with a leading unit axis for 2-D problems.
@@ -297,15 +330,57 @@ static bf16_t* op_wpack(size_t elems) {
   }
   return buf;
 }
-static int bf16_conv_op(const ursn_conv_desc& d, ConvPass pass, const void* in, const float* w, void* out, int accumulate,
+// the stored weight tensor of a layer whose kernel-view channel counts are padded (cin = 1 read as an 8-channel piece)
+static void stored_weight_strides(GatherGeom& g, int Kr, int Nr) { g.w_tap_stride = Kr * Nr; g.w_sk = Nr; g.w_sn = 1; }
+
+static int bf16_conv_op(const ursn_conv_desc& d0, ConvPass pass, const void* in, const float* w, void* out, int accumulate,
                         double* stats_partial, size_t stats_bytes, float eps, float* mean, float* rstd, hipStream_t s) {
-  URSN_REQUIRE(!d.in_split && !d.pw_dy && !d.in_mean, "bf16 conv: split inputs / fused shortcut term / normalise-on-load are fp32-only");
+  ursn_conv_desc d = d0;
+  const bool scalar_in = d.cin == 1;   // conv0 of the plan: x is one fp32 channel per voxel
+  if (scalar_in) {
+    URSN_REQUIRE(pass == PASS_FWD && !d.transposed && d.k == 3 && d.stride == 1 && !d.in_mean && !d.in_split,
+                 "bf16 conv: the scalar fp32 input form (cin = 1) is the k3 s1 forward pass / weight gradient only");
+    d.cin = 8; d.in_cstride = 8;
+  }
+  if (d.in_split) {
+    URSN_REQUIRE(pass == PASS_DGRAD && d.in_split == 8 && d.cin == 16 && d.dx2 && d.pw_dy,
+                 "bf16 conv: a split tensor is supported as the two-tensor output (dx, dx2) of the 16 -> 8 data gradient with the fused shortcut term");
+    if (d.in_cstride <= 0) d.in_cstride = 8;
+  }
   GatherGeom g[8];
   const int n = build_geoms(d, pass, g);
   URSN_REQUIRE(n >= 1, "bf16 conv: bad descriptor");
   int64_t V = (int64_t)d.n;
   for (int j = 0; j < 3; ++j) V *= g[0].out_d[j];
   URSN_REQUIRE(!stats_partial || n == 1 || pass == PASS_FWD, "bf16 conv: statistics only on forward passes");
+  if (scalar_in || d.in_mean || d.pw_dy) {   // the fused forms of the input-stationary kernel (bf16_conv3.hip)
+    URSN_REQUIRE(n == 1 && b3conv_ok(g[0]), "bf16 conv: fused forms (cin = 1 / in_mean / pw_dy) need a 3-D k3 s1 layer with 8 / 16 channels");
+    bf16_t* wp = op_wpack(b3conv_pack_elems());
+    URSN_REQUIRE(wp, "bf16 conv: no memory for the packed weights");
+    g[0].accumulate = accumulate;
+    const int blocks = bconv_grid_blocks(g[0]);
+    URSN_REQUIRE(!stats_partial || bconv_stats_scratch_doubles(g[0]) * sizeof(double) <= stats_bytes, "bf16 conv: statistics scratch too small");
+    if (scalar_in) {
+      URSN_REQUIRE(g[0].K == 8, "bf16 conv: the scalar input form needs the 8-channel kernel view");
+      stored_weight_strides(g[0], 1, d.cout);
+      URSN_TRY(launch_b3conv(g[0], nullptr, w, 1, d.cout, wp, (bf16_t*)out, stats_partial, 0, blocks, s, nullptr, 0, nullptr, nullptr, nullptr,
+                             nullptr, 0, (const float*)in));
+    } else if (d.in_mean) {
+      URSN_REQUIRE(pass == PASS_FWD && d.in_rstd && d.in_beta && b3conv_aff_ok(g[0]) && !d.pw_dy,
+                   "bf16 conv: normalise-on-load needs a C -> C forward pass");
+      B3Affine af = {d.in_mean, d.in_rstd, d.in_beta, d.in_relu};
+      URSN_TRY(launch_b3conv(g[0], (const bf16_t*)in, w, 0, 0, wp, (bf16_t*)out, stats_partial, 0, blocks, s, nullptr, 0, nullptr, nullptr, &af));
+    } else {
+      URSN_REQUIRE(pass == PASS_DGRAD && d.pw_w && b3conv_pw_ok(g[0]), "bf16 conv: the fused shortcut term needs the data gradient of a 16 -> 8 layer");
+      const int pcs = d.pw_dy_cstride > 0 ? d.pw_dy_cstride : d.cout;
+      bf16_t* out2 = d.in_split ? (bf16_t*)d.dx2 : nullptr;
+      URSN_REQUIRE(!out2 || !accumulate, "bf16 conv: the two-tensor output overwrites");
+      URSN_TRY(launch_b3conv(g[0], (const bf16_t*)in, w, 0, 0, wp, (bf16_t*)out, nullptr, 0, 0, s, (const bf16_t*)d.pw_dy, pcs, d.pw_w, nullptr, nullptr,
+                             out2, out2 ? (d.in2_cstride > 0 ? d.in2_cstride : 8) : 0));
+    }
+    if (stats_partial) URSN_TRY(bconv_stats_finalize(g[0], stats_partial, blocks, V, eps, mean, rstd, s));
+    return 0;
+  }
   bool empty = false;
   for (int i = 0; i < n; ++i) empty = empty || g[i].ntaps == 0;
   if (empty && !accumulate) {   // 1x1 stride-2 data gradient: the voxels no output reads get a zero gradient
@@ -415,8 +490,13 @@ extern "C" int32_t ursn_conv_bs_blocks(const ursn_conv_desc* d) { return d ? til
 extern "C" size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d) {
   if (!d) return 0;
   GatherGeom g[8];
+  if (d->dtype == 1) {
+    ursn_conv_desc dd = *d;
+    if (dd.cin == 1) { dd.cin = 8; dd.in_cstride = 8; }
+    if (build_geoms(dd, PASS_WGRAD, g) != 1) return 0;
+    return bwgrad_scratch_bytes(g[0]) + 256;
+  }
   if (build_geoms(*d, PASS_WGRAD, g) != 1) return 0;
-  if (d->dtype == 1) return bwgrad_scratch_bytes(g[0]) + 256;
   size_t a = wgrad_plan(g[0]).scratch_bytes;
   size_t b = tiled_wgrad_supported(*d) ? tiled_wgrad_scratch_bytes(*d) : 0;
   size_t c = igemm_wgrad_scratch_bytes(*d);
@@ -468,8 +548,20 @@ extern "C" int ursn_conv_backward_weight(const ursn_conv_desc* d, const float* x
                                          void* scratch, size_t scratch_bytes, void* stream) {
   URSN_REQUIRE(d && x && dy && dw, "conv_backward_weight: null argument");
   if (d->dtype == 1) {
+    ursn_conv_desc dd = *d;
+    const bool scalar_in = dd.cin == 1;
+    if (scalar_in) { dd.cin = 8; dd.in_cstride = 8; }
     GatherGeom g[8];
-    URSN_REQUIRE(build_geoms(*d, PASS_WGRAD, g) == 1, "conv_backward_weight: bad descriptor");
+    URSN_REQUIRE(build_geoms(dd, PASS_WGRAD, g) == 1, "conv_backward_weight: bad descriptor");
+    if (scalar_in || dd.in_mean) {   // the fused forms of the z-marching kernel (bf16_wgrad3.hip)
+      URSN_REQUIRE(!dd.transposed && b3wgrad_ok(g[0]) && (!scalar_in || (b3wgrad_scalar_ok(g[0]) && !dd.in_mean)),
+                   "conv_backward_weight: bf16 fused forms (cin = 1 / in_mean) need a 3-D k3 s1 layer with 8 / 16 channels");
+      if (scalar_in)
+        return launch_b3wgrad(g[0], nullptr, (const bf16_t*)dy, dw, 1, dd.cout, scratch, scratch_bytes, (hipStream_t)stream, nullptr, x);
+      URSN_REQUIRE(dd.in_rstd && dd.in_beta, "conv_backward_weight: incomplete normalise-on-load arguments");
+      B3Affine af = {dd.in_mean, dd.in_rstd, dd.in_beta, dd.in_relu};
+      return launch_b3wgrad(g[0], (const bf16_t*)x, (const bf16_t*)dy, dw, 0, 0, scratch, scratch_bytes, (hipStream_t)stream, &af);
+    }
     const void* S = d->transposed ? (const void*)dy : (const void*)x;
     const void* Cq = d->transposed ? (const void*)x : (const void*)dy;
     return launch_bwgrad(g[0], (const bf16_t*)S, (const bf16_t*)Cq, dw, 0, 0, scratch, scratch_bytes, (hipStream_t)stream);
@@ -522,6 +614,47 @@ extern "C" int ursn_bn_backward(const float* dy, const float* y, const float* z,
   a.beta = nullptr;  // op-level API: mask from y
   a.V = voxels; a.C = channels; a.relu = relu; a.scratch = scratch;
   return launch_bn_bwd(a, s);
+}
+
+// ---- bf16 BatchNorm passes at op level ------------------------------------------------------------------------------
+extern "C" size_t ursn_bn_bf16_scratch_bytes(int64_t voxels, int32_t channels) { return bbn_scratch_bytes(voxels, channels) + 256; }
+
+extern "C" int ursn_bn_bf16_forward(const ursn_bn_bf16_desc* d, void* stream) {
+  URSN_REQUIRE(d && d->z && d->mean && d->rstd && d->beta && d->y, "bn_bf16_forward: null argument");
+  BBnActArgs a;
+  memset(&a, 0, sizeof(a));
+  const int C = d->channels;
+  a.z = (const bf16_t*)d->z; a.zcs = d->z_cstride > 0 ? d->z_cstride : C; a.mean = d->mean; a.rstd = d->rstd; a.beta = d->beta;
+  if (d->z2) {
+    URSN_REQUIRE(d->mean2 && d->rstd2 && d->beta2, "bn_bf16_forward: the second BatchNorm needs its statistics and beta");
+    a.z2 = (const bf16_t*)d->z2; a.z2cs = d->z2_cstride > 0 ? d->z2_cstride : C; a.mean2 = d->mean2; a.rstd2 = d->rstd2; a.beta2 = d->beta2;
+  }
+  if (d->res) { a.res = (const bf16_t*)d->res; a.rescs = d->res_cstride > 0 ? d->res_cstride : C; }
+  a.y = (bf16_t*)d->y; a.ycs = d->y_cstride > 0 ? d->y_cstride : (d->cat ? 2 * C : C);
+  a.V = d->voxels; a.C = C; a.relu = d->relu; a.mask_out = d->relu ? d->mask_out : nullptr; a.cat = d->cat;
+  return launch_bbn_act(a, (hipStream_t)stream);
+}
+
+extern "C" int ursn_bn_bf16_backward(const ursn_bn_bf16_desc* d, void* scratch, size_t scratch_bytes, void* stream) {
+  URSN_REQUIRE(d && d->dy && d->z && d->mean && d->rstd && d->dz && d->dbeta && scratch, "bn_bf16_backward: null argument");
+  URSN_REQUIRE(scratch_bytes >= bbn_scratch_bytes(d->voxels, d->channels), "bn_bf16_backward: scratch too small");
+  BBnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  const int C = d->channels;
+  a.dy = (const bf16_t*)d->dy; a.dycs = d->dy_cstride > 0 ? d->dy_cstride : C;
+  if (d->dy2) { a.dy2 = (const bf16_t*)d->dy2; a.dy2cs = d->dy2_cstride > 0 ? d->dy2_cstride : C; }
+  a.mask = d->relu ? d->mask : nullptr;
+  if (d->relu && !a.mask && d->y) { a.y = (const bf16_t*)d->y; a.ycs = d->y_cstride > 0 ? d->y_cstride : C; }
+  a.z = (const bf16_t*)d->z; a.zcs = d->z_cstride > 0 ? d->z_cstride : C; a.mean = d->mean; a.rstd = d->rstd; a.beta = d->beta;
+  a.dz = (bf16_t*)d->dz; a.dzcs = d->dz_cstride > 0 ? d->dz_cstride : C; a.dbeta = d->dbeta;
+  if (d->z2) {
+    URSN_REQUIRE(d->mean2 && d->rstd2 && d->dz2 && d->dbeta2, "bn_bf16_backward: the second BatchNorm needs statistics, dz2 and dbeta2");
+    a.z2 = (const bf16_t*)d->z2; a.z2cs = d->z2_cstride > 0 ? d->z2_cstride : C; a.mean2 = d->mean2; a.rstd2 = d->rstd2;
+    a.dz2 = (bf16_t*)d->dz2; a.dz2cs = d->dz2_cstride > 0 ? d->dz2_cstride : C; a.dbeta2 = d->dbeta2;
+  }
+  if (d->dres) { a.dres = (bf16_t*)d->dres; a.drescs = d->dres_cstride > 0 ? d->dres_cstride : C; a.dres_accumulate = d->dres_accumulate; }
+  a.V = d->voxels; a.C = C; a.Cw = C; a.relu = d->relu; a.scratch = scratch;
+  return launch_bbn_bwd(a, (hipStream_t)stream);
 }
 
 extern "C" int ursn_softmax_ce(const float* logits, const float* data, const float* label, const float* weight,

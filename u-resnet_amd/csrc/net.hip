@@ -380,8 +380,9 @@ hipEvent_t prof_event(ursn_net* n) {
   return n->ev_pool[n->ev_used++];
 }
 struct ProfScope {
-  ursn_net* n; hipStream_t s; int idx = -1;
+  ursn_net* n; hipStream_t s; int idx = -1; bool range = false;
   ProfScope(ursn_net* n_, hipStream_t s_, int layer, int pass, double flops, double bytes) : n(n_), s(s_) {
+    if (ursn_roctx_on()) { ursn_roctx_push(n->layers[layer].name.c_str(), pass); range = true; }
     if (!n->profile || n->prof.size() > 200000) return;
     ursn_net::ProfRec r{layer, pass, "", flops, bytes, prof_event(n), prof_event(n), ursn_kernel_launch_count(), 1};
     if (!r.e0 || !r.e1) return;
@@ -389,6 +390,7 @@ struct ProfScope {
     n->prof.push_back(r);
     idx = (int)n->prof.size() - 1;
   }
+  ~ProfScope() { if (range) ursn_roctx_pop(); }
   void done(const char* kernel) {
     if (idx < 0) return;
     n->prof[idx].kernel = kernel;
@@ -632,9 +634,11 @@ int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStre
     URSN_HIP(hipStreamWaitEvent(n->s2, e, 0));
     ws = n->s2;
   }
-  ProfScope ps(n, ws, li, 2, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
-  URSN_TRY(wgrad_dispatch(d, in.p, L.dz, n->grads + L.w_off, n->wg_scratch, n->wg_scratch_bytes, ws));
-  ps.done(ursn_last_kernel_name());
+  {
+    ProfScope ps(n, ws, li, 2, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
+    URSN_TRY(wgrad_dispatch(d, in.p, L.dz, n->grads + L.w_off, n->wg_scratch, n->wg_scratch_bytes, ws));
+    ps.done(ursn_last_kernel_name());
+  }
   if (dgrad_done_elsewhere) {  // keeps the per-layer roofline accounting (bench.py) complete: the work ran inside conv1's kernel
     ProfScope pd(n, s, li, 1, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
     pd.done("(fused into conv1 dgrad)");

@@ -348,9 +348,10 @@ hipEvent_t bprof_event(ursn_bnet* n) {
   return n->pev[n->pev_used++];
 }
 struct BProf {   // RAII: the conv paths return from several places
-  ursn_bnet* n; hipStream_t s; int idx = -1; const char* fixed;
+  ursn_bnet* n; hipStream_t s; int idx = -1; const char* fixed; bool range = false;
   BProf(ursn_bnet* n_, hipStream_t s_, int layer, int pass, double flops, double bytes, const char* name = nullptr)
       : n(n_), s(s_), fixed(name) {
+    if (ursn_roctx_on()) { ursn_roctx_push(n->layers[layer].name.c_str(), pass); range = true; }
     if (!n->profile || n->prof.size() > 200000) return;
     BProfRec r{layer, pass, "", flops, bytes, bprof_event(n), bprof_event(n), ursn_kernel_launch_count(), 1};
     if (!r.e0 || !r.e1) return;
@@ -359,6 +360,7 @@ struct BProf {   // RAII: the conv paths return from several places
     idx = (int)n->prof.size() - 1;
   }
   ~BProf() {
+    if (range) ursn_roctx_pop();
     if (idx < 0) return;
     BProfRec& r = n->prof[idx];
     r.kernel = fixed ? fixed : ursn_last_kernel_name();

@@ -47,6 +47,12 @@ __device__ __forceinline__ void ursn_sacc_final(float piv, float s1, float s2, f
 }
 #endif   // rename the last dispatch without counting a launch
 long ursn_kernel_launch_count();
+// roctx ranges (URSN_ROCTX=1): "UResNet/<scope>:<pass>" around every launch group, so rocprofv3 --marker-trace
+// --kernel-trace attributes kernels to layers (stands in for the per-layer report of lib/ssnet_trainval.py:207-227).
+// librocprofiler-sdk-roctx is opened at run time; without the switch these are two untaken branches.
+bool ursn_roctx_on();
+void ursn_roctx_push(const char* scope, int pass);
+void ursn_roctx_pop();
 
 #define URSN_HIP(expr)                                                                   \
   do {                                                                                   \
