@@ -36,6 +36,12 @@ CASES = [
     ("k3s1_64_32", 3, 1, (4, 6, 12), 64, 32, 3, 1, 0),
     ("k3s1_64_128", 3, 1, (4, 4, 8), 64, 128, 3, 1, 0),
     ("k3s1_24_40", 3, 1, (4, 6, 20), 24, 40, 3, 1, 0),          # channel counts that are only multiples of 8
+    # z-marching channel-block kernel (bf16_convcb.hip): 16 / 32 contraction channels, ragged 8 x 32 tiles, several z
+    # segments, two blocks of produced channels, a produced-channel count that is not a multiple of 32
+    ("k3s1_32_32_cb", 3, 2, (9, 21, 37), 32, 32, 3, 1, 0),
+    ("k3s1_32_16_cb", 3, 1, (12, 18, 40), 32, 16, 3, 1, 0),     # its data gradient contracts 16 channels
+    ("k3s1_32_64_cb", 3, 1, (5, 8, 32), 32, 64, 3, 1, 0),
+    ("k3s1_16_24_cb", 3, 2, (7, 11, 33), 16, 24, 3, 1, 0),
     ("k3s2_8_16", 3, 2, (8, 12, 36), 8, 16, 3, 2, 0),
     ("k3s2_odd", 3, 1, (7, 9, 21), 16, 32, 3, 2, 0),            # odd sizes: TF SAME pad-before = 1
     ("k1s1_16_8", 3, 2, (7, 9, 37), 16, 8, 1, 1, 0),            # 1x1 between 8 / 16 channels: operands straight from global memory
@@ -69,6 +75,9 @@ def test_bf16_conv_forward_data_and_weight_gradients(case):
     torch.cuda.synchronize()
     e = np.abs(yg.float().cpu().numpy() - y).max() / np.abs(y).max()
     assert e <= BF_TOL, ("forward", e)
+    if tag.endswith("_cb"):   # the dispatch really took the channel-block kernel
+        lib.ursn_last_kernel_name.restype = ctypes.c_char_p
+        assert lib.ursn_last_kernel_name().startswith(b"bcbconv_bf16"), lib.ursn_last_kernel_name()
     dxg = torch.full(x.shape, float("nan"), dtype=torch.bfloat16, device="cuda")
     _lib.check(lib.ursn_conv_backward_data(ctypes.byref(d), P(dyg), P(wg), P(dxg), 0, stream()))
     torch.cuda.synchronize()
@@ -88,7 +97,7 @@ def test_bf16_conv_forward_data_and_weight_gradients(case):
         assert rel_err(dwg.cpu().numpy(), rep * dw) < 2e-5, ("wgrad", rep)
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if not c[8]][:16], ids=[c[0] for c in CASES if not c[8]][:16])
+@pytest.mark.parametrize("case", [c for c in CASES if not c[8]][:20], ids=[c[0] for c in CASES if not c[8]][:20])
 def test_bf16_conv_forward_fused_statistics(case):
     tag, ndim, N, S, ci, co, k, st, tr = case
     lib = _lib.load()

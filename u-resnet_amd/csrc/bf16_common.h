@@ -84,6 +84,15 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
                   int pw_cs = 0, const float* pw_w = nullptr, const B3BnRed* bs = nullptr, const B3Affine* aff = nullptr,
                   bf16_t* out2 = nullptr, int out2_cs = 0,    // out2: produced channels 8..15 of a 16-channel result
                   const float* in_f32 = nullptr);             // in_f32 (K = 8): the input is one fp32 channel per voxel (`in` unused)
+// 3x3x3 stride-1 layers with 16 / 32 contraction channels (levels 1 / 2 of an F = 8 network): z-marching channel-block kernel,
+// weights resident in LDS (bf16_convcb.hip); launch_bconv and the bconv_* helpers dispatch
+bool bcbconv_ok(const GatherGeom& g);
+size_t bcbconv_pack_elems(const GatherGeom& g);
+int bcbconv_grid_blocks(const GatherGeom& g);
+size_t bcbconv_stats_scratch_doubles(const GatherGeom& g);
+int launch_bcbconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
+                   double* stats_partial, hipStream_t s);
+int bcbconv_stats_finalize(const GatherGeom& g, const double* partial, int64_t V, float eps, float* mean, float* rstd, hipStream_t s);
 // 1x1 stride-1 conv between 8 / 16 channel tensors, operands straight from global memory (bf16_pointwise.hip)
 bool bpw_ok(const GatherGeom& g);
 int bpw_grid_blocks(const GatherGeom& g);

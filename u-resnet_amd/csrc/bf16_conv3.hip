@@ -67,18 +67,24 @@ struct B3Args {
   const float* in_f32;
 };
 
-// PF2: two input planes in flight per workgroup (second register set).  A plane iteration is memory-latency-bound (its MFMA
-// block is ~0.5 us of ~5.8 us at 256^3), so the bytes in flight per CU, not the bandwidth, set the rate with one plane ahead.
-template <int CI, int CO, bool STATS, bool PW = false, int BS = 0, bool AFF = false, bool PF2 = false>
-__global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS == 0))) ? 3 : 2) void b3conv_kernel(B3Args a) {
+// DMA: the planes travel global -> LDS by LDS-DMA (global_load_lds, no staging registers) into a ring of FOUR slots, three
+// planes in flight per workgroup.  A plane iteration is memory-latency-bound (its MFMA block is ~0.14 of ~0.5 us per plane at
+// 256^3): with one register-staged plane ahead and three workgroups per CU only ~29 KB were in flight per CU, half of what
+// 31 GB/s per CU x ~2 us of loaded HBM latency asks for (measured 2.9 - 3.9 TB/s); a second register set cost a workgroup
+// per CU (URSN_B3CONV_PF2, round 2: slower).  The wait that ends an iteration counts this wave's own younger VM operations
+// exactly (its stores of the plane just completed, the DMAs of the planes behind the next one), so it never drains the ring.
+template <int CI, int CO, bool STATS, bool PW = false, int BS = 0, bool AFF = false, bool DMA = false>
+__global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ? 3 : 2) void b3conv_kernel(B3Args a) {
   static_assert(!AFF || (!PW && BS == 0), "normalise-on-load: plain forward instantiations");
-  static_assert(!PF2 || (!AFF && !PW), "two planes in flight: plain instantiations");
+  static_assert(!DMA || (!AFF && !PW && BS == 0), "LDS-DMA staging: plain instantiations (no transform on the way in)");
   using G = B3<CI, CO>;
   static_assert(!PW || (CI == 8 && CO == 16 && !STATS), "fused shortcut term: the 8 -> 16 data gradient");
   static_assert(BS == 0 || (CO == 8 && !STATS && !PW), "fused BatchNorm-backward reductions: data gradients producing 8 channels");
   constexpr int CPV = G::CPV, PX = G::PX, RPW = G::RPW, KS = G::KS, MT = G::MT, NCH = CO / 8;
-  constexpr int PWPLANE = PW ? G::PX * G::PY * 16 : 0, SLOT = G::PLANE + PWPLANE;   // the shortcut's plane rides behind the x plane
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SLOT];
+  // the shortcut's plane rides behind the x plane; DMA slots are whole wave instructions (64 pieces each) long
+  constexpr int PWPLANE = PW ? G::PX * G::PY * 16 : 0, SLOT = DMA ? G::NST * 4096 : G::PLANE + PWPLANE,
+                NSLOT = !DMA ? 2 : (CI == 16 && CO == 8) ? 3 : 4;   // 16 -> 8: 20 KB planes, three slots keep two workgroups per CU
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NSLOT * SLOT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   int bid = blockIdx.x;
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS
       }
     }
   }
-  u32x4 st[G::NST], st2[PF2 ? G::NST : 1], stpw = {0u, 0u, 0u, 0u};
+  u32x4 st[G::NST], stpw = {0u, 0u, 0u, 0u};
   unsigned stin = 0;   // AFF: which staged pieces are real voxels
   float asc[8], ash[8];
 #pragma unroll
@@ -131,6 +137,16 @@ __global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS
   const int pwy = tid >> 5, pwx = tid & 31;
   const bool pwok = PW && y0 + pwy < a.Y && x0 + pwx < a.X;
   const int pwrel = PW ? ((y0 + pwy) * a.X + x0 + pwx) * a.pw_cs : 0;
+  auto stage_dma = [&](int p, int slot) {   // plane p -> LDS slot, straight from global memory; padding reads the zero piece
+    const bool pz = p >= 0 && p < a.Z;
+    const bf16_t* base = a.in + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
+    unsigned char* dst = lds + slot * SLOT + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < G::NST; ++i) {
+      const bf16_t* src = (pz && ((sval >> i) & 1u)) ? base + srel[i] : a.wp + G::WPACK;
+      __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+    }
+  };
   auto stage_load = [&](int p, u32x4 (&arr)[G::NST]) {
     const bool pz = p >= 0 && p < a.Z;
     const bf16_t* base = a.in + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
@@ -209,6 +225,25 @@ __global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS
     }
   }
 
+  // DMA + accumulate: the old values of the plane that completes at the end of an iteration are requested at its start, in
+  // front of that iteration's DMA (read inside the epilogue they would make it wait for every DMA in flight)
+  u32x2 oldv[RPW][NCH];
+  auto old_load = [&](int q) {
+#pragma unroll
+    for (int nt = 0; nt < RPW; ++nt) {
+      const int gy = y0 + RPW * wave + nt, gx = x0 + c;
+#pragma unroll
+      for (int cb = 0; cb < NCH; ++cb) {
+        oldv[nt][cb] = (u32x2){0u, 0u};
+        if (gy < a.Y && gx < a.X) {
+          const size_t vox = (((size_t)n * a.Z + q) * a.Y + gy) * a.X + gx;
+          const bf16_t* o = a.out + vox * a.out_cs + h * 4 + 8 * cb;
+          if (CO == 16 && cb == 1 && a.out2) o = a.out2 + vox * a.out2_cs + h * 4;
+          oldv[nt][cb] = *(const u32x2*)o;
+        }
+      }
+    }
+  };
   auto plane_step = [&](int p, int slot) {
     const unsigned char* L = lds + slot * SLOT;
     // BS: everything the epilogue of output plane p - 1 reads is requested here, a whole MFMA block ahead (loaded inside the
@@ -277,7 +312,8 @@ __global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS
               if (cb == 1 && a.out2) o = (u32x2*)(a.out2 + ((((size_t)n * a.Z + q) * a.Y + gy) * a.X + gx) * a.out2_cs + h * 4);
             }
             if (a.accumulate) {
-              const u32x2 e = *o;
+              u32x2 e;
+              if constexpr (DMA) e = oldv[nt][cb]; else e = *o;
               v[0] += __uint_as_float(e[0] << 16); v[1] += __uint_as_float(e[0] & 0xffff0000u);
               v[2] += __uint_as_float(e[1] << 16); v[3] += __uint_as_float(e[1] & 0xffff0000u);
             }
@@ -327,9 +363,9 @@ __global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS
     }
   };
 
-  stage_load(z0 - 1, st);
-  stage_store(0, st);
-  if constexpr (!PF2) {
+  if constexpr (!DMA) {
+    stage_load(z0 - 1, st);
+    stage_store(0, st);
     __syncthreads();
     int slot = 0;
     for (int p = z0 - 1; p <= z1; ++p) {
@@ -340,23 +376,41 @@ __global__ __launch_bounds__(256, (!PF2 && (BS == 1 || (CI == 8 && CO == 8 && BS
       slot ^= 1;
     }
   } else {
-    // planes z0 and z0 + 1 are requested before the first MFMA; a register set is stored to LDS one iteration before its plane
-    // is needed and re-armed with the plane three ahead, so every load has two iterations to land
-    stage_load(z0, st);
-    stage_load(z0 + 1, st2);
-    __syncthreads();
-    int slot = 0, p = z0 - 1;
-    while (true) {
+    // VM operations retire in issue order.  At the end of iteration p this wave's youngest are: the stores of output plane
+    // p - 1 (kst: one per valid row and 8-channel group, none while that plane lies outside the segment), then the DMAs of
+    // planes p + 3 and p + 2 (NST each); everything older -- plane p + 1 included -- must have landed.
+    int krow = 0;
+#pragma unroll
+    for (int nt = 0; nt < RPW; ++nt) krow += (y0 + RPW * wave + nt < a.Y) ? NCH : 0;
+    auto wait_vm = [&](int keep) {   // s_waitcnt takes an immediate
+      switch (keep) {
+#define B3W(n_) case n_: asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory"); break;
+        B3W(0) B3W(1) B3W(2) B3W(3) B3W(4) B3W(5) B3W(6) B3W(7) B3W(8) B3W(9) B3W(10) B3W(11) B3W(12) B3W(13) B3W(14) B3W(15) B3W(16) B3W(17) B3W(18)
+#undef B3W
+        default: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;   // waits for more than necessary: always safe
+      }
+    };
+    constexpr int AHEAD = NSLOT - 1;   // planes in flight
+    stage_dma(z0 - 1, 0);
+    stage_dma(z0, 1);        // z1 >= z0 + 1: planes z0 - 1, z0, z0 + 1 always exist as iterations
+    if (AHEAD > 2) stage_dma(z0 + 1, 2);
+    wait_vm((AHEAD - 1) * G::NST);
+    __builtin_amdgcn_s_barrier();
+    int slot = 0;
+    for (int p = z0 - 1; p <= z1; ++p) {
+      if (a.accumulate && p - 1 >= z0 && p - 1 < z1) old_load(p - 1);   // older than this iteration's DMA
+      // the slot behind the ring held plane p - 1: every wave left it before the last barrier
+      if (p + AHEAD <= z1) stage_dma(p + AHEAD, slot == 0 ? NSLOT - 1 : slot - 1);
       plane_step(p, slot);
-      if (p < z1) { stage_store(slot ^ 1, st); if (p + 3 <= z1) stage_load(p + 3, st); }
-      __syncthreads();
-      slot ^= 1;
-      if (++p > z1) break;
-      plane_step(p, slot);
-      if (p < z1) { stage_store(slot ^ 1, st2); if (p + 3 <= z1) stage_load(p + 3, st2); }
-      __syncthreads();
-      slot ^= 1;
-      if (++p > z1) break;
+      if (p < z1) {
+        const int kst = (p - 1 >= z0 && p - 1 < z1) ? krow : 0;
+        int nd = 0;
+#pragma unroll
+        for (int k = 2; k <= AHEAD; ++k) nd += (p + k <= z1) ? 1 : 0;
+        wait_vm(kst + G::NST * nd);
+        __builtin_amdgcn_s_barrier();   // plane p + 1 is in LDS for every wave; nobody reads this slot any more
+      }
+      slot = slot + 1 == NSLOT ? 0 : slot + 1;
     }
   }
 
@@ -411,6 +465,7 @@ template <int CI, int CO>
 __global__ void b3conv_pack_kernel(B3PackArgs k) {
   using G = B3<CI, CO>;
   const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < 8) k.wp[G::WPACK + e] = 0;   // the zero piece the LDS-DMA staging pads with
   if (e >= G::WPACK) return;
   const int j = e & 7, lane = (e >> 3) & 63, mm = e >> 9, mt = mm % G::MT, m = mm / G::MT;
   const int row = lane & 31, h = lane >> 5;
@@ -545,9 +600,13 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
     URSN_HIP(hipGetLastError());
     return 0;
   }
-  // measured at cfg5: 75.5 images/s with two planes in flight (196-207 VGPRs, two workgroups per CU) against 77.6 with one
-  // (156-160 VGPRs, three per CU) on the same box: the extra registers cost more occupancy than the deeper prefetch returns
-  static const bool pf2 = getenv("URSN_B3CONV_PF2") && getenv("URSN_B3CONV_PF2")[0] == '1';
+  // LDS-DMA ring (three planes in flight) for every plain instantiation; URSN_B3CONV_DMA=0: one register-staged plane ahead.
+  // The scalar fp32 input of conv0 is converted on the way in and keeps the register path.
+  static const bool dma_off = getenv("URSN_B3CONV_DMA") && getenv("URSN_B3CONV_DMA")[0] == '0';
+  // measured (256^3 x 4 / 128^3 x 4, tools/bf16_op_bench.py): forward 8 -> 8 0.81 -> 0.70 ms, 16 -> 8 1.12 -> 1.04, 16 -> 16 0.254 ->
+  // 0.235; data gradients 16 -> 8 1.00 -> 0.96, 16 -> 16 0.244 -> 0.232, 8 -> 8 0.553 -> 0.572 (no statistics epilogue to hide
+  // behind: stays on the register path)
+  const bool pf2 = !dma_off && !in_f32 && !(g.K == 8 && g.Nn == 8 && !stats_partial);
 #define B3GO(ci, co, label)                                                                                              \
   if (g.K == ci && g.Nn == co) {                                                                                          \
     hipLaunchKernelGGL((b3conv_pack_kernel<ci, co>), dim3((B3<ci, co>::WPACK + 255) / 256), dim3(256), 0, s, k);          \

@@ -4,18 +4,18 @@
 //
 // The generic box kernel (bf16_conv.hip) stages a halo BOX per (box, channel chunk): 2.7x the input bytes of its 512 voxels,
 // one buffer only (two do not fit beside 55 KB of weights), and every tap re-reads its B operand from LDS -- 4-5x over its
-// roofline at 64^3 / 128^3.  Here a workgroup owns a 16 x 32 voxel column and walks it through z:
+// roofline at 64^3 / 128^3.  Here a workgroup owns an 8 x 32 voxel column and walks it through z:
 //   * the packed weights of its block of 32 produced channels, all 27 taps (27 | 54 KB), are DMA'd into LDS ONCE;
-//   * every input plane (+ 1 halo ring in y / x: 1.2x) is DMA'd into LDS exactly once, into one of two slots, while the
+//   * every input plane (+ 1 halo ring in y / x: 1.33x) is DMA'd into LDS exactly once, into one of two slots, while the
 //     previous plane computes (global_load_lds, per-lane source address: padding voxels read a zero piece);
 //   * a staged input plane p feeds the THREE output planes p + 1, p, p - 1 (tap planes dz = -1, 0, +1): a B operand (32
 //     voxels x 16 channels of one in-plane tap) is read from LDS once and used by three MFMAs whose A operands are the three
-//     tap planes' weights; the three accumulator sets rotate roles (new / middle / complete) by unrolling the plane loop three
-//     times -- no register copies; a complete plane is rounded to bf16 once and stored;
+//     tap planes' weights; after a plane the complete accumulator set is rounded to bf16 once and stored and the other two
+//     move up one role (64 register copies per wave against 108 MFMAs: hidden);
 //   * MFMA rows = 32 produced channels, columns = 32 voxels of one x row; LDS images are piece-major ([16-byte channel piece]
 //     [y][x]) so that a lane's B address is a per-lane base plus a compile-time immediate and 16-lane groups read 256
 //     contiguous bytes (conflict-free); BatchNorm moments of the STORED tensor ride in the epilogue (per-lane pivots).
-// LDS reads per MFMA: (3 A + 4 B) KB per 12 MFMAs = 0.58 KB against 2 KB in the box kernel.
+// LDS reads per MFMA: (3 A + 2 B) KB per 6 MFMAs = 0.83 KB against 2 KB in the box kernel.
 #include <stdlib.h>
 
 #include "bf16_common.h"
@@ -28,7 +28,7 @@ template <int CI>
 struct CB {
   static constexpr int CPV = CI / 8;                    // 16-byte pieces per voxel
   static constexpr int KS = CI / 16;                    // k steps of 16 channels per tap
-  static constexpr int TY = 16, RPW = TY / 4;           // tile rows (32 columns); rows per wave
+  static constexpr int TY = 8, RPW = TY / 4;            // tile rows (32 columns); rows per wave
   static constexpr int PX = 34, PY = TY + 2;
   static constexpr int PVOX = PX * PY;                  // staged voxels per plane
   static constexpr int PIECES = PVOX * CPV;
@@ -66,24 +66,36 @@ __device__ __forceinline__ void cb_plane(const unsigned char* __restrict__ L, co
 #pragma unroll
       for (int i = 0; i < 16; ++i) accN[nt][i] = 0.f;
   }
-#pragma unroll
-  for (int t = 0; t < 9; ++t) {
+  // in-plane taps, software-pipelined by hand: the operands of tap t + 1 are requested before the MFMAs of tap t are issued
+  // (left to itself the scheduler hoists every LDS read of the unrolled plane to the top: 500 registers of fragments)
+  bfx8 A[2][3][KS], B[2][KS][RPW];
+  auto fetch = [&](int buf, int t) {
     const int dy = t / 3, dx = t % 3;   // in-plane tap (dy - 1, dx - 1)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       // tap plane tz of the weights multiplies input plane p into output plane p + 1 - tz
-      bfx8 A0, A1, A2;
-      if constexpr (NEW) A0 = *(const bfx8*)(W + aoff + ((0 * 9 + t) * KS + ks) * 1024);
-      if constexpr (MID) A1 = *(const bfx8*)(W + aoff + ((1 * 9 + t) * KS + ks) * 1024);
-      if constexpr (OLD) A2 = *(const bfx8*)(W + aoff + ((2 * 9 + t) * KS + ks) * 1024);
+      if constexpr (NEW) A[buf][0][ks] = *(const bfx8*)(W + aoff + ((0 * 9 + t) * KS + ks) * 1024);
+      if constexpr (MID) A[buf][1][ks] = *(const bfx8*)(W + aoff + ((1 * 9 + t) * KS + ks) * 1024);
+      if constexpr (OLD) A[buf][2][ks] = *(const bfx8*)(W + aoff + ((2 * 9 + t) * KS + ks) * 1024);
+#pragma unroll
+      for (int nt = 0; nt < RPW; ++nt) B[buf][ks][nt] = *(const bfx8*)(L + boff + (((2 * ks) * G::PY + nt + dy) * G::PX + dx) * 16);
+    }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < 9) fetch(cur ^ 1, t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int nt = 0; nt < RPW; ++nt) {
-        const bfx8 b = *(const bfx8*)(L + boff + (((2 * ks) * G::PY + nt + dy) * G::PX + dx) * 16);
-        if constexpr (NEW) accN[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, b, accN[nt], 0, 0, 0);
-        if constexpr (MID) accM[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, b, accM[nt], 0, 0, 0);
-        if constexpr (OLD) accO[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, b, accO[nt], 0, 0, 0);
+        if constexpr (NEW) accN[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur][0][ks], B[cur][ks][nt], accN[nt], 0, 0, 0);
+        if constexpr (MID) accM[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur][1][ks], B[cur][ks][nt], accM[nt], 0, 0, 0);
+        if constexpr (OLD) accO[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur][2][ks], B[cur][ks][nt], accO[nt], 0, 0, 0);
       }
-    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -149,76 +161,122 @@ __global__ __launch_bounds__(256, 1) void bcbconv_kernel(CBArgs a) {
   const unsigned boff = (unsigned)(((h * PY + RPW * wave) * PX + c) * 16);
   const unsigned aoff = (unsigned)(lane * 16);
 
-  cb_f32x16 accX[RPW], accY[RPW], accZ[RPW];
+  cb_f32x16 accN[RPW], accM[RPW], accO[RPW];   // output planes p + 1 (new), p (middle), p - 1 (complete after this plane)
+#pragma unroll
+  for (int nt = 0; nt < RPW; ++nt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accN[nt][i] = accM[nt][i] = accO[nt][i] = 0.f;
   // per-lane BatchNorm moments: channels 8 q + 4 h + r (q = 0..3, r = 0..3) over this lane's voxels
   float piv[16], s1[16], s2[16], nacc = 0.f;
 #pragma unroll
   for (int k = 0; k < 16; ++k) piv[k] = s1[k] = s2[k] = 0.f;
 
-  auto store_plane = [&](int q, cb_f32x16 (&acc)[RPW]) {   // output plane q is complete
+  // ---- epilogue geometry (fixed over z): this lane's voxel of row nt, its four 8-byte channel groups 8 qd + 4 h ----
+  int orel[RPW];
+  unsigned omask = 0;   // bit nt * 4 + qd: the lane stores that group
+#pragma unroll
+  for (int nt = 0; nt < RPW; ++nt) {
+    const int gy = y0 + RPW * wave + nt, gx = x0 + c;
+    orel[nt] = 0;
+    if (gy < a.Y && gx < a.X) {
+      orel[nt] = (gy * a.X + gx) * a.out_cs + cob * 32 + 4 * h;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+        if (cob * 32 + 8 * qd + 4 * h < a.Cout) omask |= 1u << (nt * 4 + qd);
+    }
+  }
+  const size_t oplane = (size_t)a.Y * a.X * a.out_cs;
+  // A complete plane is rounded to bf16 right after its last MFMA (pend) but STORED at the start of the next plane
+  // iteration, in front of that iteration's DMA: the wait that ends an iteration then finds the stores a whole MFMA block old
+  // instead of paying the HBM write latency every plane.  accumulate: the old values are requested a plane ahead.
+  u32x2 pend[RPW][4], oldv[RPW][4];
+  int pend_q = -1;
+  auto flush = [&]() {   // store the pending plane, take the moments of what was stored (what BatchNorm will normalise)
+    if (pend_q < 0) return;
+    bf16_t* ob = a.out + ((size_t)n * a.Z + pend_q) * oplane;
 #pragma unroll
     for (int nt = 0; nt < RPW; ++nt) {
-      const int gy = y0 + RPW * wave + nt, gx = x0 + c;
-      if (gy < a.Y && gx < a.X) {
-        bf16_t* ob = a.out + ((((size_t)n * a.Z + q) * a.Y + gy) * a.X + gx) * a.out_cs + cob * 32 + 4 * h;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {   // accumulator registers 4 qd .. 4 qd + 3 = rows (produced channels) 8 qd + 4 h + (0..3)
-          if (cob * 32 + 8 * qd + 4 * h < a.Cout) {
-            float v[4];
+      for (int qd = 0; qd < 4; ++qd) {
+        if ((omask >> (nt * 4 + qd)) & 1u) {
+          const u32x2 pk = pend[nt][qd];
+          *(u32x2*)(ob + orel[nt] + 8 * qd) = pk;
+          if constexpr (STATS) {
+            const float rv[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
+                                 __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = acc[nt][4 * qd + i];
-            u32x2* o = (u32x2*)(ob + 8 * qd);
-            if (a.accumulate) {
-              const u32x2 e = *o;
-              v[0] += __uint_as_float(e[0] << 16); v[1] += __uint_as_float(e[0] & 0xffff0000u);
-              v[2] += __uint_as_float(e[1] << 16); v[3] += __uint_as_float(e[1] & 0xffff0000u);
-            }
-            u32x2 pk;
-            pk[0] = pack_bf2(v[0], v[1]);
-            pk[1] = pack_bf2(v[2], v[3]);
-            *o = pk;
-            if constexpr (STATS) {   // moments of the STORED (rounded) tensor: that is what BatchNorm will normalise
-              const float rv[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
-                                   __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                if (nacc == 0.f) piv[4 * qd + k] = rv[k];
-                ursn_sacc(piv[4 * qd + k], s1[4 * qd + k], s2[4 * qd + k], rv[k]);
-              }
+            for (int k = 0; k < 4; ++k) {
+              if (nacc == 0.f) piv[4 * qd + k] = rv[k];
+              ursn_sacc(piv[4 * qd + k], s1[4 * qd + k], s2[4 * qd + k], rv[k]);
             }
           }
         }
-        if constexpr (STATS) nacc += 1.f;
       }
+      if constexpr (STATS) { if ((omask >> (nt * 4)) & 15u) nacc += 1.f; }
     }
+    pend_q = -1;
   };
-
-  // one plane iteration: the next plane's DMA is issued first and lands during the MFMA block
-  auto iterate = [&](int p, int slot, cb_f32x16 (&aN)[RPW], cb_f32x16 (&aM)[RPW], cb_f32x16 (&aO)[RPW]) {
-    if (p < z1) stage(p + 1, slot ^ 1);
-    const unsigned char* L = lds + slot * G::PLANE;
-    const bool nw = p + 1 < z1, md = p >= z0 && p < z1, od = p - 1 >= z0;   // uniform
-    if (nw && md && od) cb_plane<CI, true, true, true>(L, W, boff, aoff, aN, aM, aO);
-    else if (nw && md) cb_plane<CI, true, true, false>(L, W, boff, aoff, aN, aM, aO);
-    else if (nw && od) cb_plane<CI, true, false, true>(L, W, boff, aoff, aN, aM, aO);
-    else if (md && od) cb_plane<CI, false, true, true>(L, W, boff, aoff, aN, aM, aO);
-    else if (nw) cb_plane<CI, true, false, false>(L, W, boff, aoff, aN, aM, aO);
-    else if (md) cb_plane<CI, false, true, false>(L, W, boff, aoff, aN, aM, aO);
-    else if (od) cb_plane<CI, false, false, true>(L, W, boff, aoff, aN, aM, aO);
-    if (od) store_plane(p - 1, aO);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next plane has landed (and this plane's stores are out)
+  auto prefetch_old = [&](int q) {
+    if (!a.accumulate) return;
+    const bf16_t* ob = a.out + ((size_t)n * a.Z + q) * oplane;
+#pragma unroll
+    for (int nt = 0; nt < RPW; ++nt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        oldv[nt][qd] = (u32x2){0u, 0u};
+        if ((omask >> (nt * 4 + qd)) & 1u) oldv[nt][qd] = *(const u32x2*)(ob + orel[nt] + 8 * qd);
+      }
+  };
+  auto finish = [&](int q, cb_f32x16 (&acc)[RPW]) {   // output plane q has seen its three input planes
+#pragma unroll
+    for (int nt = 0; nt < RPW; ++nt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {   // accumulator registers 4 qd .. 4 qd + 3 = rows (produced channels) 8 qd + 4 h + (0..3)
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[nt][4 * qd + i];
+        if (a.accumulate) {
+          const u32x2 e = oldv[nt][qd];
+          v[0] += __uint_as_float(e[0] << 16); v[1] += __uint_as_float(e[0] & 0xffff0000u);
+          v[2] += __uint_as_float(e[1] << 16); v[3] += __uint_as_float(e[1] & 0xffff0000u);
+        }
+        pend[nt][qd][0] = pack_bf2(v[0], v[1]);
+        pend[nt][qd][1] = pack_bf2(v[2], v[3]);
+      }
+    pend_q = q;
+  };
+  auto plane_done = [&]() {   // the next plane has landed; every wave is done with this slot
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
 
+  // Input plane p meets tap plane tz in output plane p + 1 - tz.  First plane (z0 - 1): only the "new" set; planes z0 .. z1 - 1:
+  // all three (the sets that fall outside the segment at its two ends collect values that are never stored); plane z1: only
+  // the set it completes.
   stage(z0 - 1, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int slot = 0;
-  for (int p = z0 - 1; p <= z1;) {   // roles rotate: what was "new" becomes "middle", "middle" becomes "complete"
-    iterate(p, slot, accX, accY, accZ); slot ^= 1; if (++p > z1) break;
-    iterate(p, slot, accZ, accX, accY); slot ^= 1; if (++p > z1) break;
-    iterate(p, slot, accY, accZ, accX); slot ^= 1; ++p;
+  plane_done();
+  stage(z0, 1);
+  cb_plane<CI, true, false, false>(lds, W, boff, aoff, accN, accM, accO);
+#pragma unroll
+  for (int nt = 0; nt < RPW; ++nt) accM[nt] = accN[nt];
+  plane_done();
+  int slot = 1;
+  for (int p = z0; p < z1; ++p) {
+    flush();                                 // plane p - 2
+    if (p - 1 >= z0) prefetch_old(p - 1);    // completes at the end of this iteration
+    stage(p + 1, slot ^ 1);                  // lands during the MFMA block
+    cb_plane<CI, true, true, true>(lds + slot * G::PLANE, W, boff, aoff, accN, accM, accO);
+    if (p - 1 >= z0) finish(p - 1, accO);
+#pragma unroll
+    for (int nt = 0; nt < RPW; ++nt) { accO[nt] = accM[nt]; accM[nt] = accN[nt]; }
+    plane_done();
+    slot ^= 1;
   }
+  flush();
+  prefetch_old(z1 - 1);
+  cb_plane<CI, false, false, true>(lds + slot * G::PLANE, W, boff, aoff, accN, accM, accO);
+  finish(z1 - 1, accO);
+  flush();
 
   if constexpr (STATS) {
     __shared__ double red[4][64];
@@ -281,7 +339,7 @@ CBPlan cb_plan(const GatherGeom& g) {
   CBPlan p;
   const int Z = g.in_d[0], Y = g.in_d[1], X = g.in_d[2];
   p.ntx = (X + 31) / 32;
-  p.nty = (Y + 15) / 16;
+  p.nty = (Y + 7) / 8;
   p.ncob = (g.Nn + 31) / 32;
   // one workgroup per CU: segments as long as possible (two halo planes each) while every CU still gets a column
   const int64_t cols = (int64_t)g.N * p.nty * p.ntx * p.ncob;
@@ -308,7 +366,7 @@ bool bcbconv_ok(const GatherGeom& g) {
   for (int t = 0; t < 27; ++t)
     for (int j = 0; j < 3; ++j)
       if (g.tap_d[t][j] < -1 || g.tap_d[t][j] > 1) return false;
-  if (g.in_d[0] < 2 || g.in_d[2] < 24 || g.in_d[1] < 12) return false;   // narrow volumes idle most of a 16 x 32 tile: box kernel
+  if (g.in_d[0] < 2 || g.in_d[2] < 24 || g.in_d[1] < 6) return false;   // narrow volumes idle most of an 8 x 32 tile: box kernel
   if ((int64_t)g.in_d[1] * g.in_d[2] * (g.in_cs > g.out_cs ? g.in_cs : g.out_cs) >= ((int64_t)1 << 31)) return false;   // int plane offsets
   const CBPlan p = cb_plan(g);
   return (int64_t)p.grid * p.ncob < ((int64_t)1 << 30);
