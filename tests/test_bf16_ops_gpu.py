@@ -36,6 +36,8 @@ CASES = [
     ("k3s1_64_32", 3, 1, (4, 6, 12), 64, 32, 3, 1, 0),
     ("k3s1_64_128", 3, 1, (4, 4, 8), 64, 128, 3, 1, 0),
     ("k3s1_24_40", 3, 1, (4, 6, 20), 24, 40, 3, 1, 0),          # channel counts that are only multiples of 8
+    ("k3s1_64_64_x8", 3, 2, (8, 8, 8), 64, 64, 3, 1, 0),        # 8-wide level: MFMA tile columns fold over two rows (8-wide boxes)
+    ("k3s1_32_64_x16", 3, 1, (10, 12, 16), 32, 64, 3, 1, 0),    # 16-wide level: 16-wide boxes, ragged in z / y
     # z-marching channel-block kernel (bf16_convcb.hip): 16 / 32 contraction channels, ragged 8 x 32 tiles, several z
     # segments, two blocks of produced channels, a produced-channel count that is not a multiple of 32
     ("k3s1_32_32_cb", 3, 2, (9, 21, 37), 32, 32, 3, 1, 0),
@@ -97,7 +99,7 @@ def test_bf16_conv_forward_data_and_weight_gradients(case):
         assert rel_err(dwg.cpu().numpy(), rep * dw) < 2e-5, ("wgrad", rep)
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if not c[8]][:20], ids=[c[0] for c in CASES if not c[8]][:20])
+@pytest.mark.parametrize("case", [c for c in CASES if not c[8]][:22], ids=[c[0] for c in CASES if not c[8]][:22])
 def test_bf16_conv_forward_fused_statistics(case):
     tag, ndim, N, S, ci, co, k, st, tr = case
     lib = _lib.load()

@@ -54,7 +54,7 @@ def _full_size_checks(net, P, bf16, ns=5):
     """Level-0 / level-1 layers of a full-size step: 8 -> 8 with a normalised-on-load input (bf16) and the join's gradient,
     conv1 (ReLU mask), the split-input 16 -> 8 pair of the first decoder unit at level 0 with the fused shortcut term, the
     16 -> 16 layer of level 1 behind an identity shortcut, and the last transposed conv."""
-    fs = FullSize(net, P, bf16)
+    fs = FullSize(net, P, bf16, workers=14)
     m9, m8 = U + "resnet_module%d" % (ns + 4), U + "resnet_module%d" % (ns + 3)
     dec = U + "deconv%d" % (ns - 1)
     q = fs.q
@@ -96,7 +96,7 @@ def _full_size_checks(net, P, bf16, ns=5):
     fs.check_forward(U + "conv1", "conv", x_b)
     fs.check_data_gradient(U + "conv1:grad", gc1, [(U + "conv2", "conv", slice(None))])
     fs.check_bn_backward(U + "conv1", lambda n, a, b: gc1[n, a:b].astype(np.float64) * (a1(n, a, b) > 0))
-    fs.check_weight_gradient(U + "conv1", "conv", x_b)
+    # (its weight gradient runs the same kernel instantiation as module2/resnet_conv1's above: not repeated at full size)
     fs.check_data_gradient(m9 + "/module2:grad", gout, [(U + "conv1", "conv", slice(None))])
     fs.drop(U + "conv1:z", U + "conv1:dz", U + "conv1:grad", U + "conv1", U + "conv2:dz", m9 + "/module2", m9 + "/module2:grad")
 

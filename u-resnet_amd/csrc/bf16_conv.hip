@@ -4,7 +4,7 @@
 // (k3 s1, k3 s2, 1x1 s1|s2, transposed conv and scatter-type data gradients by output-parity class: lib/uresnet.py:37-121,
 // lib/resnet_module.py:25-66).  bf16 operands, fp32 accumulation on v_mfma_f32_16x16x32_bf16.
 //
-// bconv: a workgroup (4 waves) owns a box of q points (BZ x BY x BX, BX a multiple of 16) and one block of <= 32 produced
+// bconv: a workgroup (4 waves) owns a box of q points (BZ x BY x BX, BX in {8, 16, 32}) and one block of <= 32 produced
 // channels.  Per chunk of <= 32 contraction channels the input halo box is staged ONCE in LDS as [voxel][channel] (NDHWC
 // order: a lane's MFMA B operand = 8 consecutive channels of one tap of one voxel = one ds_read_b128) together with the
 // chunk's weights in A-operand order; every tap re-reads the box from LDS, never from HBM.  D = W^T (M = produced
@@ -64,7 +64,6 @@ __global__ __launch_bounds__(256) void bconv_kernel(BConvArgs a) {
   const int plane = a.hb[1] * a.hb[2] * cpb;                     // real pieces per plane
   const int wpieces = a.nj * COT * 64;
   const int co0 = blockIdx.y * a.cob;
-  const int xr = a.bq[2] >> 4;
   unsigned char* wbase = smem + (size_t)a.nbuf * a.stage_bytes;
 
   __shared__ int toff_s[BCONV_MAX_SLOTS];   // tap / channel-block offsets of the k slots, read per lane (slot 4 j + g)
@@ -96,7 +95,9 @@ __global__ __launch_bounds__(256) void bconv_kernel(BConvArgs a) {
   int qrel[VT];    // qz | qy << 8 | qx << 16 inside the box
 #pragma unroll
   for (int vt = 0; vt < VT; ++vt) {
-    const int tl = wave * VT + vt, row = tl / xr, qx = (tl % xr) * 16 + m;
+    // the 16 columns of an MFMA tile are 16 consecutive q points of the box in (z, y, x) order: a whole x run of a wide box,
+    // two rows of an 8-wide one (the 8^3 / 16^3 levels: a 32-wide tile idled 75 % / 50 % of its lanes there)
+    const int lin = (wave * VT + vt) * 16 + m, row = lin / a.bq[2], qx = lin - row * a.bq[2];
     const int qz = row / a.bq[1], qy = row % a.bq[1];
     vbase[vt] = (qz * a.si[0]) * a.pp * 16 + ((qy * a.si[1]) * a.hb[2] + qx * a.si[2]) * cpb * 16;
     orel[vt] = ((qz * a.so[0] * a.out_d[1] + qy * a.so[1]) * a.out_d[2] + qx * a.so[2]) * a.out_cs;
@@ -363,20 +364,7 @@ static bool bconv_plan(const GatherGeom& g, BPlan& p) {
       if (g.tap_d[t][j] > dmax[j]) dmax[j] = g.tap_d[t][j];
     }
   }
-  // contraction channels per staged chunk: 32 where the two stage buffers fit the LDS, else 16, else 8
-  const int cinc_opts[3] = {32, 16, 8};
-  for (int co_i = 0; co_i < 3; ++co_i) {
-  p.cinc = g.K < cinc_opts[co_i] ? g.K : cinc_opts[co_i];
-  if (g.K % p.cinc) continue;
-  p.nchunks = g.K / p.cinc;
-  const int slots = g.ntaps * (p.cinc / 8);
-  p.nj = (slots + 3) / 4;
-  if (p.nj * 4 > BCONV_MAX_SLOTS) continue;
-  p.cot = g.Nn > 16 ? 2 : 1;
-  p.ncob = (g.Nn + 16 * p.cot - 1) / (16 * p.cot);
-  // largest box whose two stage buffers (halo chunk + weight chunk each) fit the LDS budget and that still leaves every CU
-  // a workgroup; small problems fall through to the smallest box that fits
-  static int cand[][3] = {{2, 8, 32}, {1, 8, 32}, {1, 4, 32}, {1, 2, 32}, {1, 4, 16}};
+  static int cand[][3] = {{2, 8, 32}, {1, 8, 32}, {2, 8, 16}, {1, 4, 32}, {1, 8, 16}, {4, 8, 8}, {1, 2, 32}, {1, 4, 16}, {2, 8, 8}, {1, 8, 8}};
   static bool env_done = false;
   // first-pass LDS budget.  78 KB (two workgroups per CU) chose 64-voxel boxes for the 32..256-channel layers, whose packed
   // weights alone take 55 KB: 0.31 ms per 32 -> 32 conv at 64^3 x 4; one workgroup per CU on 256..512-voxel boxes: 0.11 ms
@@ -392,18 +380,36 @@ static bool bconv_plan(const GatherGeom& g, BPlan& p) {
     if (nb) nbuf_env = atoi(nb) == 1 ? 1 : 2;
   }
   const int ncand = (int)(sizeof(cand) / sizeof(cand[0]));
-  const size_t wbytes = (size_t)p.nj * p.cot * 64 * 16;
-  // per box candidate (largest first): two input buffers (the next stage lands while this one computes), else one (the
-  // co-resident workgroups hide the staging latency); first within half the LDS (two workgroups per CU), then all of it
+  static const int64_t minwg = getenv("URSN_BCONV_MINWG") ? atoi(getenv("URSN_BCONV_MINWG")) : 256;   // one workgroup per CU is enough to take the larger box (512: 77.7, 256: 78.6 img/s at cfg5)
+  // Per box candidate (largest first: the packed weights of a chunk are re-read per box), the staging forms in order of
+  // preference: 32 contraction channels per chunk with TWO stage buffers (the next chunk's halo box and weights land while this
+  // one computes), then 16 channels with two buffers (half the LDS: what lets the 512-voxel boxes of the 64 .. 256-channel
+  // levels double-buffer at all -- with one 142 KB buffer every chunk paid its whole DMA latency: 54 us per 64 -> 64 layer at
+  // 32^3 x 4), then one buffer.  First within the first-pass LDS budget, then all of the LDS.
+  const int forms[6][2] = {{32, 2}, {16, 2}, {32, 1}, {16, 1}, {8, 2}, {8, 1}};
   const size_t limits[2] = {lds_cap, 158 * 1024};
   for (size_t limit : limits) {
     BPlan fit;
     bool have = false;
     for (int ci = 0; ci < ncand; ++ci)
-      for (int nbuf = (nbuf_env == 1 ? 1 : 2); nbuf >= 1; --nbuf) {
+      for (int fi = 0; fi < 6; ++fi) {
+        const int nbuf = forms[fi][1];
+        if (nbuf == 2 && nbuf_env == 1) continue;
         BPlan c = p;
+        c.cinc = g.K < forms[fi][0] ? g.K : forms[fi][0];
+        if (g.K % c.cinc) continue;
+        c.nchunks = g.K / c.cinc;
+        const int slots = g.ntaps * (c.cinc / 8);
+        c.nj = (slots + 3) / 4;
+        if (c.nj * 4 > BCONV_MAX_SLOTS) continue;
+        c.cot = g.Nn > 16 ? 2 : 1;
+        c.ncob = (g.Nn + 16 * c.cot - 1) / (16 * c.cot);
+        const size_t wbytes = (size_t)c.nj * c.cot * 64 * 16;
         int bq[3] = {cand[ci][0], cand[ci][1], cand[ci][2]};
         if (g.q_d[0] == 1) { bq[1] *= bq[0]; bq[0] = 1; }          // 2-D problems: all rows in y
+        // a box wider than the volume computes padding: 8- and 16-wide levels take the 8- / 16-wide boxes
+        if (bq[2] > 8 && bq[2] >= 2 * g.q_d[2]) continue;
+        if (bq[2] == 8 && g.q_d[2] > 8) continue;                   // narrow boxes only where the volume is narrow (short DMA runs)
         for (int j = 0; j < 3; ++j) {
           c.bq[j] = bq[j];
           c.hb[j] = (bq[j] - 1) * g.si[j] + (dmax[j] - p.dmin[j]) + 1;
@@ -427,14 +433,11 @@ static bool bconv_plan(const GatherGeom& g, BPlan& p) {
         if (wg > boxes) wg = boxes;
         c.per = (int)((boxes + wg - 1) / wg);
         c.gridx = (int)((boxes + c.per - 1) / c.per);
-        fit = c;
-        have = true;
-        static const int64_t minwg = getenv("URSN_BCONV_MINWG") ? atoi(getenv("URSN_BCONV_MINWG")) : 256;   // one workgroup per CU is enough to take the larger box (512: 77.7, 256: 78.6 img/s at cfg5)
+        if (!have) { fit = c; have = true; }
         if (boxes * c.ncob >= minwg) { p = c; return true; }
       }
     if (have) { p = fit; return true; }
   }
-  }   // next (smaller) chunk
   return false;
 }
 

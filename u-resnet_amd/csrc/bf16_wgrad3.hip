@@ -218,7 +218,30 @@ struct W3ReduceArgs {
   const float* slab; float* dw;
   int nslabs, Kw, Nw;
   int tapw[27];   // stored tap index by (dz * 9 + dy * 3 + dx), -1 = none
+  int stride;     // in slabs: > 1 after slab_fold_kernel summed groups of `stride` slabs into the first slab of each group
 };
+// Stage 1 of the slab sum, in place: slab[g * group] += slab[g * group + 1 .. (g + 1) * group - 1], element-wise in that fixed
+// order, on a grid that fills the chip.  The per-tile reduce kernels below (15 .. 27 workgroups) then walk nslabs / group
+// slabs instead of 1024: walking all of them took 0.11 ms per layer of pure load latency (rocprofv3, cfg5).
+__global__ __launch_bounds__(256) void slab_fold_kernel(float* __restrict__ slab, int nslabs, size_t per4, int group) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per4) return;
+  const int k0 = blockIdx.y * group, k1 = k0 + group < nslabs ? k0 + group : nslabs;
+  bf_f32x4* base = (bf_f32x4*)slab;
+  bf_f32x4 acc = base[(size_t)k0 * per4 + i];
+  for (int k = k0 + 1; k < k1; ++k) acc += base[(size_t)k * per4 + i];
+  base[(size_t)k0 * per4 + i] = acc;
+}
+static int slab_fold(float* slab, int& nslabs, int& stride, size_t per, hipStream_t s) {
+  stride = 1;
+  static const int group = getenv("URSN_SLAB_FOLD") ? atoi(getenv("URSN_SLAB_FOLD")) : 16;   // A/B: 0 | 1 = off
+  if (group < 2 || nslabs < 4 * group || (per & 3)) return 0;
+  const int ng = (nslabs + group - 1) / group;
+  hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)((per / 4 + 255) / 256), ng), dim3(256), 0, s, slab, nslabs, per / 4, group);
+  URSN_HIP(hipGetLastError());
+  nslabs = ng; stride = group;
+  return 0;
+}
 // dw[tap][ci][co] += sum over workgroup slabs in a fixed order: a block owns one 16 x 16 tile, its four y-slices each sum a
 // quarter of the slabs (one thread per element walking 1024 slabs was 0.11 ms of pure load latency per layer), then add up
 // in slice order
@@ -230,12 +253,13 @@ __global__ __launch_bounds__(1024) void b3wgrad_reduce_kernel(W3ReduceArgs a) {
   const size_t per = (size_t)G::NT * 256;
   const int q = (a.nslabs + 3) / 4, k0 = sl * q, k1 = k0 + q < a.nslabs ? k0 + q : a.nslabs;
   const float* p = a.slab + (size_t)u * 256 + el;
+  const size_t pstep = per * a.stride;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int k = k0;
   for (; k + 3 < k1; k += 4) {
-    s0 += p[(size_t)k * per]; s1 += p[(size_t)(k + 1) * per]; s2 += p[(size_t)(k + 2) * per]; s3 += p[(size_t)(k + 3) * per];
+    s0 += p[(size_t)k * pstep]; s1 += p[(size_t)(k + 1) * pstep]; s2 += p[(size_t)(k + 2) * pstep]; s3 += p[(size_t)(k + 3) * pstep];
   }
-  for (; k < k1; ++k) s0 += p[(size_t)k * per];
+  for (; k < k1; ++k) s0 += p[(size_t)k * pstep];
   part[sl][el] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (sl != 0) return;
@@ -418,7 +442,7 @@ __global__ __launch_bounds__(1024) void b3wgradz_reduce_kernel(W3ReduceArgs a) {
   const int dzt = blk / WZ::TPD, i = blk - dzt * WZ::TPD;
   const int el = threadIdx.x, sl = threadIdx.y;   // el: (row 0..15, co 0..7)
   const int row = el >> 3, co = el & 7;
-  const size_t per = (size_t)WZ::NT * 256;
+  const size_t per = (size_t)WZ::NT * 256 * a.stride;
   const float* p0 = a.slab + (size_t)(dzt * WZ::TPD + i) * 256 + row * 16 + co;
   const float* p1 = a.slab + (size_t)((dzt + 1) * WZ::TPD + i) * 256 + row * 16 + 8 + co;
   const int qn = (a.nslabs + 3) / 4, k0 = sl * qn, k1 = k0 + qn < a.nslabs ? k0 + qn : a.nslabs;
@@ -490,7 +514,9 @@ static int w3_launch(const W3Plan& p, const W3Args& a, const W3ReduceArgs& r, hi
   }
   hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), G::LDS, s, a);
   URSN_HIP(hipGetLastError());
-  hipLaunchKernelGGL((b3wgrad_reduce_kernel<K, NN>), dim3(G::NT), dim3(256, 4), 0, s, r);
+  W3ReduceArgs r2 = r;
+  URSN_TRY(slab_fold(a.slab, r2.nslabs, r2.stride, (size_t)G::NT * 256, s));
+  hipLaunchKernelGGL((b3wgrad_reduce_kernel<K, NN>), dim3(G::NT), dim3(256, 4), 0, s, r2);
   URSN_HIP(hipGetLastError());
   return 0;
 }
@@ -513,6 +539,7 @@ int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float*
     a.aff_mean = aff->mean; a.aff_rstd = aff->rstd; a.aff_beta = aff->beta; a.aff_relu = aff->relu;
   }
   W3ReduceArgs r;
+  r.stride = 1;
   r.slab = a.slab; r.dw = dw; r.nslabs = p.grid; r.Kw = Kw > 0 ? Kw : g.K; r.Nw = Nw > 0 ? Nw : g.Nn;
   for (int i = 0; i < 27; ++i) r.tapw[i] = -1;
   for (int t = 0; t < g.ntaps; ++t) r.tapw[(g.tap_d[t][0] + 1) * 9 + (g.tap_d[t][1] + 1) * 3 + (g.tap_d[t][2] + 1)] = g.tap_w[t];
@@ -527,6 +554,7 @@ int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float*
     if (aff) hipLaunchKernelGGL(b3wgradz_kernel<true>, dim3(p.grid), dim3(256), WZ::LDS, s, a);
     else hipLaunchKernelGGL(b3wgradz_kernel<false>, dim3(p.grid), dim3(256), WZ::LDS, s, a);
     URSN_HIP(hipGetLastError());
+    URSN_TRY(slab_fold(a.slab, r.nslabs, r.stride, (size_t)WZ::NT * 256, s));
     hipLaunchKernelGGL(b3wgradz_reduce_kernel, dim3(3 * WZ::TPD), dim3(128, 4), 0, s, r);
     URSN_HIP(hipGetLastError());
     return 0;
