@@ -1,13 +1,16 @@
-"""Aggregates gpurun_out/pmc_traffic/{FETCH_SIZE,WRITE_SIZE} (tools/pmc_traffic.sh) into profiles/r02_pmc_traffic_cfg3.csv and
-profiles/pmc_traffic.json (bench.py reads the latter for roofline.traffic).  gfx950: FETCH_SIZE counts 64 B per 128-B
+"""Aggregates gpurun_out/pmc_traffic/{FETCH_SIZE,WRITE_SIZE} (tools/pmc_traffic.sh) into profiles/<round>_pmc_traffic_cfg3.csv and
+profiles/pmc_traffic.json (bench.py reads the latter for roofline.traffic); `bf16`: profiles/<round>_pmc_traffic_cfg5_bf16.{csv,json}.
+Round tag: URSN_ROUND (default r03).  gfx950: FETCH_SIZE counts 64 B per 128-B
 request for wide coalesced loads (MI355X_MICROARCH.md) -> hbm_bytes = 2 * fetch + write."""
 import collections
 import csv
 import glob
 import json
 import re
+import os
 import sys
 
+ROUND = os.environ.get("URSN_ROUND", "r03")
 BF16 = len(sys.argv) > 1 and sys.argv[1] == "bf16"   # python tools/pmc_traffic.py bf16 -> profiles/r02_pmc_traffic_cfg5_bf16.json
 
 LABEL = [  # rocprof kernel name (regex) -> bench.py kernel label
@@ -26,6 +29,8 @@ if BF16:
              (r"b3conv_kernel<16, 8, true", "b3conv_bf16<16,8>"), (r"b3conv_kernel<8, 16, false, true", "b3conv_bf16<8,16>+pw"),
              (r"b3wgradz_kernel<false>", "b3wgrad_bf16<8,8>(pair)"), (r"b3wgrad_kernel<16, 8", "b3wgrad_bf16<16,8>"),
              (r"bdeconv_kernel<true>", "bdeconv_bf16<16,8>"), (r"bpw_kernel<16, 8", "bpw_bf16"),
+             (r"bcbconv_kernel<32, true>", "bcbconv_bf16<32>"), (r"bcbconv_kernel<32, false>", "bcbconv_bf16<32>(dgrad)"),
+             (r"bcbconv_kernel<16, false>", "bcbconv_bf16<16>(dgrad)"), (r"b3conv_kernel<16, 16, false, false, 0, false", "b3conv_bf16<16,16>(dgrad)"),
              (r"bbn_bwd_apply_kernel<true, 0, false, false", "bbn_bwd_apply(C8)"), (r"bbn_bwd_reduce_kernel<true, 0, false", "bbn_bwd_reduce(C8)"),
              (r"bbn_act_kernel<true, false, false, false", "bbn_act(C8)")]
 
@@ -52,11 +57,11 @@ if BF16:   # bench.py's label "b3conv_bf16<8,8>" covers the plain forward and da
     if fs and ws:
         fa, wa = sum(fs) / len(fs), sum(ws) / len(ws)
         out["b3conv_bf16<8,8>"] = {"launches": len(fs), "fetch_kib_raw": fa, "write_kib": wa, "hbm_bytes_per_launch": (2 * fa + wa) * 1024}
-with open("profiles/r02_pmc_traffic_cfg5_bf16.csv" if BF16 else "profiles/r02_pmc_traffic_cfg3.csv", "w") as fh:
+with open("profiles/%s_pmc_traffic_cfg5_bf16.csv" % ROUND if BF16 else "profiles/%s_pmc_traffic_cfg3.csv" % ROUND, "w") as fh:
     fh.write("kernel,launches,FETCH_SIZE_KiB_raw_per_launch,WRITE_SIZE_KiB_per_launch\n")
     for k, n, fa, wa in rows:
         fh.write('"%s",%d,%s,%s\n' % (k, n, fa, wa))
-json.dump(out, open("profiles/r02_pmc_traffic_cfg5_bf16.json" if BF16 else "profiles/pmc_traffic.json", "w"), indent=1)
+json.dump(out, open("profiles/%s_pmc_traffic_cfg5_bf16.json" % ROUND if BF16 else "profiles/pmc_traffic.json", "w"), indent=1)
 for lab in out:
     if lab != "_note":
         print("%-22s %8.1f MB/launch" % (lab, out[lab]["hbm_bytes_per_launch"] / 1e6))
