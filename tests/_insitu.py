@@ -146,7 +146,10 @@ class InSitu(object):
         if a is not None:
             return a.astype(np.float64)
         kind = self._producer[name]
-        assert self.bf16 and kind[0] == "layer", "only single conv-BN(-ReLU) activations of the bf16 plan can be virtual: %s" % name
+        assert kind[0] == "layer", "only single conv-BN(-ReLU) activations can be virtual: %s" % name
+        if not self.bf16:   # fp32 plan, URSN_NORM_ON_LOAD=1: z * r + (beta - mu * r) in fp32, no rounding step to reproduce
+            y = self.bn_apply(name)
+            return np.maximum(y, 0.0) if kind[1] else y
         return staged_bn(self.t(name + ":z"), self.t(name + ":mean"), self.t(name + ":rstd"), self.P[name + "/BatchNorm/beta"], kind[1])
 
     def x_of(self, ins):

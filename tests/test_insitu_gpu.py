@@ -46,6 +46,44 @@ def test_every_layer_against_oracle_primitives_on_stored_operands(case):
     assert set(T.worst) >= {"z", "rstd", "act", "join", "dlogits", "dz", "dw", "dx"}, sorted(T.worst)
 
 
+# ---- the optional kernel paths behind the A/B switches, held to the same local bounds ------------------------------------
+_CHILD = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from test_insitu_gpu import _step
+from _insitu import InSitu
+dims, base, ncls, N, ns, prec = (32, 64, 64, 1), 8, 3, 1, 5, sys.argv[2]
+net, P, data, label, weight = _step(dims, base, ncls, N, ns, prec)
+T = InSitu(net, P, dims, base, ncls, ns, data, label, weight, bf16=(prec == "bf16")).run(sys.argv[3])
+assert set(T.worst) >= {"z", "rstd", "act", "join", "dlogits", "dz", "dw", "dx"}
+print("INSITU_OK")
+"""
+SWITCHES = [
+    ("bf16", {"URSN_B3CONV_DMA": "0"}),                    # register-staged planes instead of the LDS-DMA ring
+    ("bf16", {"URSN_BCB": "0", "URSN_SLAB_FOLD": "0"}),    # generic box kernel at levels 1-2, one-stage slab reduce
+    ("bf16", {"URSN_BF16_FUSE_BN_BWD_REDUCE": "1"}),       # BatchNorm-backward reductions in the data-gradient epilogue
+    ("bf16", {"URSN_B3CONV_PW": "0", "URSN_BF16_NORM_ON_LOAD": "0", "URSN_BF16_SKIP0_OWN": "0"}),   # no fused shortcut term, materialised activations, skip inside the concat buffer
+    ("bf16", {"URSN_B3CONV": "0", "URSN_B3WGRAD": "0", "URSN_BDECONV": "0", "URSN_BPW": "0"}),      # generic kernels everywhere
+    ("fp32", {"URSN_FUSE_BN_BWD_REDUCE": "0", "URSN_FUSE_SHORTCUT_DGRAD": "0", "URSN_RELU_MASK": "0"}),
+    ("fp32", {"URSN_SPLIT_CAT": "0", "URSN_NORM_ON_LOAD": "1"}),
+    ("fp32", {"URSN_DISABLE_TILED": "1", "URSN_WGRAD_STREAM": "0"}),
+]
+
+
+@pytest.mark.parametrize("case", SWITCHES, ids=["%s:%s" % (p, ",".join("%s=%s" % kv for kv in sorted(e.items()))) for p, e in SWITCHES])
+def test_optional_kernel_paths_in_situ(case):
+    """cfg5's / cfg3's model at 32 x 64 x 64 with the A/B switches of DESIGN.md section 3 flipped (child process: the switches are
+    read once per process): every alternative path is held to the same per-layer bounds as the default plan."""
+    import os
+    import subprocess
+    import sys
+    prec, env = case
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _CHILD, root, prec, "switch"], env=dict(os.environ, **env), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0 and "INSITU_OK" in p.stdout, (p.stdout[-1500:], p.stderr[-2500:])
+
+
 # ---- full size ---------------------------------------------------------------------------------------------------------
 U = "UResNet/"
 

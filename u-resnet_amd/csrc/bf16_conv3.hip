@@ -376,18 +376,19 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
       slot ^= 1;
     }
   } else {
-    // VM operations retire in issue order.  At the end of iteration p this wave's youngest are: the stores of output plane
-    // p - 1 (kst: one per valid row and 8-channel group, none while that plane lies outside the segment), then the DMAs of
-    // planes p + 3 and p + 2 (NST each); everything older -- plane p + 1 included -- must have landed.
+    // VM operations retire in issue order.  At the end of iteration p everything up to the DMA of plane p + 1 must have landed;
+    // younger than it are this wave's stores of the last AHEAD output planes (one per valid row and 8-channel group, none while
+    // a plane lies outside the segment) and the DMAs of planes p + 2 .. p + AHEAD (NST each): exactly those may stay in flight.
     int krow = 0;
 #pragma unroll
     for (int nt = 0; nt < RPW; ++nt) krow += (y0 + RPW * wave + nt < a.Y) ? NCH : 0;
-    auto wait_vm = [&](int keep) {   // s_waitcnt takes an immediate
+    auto wait_vm = [&](int keep) {   // s_waitcnt takes an immediate; a smaller count than necessary only waits for more
       switch (keep) {
 #define B3W(n_) case n_: asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory"); break;
         B3W(0) B3W(1) B3W(2) B3W(3) B3W(4) B3W(5) B3W(6) B3W(7) B3W(8) B3W(9) B3W(10) B3W(11) B3W(12) B3W(13) B3W(14) B3W(15) B3W(16) B3W(17) B3W(18)
+        B3W(19) B3W(20) B3W(21) B3W(22) B3W(23) B3W(24) B3W(25) B3W(26) B3W(27) B3W(28) B3W(29) B3W(30) B3W(31) B3W(32) B3W(33) B3W(34)
 #undef B3W
-        default: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;   // waits for more than necessary: always safe
+        default: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
       }
     };
     constexpr int AHEAD = NSLOT - 1;   // planes in flight
@@ -403,8 +404,11 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
       if (p + AHEAD <= z1) stage_dma(p + AHEAD, slot == 0 ? NSLOT - 1 : slot - 1);
       plane_step(p, slot);
       if (p < z1) {
-        const int kst = (p - 1 >= z0 && p - 1 < z1) ? krow : 0;
-        int nd = 0;
+        // younger than the DMA of plane p + 1 (issued AHEAD - 1 iterations ago): the stores of output planes p - AHEAD .. p - 1
+        // and the DMAs of planes p + 2 .. p + AHEAD
+        int kst = 0, nd = 0;
+#pragma unroll
+        for (int k = 1; k <= AHEAD; ++k) kst += (p - k >= z0 && p - k < z1) ? krow : 0;
 #pragma unroll
         for (int k = 2; k <= AHEAD; ++k) nd += (p + k <= z1) ? 1 : 0;
         wait_vm(kst + G::NST * nd);
