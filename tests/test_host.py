@@ -276,3 +276,23 @@ def test_native_plan_against_reference_graph():
             lim = G["xavier_limits"][name.rsplit("/", 1)[0]]["limit"]
             fan = int(np.prod(shape[:2]))
             assert abs(np.sqrt(6.0 / (fan * (shape[-1] + shape[-2]))) - lim) < 1e-8
+
+
+def test_library_is_built_from_the_sources_as_they_are():
+    """The in-tree .so is reused only while the digest written beside it at build time matches the sources (a stale library
+    with fresh timestamps must rebuild, not pass an mtime comparison)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_ursn_build_t", os.path.join(root, "u-resnet_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build(force=False, verbose=False)
+    assert os.path.isfile(b.LIB) and not b.needs_build()
+    with open(b.STAMP) as f:
+        assert f.read().strip() == b.sources_digest()
+    real = b.sources_digest
+    try:
+        b.sources_digest = lambda: "0" * 64     # any source change
+        assert b.needs_build()
+    finally:
+        b.sources_digest = real

@@ -11,13 +11,32 @@ SOURCES = ["conv_generic.hip", "conv_tiled.hip", "conv_tiled_3d.hip", "conv_tile
            "conv_api.hip", "net.hip"]
 
 
-def needs_build():
-    if not os.path.isfile(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + \
+STAMP = os.path.join(CSRC, "build", "sources.sha256")
+
+
+def _deps():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))) + \
         [os.path.join(CSRC, "..", "..", "include", "uresnet_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def sources_digest():
+    """sha256 over every source / header the library is built from (names + contents)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in _deps():
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def needs_build():
+    """The library is current when it exists and the digest written beside it at build time matches the sources as they are
+    now: a stale .so with fresh timestamps (a copied tree, a checkout) rebuilds instead of passing an mtime comparison."""
+    if not os.path.isfile(LIB) or not os.path.isfile(STAMP):
+        return True
+    with open(STAMP) as f:
+        return f.read().strip() != sources_digest()
 
 
 def build(force=False, verbose=True):
@@ -48,6 +67,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(sources_digest() + "\n")
     return LIB
 
 
