@@ -424,3 +424,33 @@ def test_bf16_concat_pass_and_two_operand_backward_of_conv0():
     torch.cuda.synchronize()
     assert np.abs(dzg.float().cpu().numpy() - dz).max() <= BF_TOL * np.abs(dz).max()
     assert np.abs(dbeta.cpu().numpy() - g.sum(0)).max() <= 1e-5 * np.abs(g).sum(0).max()
+
+
+@pytest.mark.parametrize("chan", [(32, 16), (64, 32)], ids=["32_16", "64_32"])
+@pytest.mark.parametrize("shape", [(2, (9, 21, 37)), (1, (12, 8, 64))], ids=["odd", "zseg"])
+def test_bf16_channel_block_data_gradient_with_fused_shortcut_term(shape, chan):
+    """First decoder unit of levels 1 / 2 (lib/resnet_module.py:25-51, 32 -> 16 and 64 -> 32): d(in) = conv1^T(dz1) +
+    shortcut^T(dz_sc) in the z-marching channel-block kernel (the shortcut's dz plane staged beside the x plane, its weights as
+    KS more A fragments of the centre tap); overwrite and accumulate."""
+    N, S = shape
+    ci, co = chan
+    lib = _lib.load()
+    rng = np.random.default_rng(ci + N)
+    w, wg = _bf_w(rng.standard_normal((3, 3, 3, ci, co)) * 0.2)
+    pw, pwg = _bf_w(rng.standard_normal((ci, co)) * 0.3)
+    dy, dyg = bf(rng.standard_normal((N,) + S + (co,)))
+    pdy, pdyg = bf(rng.standard_normal((N,) + S + (co,)))
+    dx = O.conv_bwd(np.zeros((N,) + S + (ci,)), w, 1, dy)[0] + pdy @ pw.T
+    d = desc(3, N, S, ci, co, 3, 1)
+    d.dtype = 1
+    d.pw_dy, d.pw_w = pdyg.data_ptr(), pwg.data_ptr()
+    g = torch.full(dx.shape, float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.ursn_conv_backward_data(ctypes.byref(d), P(dyg), P(wg), P(g), 0, stream()))
+    torch.cuda.synchronize()
+    lib.ursn_last_kernel_name.restype = ctypes.c_char_p
+    assert lib.ursn_last_kernel_name().endswith(b"+pw") and lib.ursn_last_kernel_name().startswith(b"bcbconv"), lib.ursn_last_kernel_name()
+    assert np.abs(g.float().cpu().numpy() - dx).max() <= BF_TOL * np.abs(dx).max()
+    base, baseg = bf(rng.standard_normal(dx.shape))
+    _lib.check(lib.ursn_conv_backward_data(ctypes.byref(d), P(dyg), P(wg), P(baseg), 1, stream()))
+    torch.cuda.synchronize()
+    assert np.abs(baseg.float().cpu().numpy() - (dx + base)).max() <= BF_TOL * np.abs(dx + base).max()

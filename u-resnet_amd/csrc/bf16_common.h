@@ -90,8 +90,11 @@ bool bcbconv_ok(const GatherGeom& g);
 size_t bcbconv_pack_elems(const GatherGeom& g);
 int bcbconv_grid_blocks(const GatherGeom& g);
 size_t bcbconv_stats_scratch_doubles(const GatherGeom& g);
+// pw (data gradient, bcbconv_pw_ok): + pw[v] . pw_w^T, the data gradient of the unit's 1x1 stride-1 shortcut (pw = its dz with
+// g.K channels, pw_w = its weights [g.Nn][g.K])
+bool bcbconv_pw_ok(const GatherGeom& g);
 int launch_bcbconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
-                   double* stats_partial, hipStream_t s);
+                   double* stats_partial, hipStream_t s, const bf16_t* pw = nullptr, int pw_cs = 0, const float* pw_w = nullptr);
 int bcbconv_stats_finalize(const GatherGeom& g, const double* partial, int64_t V, float eps, float* mean, float* rstd, hipStream_t s);
 // 1x1 stride-1 conv between 8 / 16 channel tensors, operands straight from global memory (bf16_pointwise.hip)
 bool bpw_ok(const GatherGeom& g);

@@ -381,18 +381,20 @@ static bool bconv_plan(const GatherGeom& g, BPlan& p) {
   }
   const int ncand = (int)(sizeof(cand) / sizeof(cand[0]));
   static const int64_t minwg = getenv("URSN_BCONV_MINWG") ? atoi(getenv("URSN_BCONV_MINWG")) : 256;   // one workgroup per CU is enough to take the larger box (512: 77.7, 256: 78.6 img/s at cfg5)
-  // Per box candidate (largest first: the packed weights of a chunk are re-read per box), the staging forms in order of
-  // preference: 32 contraction channels per chunk with TWO stage buffers (the next chunk's halo box and weights land while this
-  // one computes), then 16 channels with two buffers (half the LDS: what lets the 512-voxel boxes of the 64 .. 256-channel
-  // levels double-buffer at all -- with one 142 KB buffer every chunk paid its whole DMA latency: 54 us per 64 -> 64 layer at
-  // 32^3 x 4), then one buffer.  First within the first-pass LDS budget, then all of the LDS.
-  const int forms[6][2] = {{32, 2}, {16, 2}, {32, 1}, {16, 1}, {8, 2}, {8, 1}};
+  // Contraction channels per staged chunk: 32 where some box fits the LDS, else 16, else 8; per box candidate (largest first: the
+  // packed weights of a chunk are re-read per box) two stage buffers (the next chunk's halo box and weights land while this one
+  // computes), else one.  Measured and rejected (round 3): preferring 16-channel chunks with two buffers over 32-channel chunks
+  // with one -- 64 -> 32 @64^3 0.200 -> 0.229 ms, 64 -> 64 @32^3 unchanged -- and 8-channel chunks on the largest box for the
+  // stride-2 layers (16 -> 32 s2 @128^3: 0.157 -> 0.228 ms).
+  const int forms[6][2] = {{32, 2}, {32, 1}, {16, 2}, {16, 1}, {8, 2}, {8, 1}};
   const size_t limits[2] = {lds_cap, 158 * 1024};
+  for (int f0 = 0; f0 < 6; f0 += 2) {   // chunk width
+  if (f0 > 0 && (g.K < forms[f0 - 2][0])) break;   // the narrower chunk is the same chunk (K itself)
   for (size_t limit : limits) {
     BPlan fit;
     bool have = false;
     for (int ci = 0; ci < ncand; ++ci)
-      for (int fi = 0; fi < 6; ++fi) {
+      for (int fi = f0; fi < f0 + 2; ++fi) {
         const int nbuf = forms[fi][1];
         if (nbuf == 2 && nbuf_env == 1) continue;
         BPlan c = p;
@@ -410,6 +412,7 @@ static bool bconv_plan(const GatherGeom& g, BPlan& p) {
         // a box wider than the volume computes padding: 8- and 16-wide levels take the 8- / 16-wide boxes
         if (bq[2] > 8 && bq[2] >= 2 * g.q_d[2]) continue;
         if (bq[2] == 8 && g.q_d[2] > 8) continue;                   // narrow boxes only where the volume is narrow (short DMA runs)
+        if (bq[2] == 16 && g.q_d[2] > 16 && !(cand[ci][0] == 1 && cand[ci][1] == 4)) continue;   // (1 x 4 x 16 stays the last resort of wide volumes)
         for (int j = 0; j < 3; ++j) {
           c.bq[j] = bq[j];
           c.hb[j] = (bq[j] - 1) * g.si[j] + (dmax[j] - p.dmin[j]) + 1;
@@ -438,6 +441,7 @@ static bool bconv_plan(const GatherGeom& g, BPlan& p) {
       }
     if (have) { p = fit; return true; }
   }
+  }   // next (narrower) chunk
   return false;
 }
 

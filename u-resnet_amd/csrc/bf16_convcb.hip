@@ -35,7 +35,13 @@ struct CB {
   static constexpr int NST = (PIECES + 255) / 256;      // DMA instructions per thread per plane
   static constexpr int PLANE = NST * 256 * 16;          // bytes of one slot (padded to whole wave instructions)
   static constexpr int WBYTES = 27 * KS * 1024;         // one block of 32 produced channels: [tap][k step][lane][8] bf16
-  static constexpr int LDS = 2 * PLANE + WBYTES;
+  // fused shortcut term of a data gradient (PW): + pw[v] . Wsc^T, the data gradient of the unit's parallel 1x1 shortcut
+  // (lib/resnet_module.py:25-33): the shortcut's dz plane (interior voxels, piece-major) rides behind the x plane of every
+  // slot and KS more A fragments behind the 27 taps
+  static constexpr int PWPLANE = TY * 32 * CPV * 16;    // bytes, a multiple of 4096
+  static constexpr int NSTPW = PWPLANE / 4096;          // DMA instructions per thread
+  static constexpr int WPW = KS * 1024;
+  static constexpr int lds(bool pw) { return 2 * (PLANE + (pw ? PWPLANE : 0)) + WBYTES + (pw ? WPW : 0); }
 };
 
 struct CBArgs {
@@ -49,15 +55,17 @@ struct CBArgs {
   int zseg, nzseg, nty, ntx;
   int accumulate;
   int stats_total;
+  const bf16_t* pw;        // PW: the shortcut's dz, CI channels per voxel (the data gradient's contraction channels)
+  int pw_cs;
 };
 
 // One input plane (LDS slot L) against the three tap planes.  accN / accM / accO: the accumulator sets of output planes
 // p + 1 (first contribution: starts from zero), p, p - 1 (last contribution).  NEW / MID / OLD: which of them exist inside the
 // z segment (uniform; instantiated, not branched on, so that the MFMA stream stays one basic block).
-template <int CI, bool NEW, bool MID, bool OLD>
+template <int CI, bool NEW, bool MID, bool OLD, bool PW = false>
 __device__ __forceinline__ void cb_plane(const unsigned char* __restrict__ L, const unsigned char* __restrict__ W, unsigned boff,
                                          unsigned aoff, cb_f32x16 (&accN)[CB<CI>::RPW], cb_f32x16 (&accM)[CB<CI>::RPW],
-                                         cb_f32x16 (&accO)[CB<CI>::RPW]) {
+                                         cb_f32x16 (&accO)[CB<CI>::RPW], unsigned pwoff = 0) {
   using G = CB<CI>;
   constexpr int KS = G::KS, RPW = G::RPW;
   if constexpr (NEW) {
@@ -97,14 +105,27 @@ __device__ __forceinline__ void cb_plane(const unsigned char* __restrict__ L, co
       }
     __builtin_amdgcn_sched_barrier(0);
   }
+  if constexpr (PW && MID) {   // the shortcut's term of output plane p: its own voxel only, KS more k steps
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bfx8 Ap = *(const bfx8*)(W + G::WBYTES + aoff + ks * 1024);
+#pragma unroll
+      for (int nt = 0; nt < RPW; ++nt) {
+        const bfx8 Bp = *(const bfx8*)(L + G::PLANE + pwoff + ((2 * ks) * G::TY * 32 + nt * 32) * 16);
+        accM[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ap, Bp, accM[nt], 0, 0, 0);
+      }
+    }
+  }
 }
 
-template <int CI, bool STATS>
+template <int CI, bool STATS, bool PW = false>
 __global__ __launch_bounds__(256, 1) void bcbconv_kernel(CBArgs a) {
+  static_assert(!(PW && STATS), "the fused shortcut term belongs to a data gradient");
   using G = CB<CI>;
   constexpr int RPW = G::RPW, PX = G::PX, PY = G::PY, CPV = G::CPV;
+  constexpr int SLOT = G::PLANE + (PW ? G::PWPLANE : 0), WALL = G::WBYTES + (PW ? G::WPW : 0);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char* const W = lds + 2 * G::PLANE;
+  unsigned char* const W = lds + 2 * SLOT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 31, h = lane >> 5;
   int bid = blockIdx.x;
@@ -121,9 +142,9 @@ __global__ __launch_bounds__(256, 1) void bcbconv_kernel(CBArgs a) {
 
   // ---- weights of this block of produced channels: global (L2-resident) -> LDS, once ----
   {
-    const bf16_t* wsrc = a.wp + (size_t)cob * (G::WBYTES / 2);
-    for (int base = 0; base < G::WBYTES / 16; base += 256)   // WBYTES / 16 pieces, a multiple of 64
-      if (base + wave * 64 < G::WBYTES / 16)
+    const bf16_t* wsrc = a.wp + (size_t)cob * (WALL / 2);
+    for (int base = 0; base < WALL / 16; base += 256)   // WALL / 16 pieces, a multiple of 64
+      if (base + wave * 64 < WALL / 16)
         __builtin_amdgcn_global_load_lds((const void*)(wsrc + (size_t)(base + tid) * 8),
                                          (__attribute__((address_space(3))) void*)(W + (size_t)(base + wave * 64) * 16), 16, 0, 0);
   }
@@ -146,20 +167,42 @@ __global__ __launch_bounds__(256, 1) void bcbconv_kernel(CBArgs a) {
     }
   }
   const size_t plane_stride = (size_t)a.Y * a.X * a.in_cs;
+  // PW: this thread's pieces of the shortcut plane (interior voxels): LDS piece index i * 256 + tid = (piece, y, x)
+  int prel[PW ? G::NSTPW : 1];
+  unsigned pval = 0;
+  if constexpr (PW) {
+#pragma unroll
+    for (int i = 0; i < G::NSTPW; ++i) {
+      const int idx = tid + 256 * i, hp = idx / (G::TY * 32), vi = idx - hp * (G::TY * 32);
+      const int gy = y0 + vi / 32, gx = x0 + (vi & 31);
+      prel[i] = 0;
+      if (gy < a.Y && gx < a.X) { pval |= 1u << i; prel[i] = (gy * a.X + gx) * a.pw_cs + hp * 8; }
+    }
+  }
   auto stage = [&](int p, int slot) {   // plane p -> LDS slot; planes outside the tensor are zero planes
     const bool pz = p >= 0 && p < a.Z;
     const bf16_t* base = a.in + ((size_t)n * a.Z + (pz ? p : 0)) * plane_stride;
-    unsigned char* dst = lds + slot * G::PLANE + wave * 1024;
+    unsigned char* dst = lds + slot * SLOT + wave * 1024;
 #pragma unroll
     for (int i = 0; i < G::NST; ++i) {
       const bf16_t* src = (pz && ((sval >> i) & 1u)) ? base + srel[i] : a.zero;
       __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+    }
+    if constexpr (PW) {   // the shortcut's dz of the same plane (used by the middle role only: planes of the segment)
+      const bool pq = p >= z0 && p < z1;
+      const bf16_t* pbase = a.pw + ((size_t)n * a.Z + (pq ? p : 0)) * (size_t)a.Y * a.X * a.pw_cs;
+#pragma unroll
+      for (int i = 0; i < G::NSTPW; ++i) {
+        const bf16_t* src = (pq && ((pval >> i) & 1u)) ? pbase + prel[i] : a.zero;
+        __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(dst + G::PLANE + i * 4096), 16, 0, 0);
+      }
     }
   };
 
   // B operand of lane (column c, k half h): piece 2 ks + h of voxel (row RPW * wave + nt + dy, column c + dx) of the halo plane
   const unsigned boff = (unsigned)(((h * PY + RPW * wave) * PX + c) * 16);
   const unsigned aoff = (unsigned)(lane * 16);
+  const unsigned pwoff = (unsigned)(((h * G::TY + RPW * wave) * 32 + c) * 16);   // shortcut plane: piece h of this lane's voxel
 
   cb_f32x16 accN[RPW], accM[RPW], accO[RPW];   // output planes p + 1 (new), p (middle), p - 1 (complete after this plane)
 #pragma unroll
@@ -265,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void bcbconv_kernel(CBArgs a) {
     flush();                                 // plane p - 2
     if (p - 1 >= z0) prefetch_old(p - 1);    // completes at the end of this iteration
     stage(p + 1, slot ^ 1);                  // lands during the MFMA block
-    cb_plane<CI, true, true, true>(lds + slot * G::PLANE, W, boff, aoff, accN, accM, accO);
+    cb_plane<CI, true, true, true, PW>(lds + slot * SLOT, W, boff, aoff, accN, accM, accO, pwoff);
     if (p - 1 >= z0) finish(p - 1, accO);
 #pragma unroll
     for (int nt = 0; nt < RPW; ++nt) { accO[nt] = accM[nt]; accM[nt] = accN[nt]; }
@@ -274,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void bcbconv_kernel(CBArgs a) {
   }
   flush();
   prefetch_old(z1 - 1);
-  cb_plane<CI, false, false, true>(lds + slot * G::PLANE, W, boff, aoff, accN, accM, accO);
+  cb_plane<CI, false, false, true>(lds + slot * SLOT, W, boff, aoff, accN, accM, accO);
   finish(z1 - 1, accO);
   flush();
 
@@ -307,6 +350,7 @@ struct CBPackArgs {
   bf16_t* wp;
   int tapw[27];   // weight tap index by displacement (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)
   int Kw, Nw, w_tap_stride, w_sk, w_sn, ncob;
+  const float* pw_w;   // shortcut weights [produced channel of the data gradient][contraction channel] or null
 };
 
 // fp32 master weights -> A operands [cout block][tap plane tz][in-plane tap][k step][lane][8]: lane (row = l & 31, k half
@@ -316,20 +360,26 @@ struct CBPackArgs {
 template <int CI>
 __global__ void bcbconv_pack_kernel(CBPackArgs k) {
   using G = CB<CI>;
-  const int total = k.ncob * 27 * G::KS * 512;
+  const int nk = 27 * G::KS + (k.pw_w ? G::KS : 0);   // KB of A fragments per block of produced channels
+  const int total = k.ncob * nk * 512;
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e < 8) k.wp[total + e] = 0;   // the zero piece
   if (e >= total) return;
   const int j = e & 7, lane = (e >> 3) & 63;
   int r = e >> 9;
-  const int ks = r % G::KS; r /= G::KS;
-  const int t = r % 9; r /= 9;
-  const int tz = r % 3, cob = r / 3;
-  const int co = cob * 32 + (lane & 31), ci = 16 * ks + 8 * (lane >> 5) + j;
+  const int slot = r % nk, cob = r / nk;
+  const int co = cob * 32 + (lane & 31);
   float v = 0.f;
-  if (ci < k.Kw && co < k.Nw) {
-    const int tw = k.tapw[tz * 9 + t];
-    if (tw >= 0) v = k.w[(size_t)tw * k.w_tap_stride + (size_t)ci * k.w_sk + (size_t)co * k.w_sn];
+  if (slot < 27 * G::KS) {
+    const int ks = slot % G::KS, tt = slot / G::KS, t = tt % 9, tz = tt / 9;
+    const int ci = 16 * ks + 8 * (lane >> 5) + j;
+    if (ci < k.Kw && co < k.Nw) {
+      const int tw = k.tapw[tz * 9 + t];
+      if (tw >= 0) v = k.w[(size_t)tw * k.w_tap_stride + (size_t)ci * k.w_sk + (size_t)co * k.w_sn];
+    }
+  } else {
+    const int ci = 16 * (slot - 27 * G::KS) + 8 * (lane >> 5) + j;
+    if (ci < k.Kw && co < k.Nw) v = k.pw_w[(size_t)co * k.Kw + ci];
   }
   k.wp[e] = f2bf(v);
 }
@@ -372,34 +422,41 @@ bool bcbconv_ok(const GatherGeom& g) {
   return (int64_t)p.grid * p.ncob < ((int64_t)1 << 30);
 }
 
-size_t bcbconv_pack_elems(const GatherGeom& g) { return (size_t)((g.Nn + 31) / 32) * 27 * (g.K / 16) * 512 + 8; }
+size_t bcbconv_pack_elems(const GatherGeom& g) { return (size_t)((g.Nn + 31) / 32) * 28 * (g.K / 16) * 512 + 8; }   // incl. a fused shortcut's fragments
 int bcbconv_grid_blocks(const GatherGeom& g) { return cb_plan(g).grid; }   // rows of the statistics partials PER cout block
 size_t bcbconv_stats_scratch_doubles(const GatherGeom& g) { const CBPlan p = cb_plan(g); return (size_t)p.grid * p.ncob * 64; }
 
-template <int CI, bool STATS>
+template <int CI, bool STATS, bool PW>
 static int cb_launch(const CBPlan& p, const CBArgs& a, hipStream_t s) {
-  auto kern = bcbconv_kernel<CI, STATS>;
+  auto kern = bcbconv_kernel<CI, STATS, PW>;
   static bool attr = false;
   if (!attr) {
-    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CB<CI>::LDS));
+    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CB<CI>::lds(PW)));
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3(p.grid, p.ncob), dim3(256), CB<CI>::LDS, s, a);
+  hipLaunchKernelGGL(kern, dim3(p.grid, p.ncob), dim3(256), CB<CI>::lds(PW), s, a);
   URSN_HIP(hipGetLastError());
   return 0;
 }
 
+bool bcbconv_pw_ok(const GatherGeom& g) {
+  static const bool off = getenv("URSN_BCB_PW") && getenv("URSN_BCB_PW")[0] == '0';
+  return !off && bcbconv_ok(g);
+}
+
 int launch_bcbconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
-                   double* stats_partial, hipStream_t s) {
+                   double* stats_partial, hipStream_t s, const bf16_t* pw, int pw_cs, const float* pw_w) {
   URSN_REQUIRE(bcbconv_ok(g), "bf16 channel-block conv: unsupported geometry");
+  URSN_REQUIRE(!pw || (pw_w && !stats_partial && (pw_cs & 7) == 0 && pw_cs >= g.K), "bf16 channel-block conv: bad fused shortcut arguments");
   const CBPlan p = cb_plan(g);
   CBPackArgs k;
   k.w = w; k.wp = wpack; k.Kw = Kw > 0 ? Kw : g.K; k.Nw = Nw > 0 ? Nw : g.Nn;
   k.w_tap_stride = g.w_tap_stride; k.w_sk = g.w_sk; k.w_sn = g.w_sn; k.ncob = p.ncob;
+  k.pw_w = pw ? pw_w : nullptr;
   for (int i = 0; i < 27; ++i) k.tapw[i] = -1;
   // in[q + d_t] W_t lands in out[q]: the staged plane p = q + dz feeds output plane p - dz, tap plane tz = dz + 1
   for (int t = 0; t < g.ntaps; ++t) k.tapw[(g.tap_d[t][0] + 1) * 9 + (g.tap_d[t][1] + 1) * 3 + (g.tap_d[t][2] + 1)] = g.tap_w[t];
-  const int total = p.ncob * 27 * (g.K / 16) * 512;
+  const int total = p.ncob * (27 + (pw ? 1 : 0)) * (g.K / 16) * 512;
   if (g.K == 16) hipLaunchKernelGGL(bcbconv_pack_kernel<16>, dim3((total + 255) / 256), dim3(256), 0, s, k);
   else hipLaunchKernelGGL(bcbconv_pack_kernel<32>, dim3((total + 255) / 256), dim3(256), 0, s, k);
   URSN_HIP(hipGetLastError());
@@ -410,9 +467,14 @@ int launch_bcbconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw
   a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
   a.accumulate = g.accumulate;
   a.stats_total = p.grid;
+  a.pw = pw; a.pw_cs = pw_cs;
+  if (pw) {
+    ursn_note_kernel(g.K == 16 ? "bcbconv_bf16<16>+pw" : "bcbconv_bf16<32>+pw");
+    return g.K == 16 ? cb_launch<16, false, true>(p, a, s) : cb_launch<32, false, true>(p, a, s);
+  }
   ursn_note_kernel(g.K == 16 ? "bcbconv_bf16<16>" : "bcbconv_bf16<32>");
-  if (g.K == 16) return stats_partial ? cb_launch<16, true>(p, a, s) : cb_launch<16, false>(p, a, s);
-  return stats_partial ? cb_launch<32, true>(p, a, s) : cb_launch<32, false>(p, a, s);
+  if (g.K == 16) return stats_partial ? cb_launch<16, true, false>(p, a, s) : cb_launch<16, false, false>(p, a, s);
+  return stats_partial ? cb_launch<32, true, false>(p, a, s) : cb_launch<32, false, false>(p, a, s);
 }
 
 int bcbconv_stats_finalize(const GatherGeom& g, const double* partial, int64_t V, float eps, float* mean, float* rstd, hipStream_t s) {

@@ -353,6 +353,14 @@ static int bf16_conv_op(const ursn_conv_desc& d0, ConvPass pass, const void* in,
   int64_t V = (int64_t)d.n;
   for (int j = 0; j < 3; ++j) V *= g[0].out_d[j];
   URSN_REQUIRE(!stats_partial || n == 1 || pass == PASS_FWD, "bf16 conv: statistics only on forward passes");
+  if (d.pw_dy && n == 1 && !b3conv_ok(g[0]) && bcbconv_pw_ok(g[0])) {   // fused shortcut term on the channel-block kernel (levels 1-2)
+    URSN_REQUIRE(pass == PASS_DGRAD && d.pw_w && !d.in_split && !d.in_mean && !stats_partial, "bf16 conv: the fused shortcut term belongs to a plain data gradient");
+    bf16_t* wp = op_wpack(bcbconv_pack_elems(g[0]));
+    URSN_REQUIRE(wp, "bf16 conv: no memory for the packed weights");
+    g[0].accumulate = accumulate;
+    return launch_bcbconv(g[0], (const bf16_t*)in, w, 0, 0, wp, (bf16_t*)out, nullptr, s, (const bf16_t*)d.pw_dy,
+                          d.pw_dy_cstride > 0 ? d.pw_dy_cstride : d.cout, d.pw_w);
+  }
   if (scalar_in || d.in_mean || d.pw_dy) {   // the fused forms of the input-stationary kernel (bf16_conv3.hip)
     URSN_REQUIRE(n == 1 && b3conv_ok(g[0]), "bf16 conv: fused forms (cin = 1 / in_mean / pw_dy) need a 3-D k3 s1 layer with 8 / 16 channels");
     bf16_t* wp = op_wpack(b3conv_pack_elems());

@@ -581,6 +581,13 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
       return 0;
     }
   }
+  if (fused_sc >= 0 && cnt == 1 && !b3conv_ok(g[0]) && bcbconv_pw_ok(g[0])) {   // levels 1-2: the term rides in the channel-block kernel
+    const BLayer& S = n->layers[fused_sc];
+    URSN_REQUIRE(S.k == 1 && S.stride == 1 && S.kout == g[0].K && S.cout == S.kout && S.kin == g[0].Nn && S.cin == S.kin,
+                 "bf16 backward: shortcut of %s does not match its data gradient", L.name.c_str());
+    g[0].accumulate = acc ? 1 : 0;
+    return launch_bcbconv(g[0], L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, s, S.dz, S.kout, n->params + S.w_off);
+  }
   if (fused_sc >= 0) {
     const BLayer& S = n->layers[fused_sc];
     URSN_REQUIRE(cnt == 1 && b3conv_pw_ok(g[0]) && S.kin == 16 && S.cin == 16 && S.cout == 8 && S.kout == 8, "bf16 backward: no fused shortcut term for %s", L.name.c_str());
@@ -641,8 +648,10 @@ int unit_bwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s, const BBsTarget* in_t
   if (u.sc >= 0 && n->layers[u.sc].stride == 1) {
     GatherGeom g[8];
     const BLayer& S = n->layers[u.sc];
-    fuse = layer_geoms(n, n->layers[u.c1], PASS_DGRAD, N, u.in.cs, n->layers[u.c1].kout, g) == 1 && b3conv_pw_ok(g[0]) &&
-           S.kin == 16 && S.cin == 16 && S.cout == 8 && S.kout == 8;
+    const bool one = layer_geoms(n, n->layers[u.c1], PASS_DGRAD, N, u.in.cs, n->layers[u.c1].kout, g) == 1;
+    fuse = one && b3conv_pw_ok(g[0]) && S.kin == 16 && S.cin == 16 && S.cout == 8 && S.kout == 8;
+    // ... or, at levels 1-2, as KS more k steps of the channel-block kernel's centre tap
+    fuse = fuse || (one && !b3conv_ok(g[0]) && bcbconv_pw_ok(g[0]) && S.kout == g[0].K && S.cout == S.kout && S.kin == g[0].Nn && S.cin == S.kin);
   }
   // with an identity shortcut conv1's data gradient is the last contribution to d(in): its consumer's reductions ride along
   URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, fuse ? u.sc : -1, u.sc < 0 ? in_target : nullptr));   // k3 (s1 | s2): writes every voxel of d(in)
