@@ -14,6 +14,7 @@
 #include <utility>
 
 #include "ursn_common.h"
+#include "wave_pivot.h"
 
 typedef float pw_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -64,9 +65,11 @@ __global__ __launch_bounds__(256) void pconv_kernel(PConvArgs a) {
         wreg[cq][r] = v;
       }
   }
-  float s1[STATS ? CP : 1], s2[STATS ? CP : 1];
+  // BatchNorm moments around a wave-uniform pivot (wave_pivot.h): piv[] lives in SGPRs
+  float s1[STATS ? CP : 1], s2[STATS ? CP : 1], piv[STATS ? CP : 1], nsum = 0.f;
+  bool have_piv = false;
 #pragma unroll
-  for (int c = 0; c < (STATS ? CP : 1); ++c) s1[c] = s2[c] = 0.f;
+  for (int c = 0; c < (STATS ? CP : 1); ++c) s1[c] = s2[c] = piv[c] = 0.f;
 
   const int64_t hi_z = (int64_t)a.lo[0] * a.sm[0], hi_y = (int64_t)a.lo[1] * a.sm[1], hi_x = (int64_t)a.lo[2] * a.sm[2];
   // The loop is wave-uniform: v_mfma with the cbsz/abid A-broadcast must run with all 64 lanes active (a masked-off
@@ -103,7 +106,20 @@ __global__ __launch_bounds__(256) void pconv_kernel(PConvArgs a) {
         acc[cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[cq][k / 16], xv[k / 4][k % 4], acc[cq], 4, k % 16, 0);
       });
     });
+    if constexpr (STATS) {
+      if (!have_piv && a.stats_partial) {   // wave-uniform, once: lane 0 of a wave's first iteration is always a real voxel
+#pragma unroll
+        for (int cq = 0; cq < CQ; ++cq) {
+          pw_f32x4 val = acc[cq];
+          if (a.accumulate) val += *(const pw_f32x4*)(op + 4 * cq);   // tail lanes sit on a clamped, readable voxel
+#pragma unroll
+          for (int j = 0; j < 4; ++j) piv[4 * cq + j] = wave_lane_value(val[j], 0);
+        }
+        have_piv = true;
+      }
+    }
     if (!ok) continue;
+    nsum += 1.f;
 #pragma unroll
     for (int cq = 0; cq < CQ; ++cq) {
       pw_f32x4 val = acc[cq];
@@ -112,23 +128,24 @@ __global__ __launch_bounds__(256) void pconv_kernel(PConvArgs a) {
       *(pw_f32x4*)o = val;
       if constexpr (STATS) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[4 * cq + j] += val[j]; s2[4 * cq + j] += val[j] * val[j]; }
+        for (int j = 0; j < 4; ++j) {
+          const float d = val[j] - piv[4 * cq + j];
+          s1[4 * cq + j] += d;
+          s2[4 * cq + j] = __builtin_fmaf(d, d, s2[4 * cq + j]);
+        }
       }
     }
   }
   if constexpr (STATS) if (a.stats_partial) {
-    __shared__ float red[4][2 * CP];
+    __shared__ double red[4][2 * CP];
+    const float nw = wave_sum(nsum);
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
-      float u = s1[c], w2 = s2[c];
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
-      if (lane == 0) { red[tid >> 6][c] = u; red[tid >> 6][CP + c] = w2; }
+      const float u = wave_sum(s1[c]), w2 = wave_sum(s2[c]);
+      if (lane == 0) wave_unpivot(u, w2, nw, piv[c], red[tid >> 6][c], red[tid >> 6][CP + c]);
     }
     __syncthreads();
-    if (tid < 2 * CP)
-      a.stats_partial[(size_t)blockIdx.x * 2 * CP + tid] =
-          (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
+    if (tid < 2 * CP) a.stats_partial[(size_t)blockIdx.x * 2 * CP + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   }
 }
 
@@ -336,7 +353,7 @@ int launch_pointwise_conv(const ursn_conv_desc& d, ConvPass pass, const float* i
   else if (ck == 64 && cp == 32) rc = pconv_launch<64, 32>(a, flip, grid, s);
   else ursn_set_error("pointwise conv: no instantiation for %d->%d", ck, cp);
   if (rc) return rc;
-  if (stats_partial) return launch_bn_stats_final(stats_partial, grid, cp, cp, a.nvox, eps, mean, rstd, s, a.out, a.out_cs);
+  if (stats_partial) return launch_bn_stats_final(stats_partial, grid, cp, cp, a.nvox, eps, mean, rstd, s);
   return 0;
 }
 

@@ -231,8 +231,7 @@ static int launch_blocks(const ursn_conv_desc& d, const TPlan& p, const Blocking
       URSN_TRY(p.mode == 3 ? tconv_dispatch_3d(p, a, s) : tconv_dispatch_2d(p, a, s));
       if (stats_partial && last) {
         int cb = (b.nbo > 1) ? b.bsz : real_out;  // real channels produced by this block
-        URSN_TRY(launch_bn_stats_final(stats_partial, p.grid, cb, p.cout, V, eps, mean + b.bsz * bo, rstd + b.bsz * bo, s,
-                                       a.out, a.out_cs));
+        URSN_TRY(launch_bn_stats_final(stats_partial, p.grid, cb, p.cout, V, eps, mean + b.bsz * bo, rstd + b.bsz * bo, s));
       }
     }
   if (d.bs_partial) {   // own lines in the per-kernel breakdown: the epilogue is not free

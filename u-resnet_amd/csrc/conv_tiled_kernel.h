@@ -23,6 +23,7 @@
 #include <utility>
 
 #include "ursn_common.h"
+#include "wave_pivot.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -192,9 +193,10 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
     }
   };
 
-  float s1[STATS ? COUT : 1], s2[STATS ? COUT : 1];
+  // BatchNorm moments around a wave-uniform pivot (wave_pivot.h): piv[] lives in SGPRs
+  float s1[STATS ? COUT : 1], s2[STATS ? COUT : 1], piv[STATS ? COUT : 1];
 #pragma unroll
-  for (int c = 0; c < (STATS ? COUT : 1); ++c) s1[c] = s2[c] = 0.f;
+  for (int c = 0; c < (STATS ? COUT : 1); ++c) s1[c] = s2[c] = piv[c] = 0.f;
   // fused BatchNorm-backward reductions.  Per lane (its <= zseg voxels of one column) fp32 in packed-math form -- the
   // MFMA-bound loop has few VALU slots to spare (fp64 per-lane sums: +0.9 ms/step); fp64 from the cross-lane step on, where
   // the cancellation of sum g (~1e-3 of sum |g|) happens
@@ -290,6 +292,22 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
         });
       }
     }
+    if constexpr (STATS) {
+      if (z == z0 && a.stats_partial) {   // wave-uniform, once: the pivots = the first valid lane's values of this plane
+        const int src = wave_first_valid(vox_ok);
+        if (src >= 0) {
+          const float* op = a.out + ((((size_t)n * a.Z + z) * a.Y + gy) * a.X + gx) * a.out_cs;
+#pragma unroll
+          for (int cq = 0; cq < CQ; ++cq) {
+            f32x4 v = acc[cq];
+            if constexpr (CQ == 1) v += acc2;
+            if (a.accumulate && vox_ok) v += *(const f32x4*)(op + 4 * cq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) piv[4 * cq + j] = wave_lane_value(v[j], src);
+          }
+        }
+      }
+    }
     if (vox_ok) {
       float* op = a.out + ((((size_t)n * a.Z + z) * a.Y + gy) * a.X + gx) * a.out_cs;
 #pragma unroll
@@ -309,8 +327,9 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
         if constexpr (STATS) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            s1[4 * cq + j] += v[j];
-            s2[4 * cq + j] += v[j] * v[j];
+            const float d = v[j] - piv[4 * cq + j];
+            s1[4 * cq + j] += d;
+            s2[4 * cq + j] = __builtin_fmaf(d, d, s2[4 * cq + j]);
           }
         }
         if constexpr (BS != 0) {
@@ -343,25 +362,15 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
   }
 
   if constexpr (STATS) if (a.stats_partial) {  // workgroup partial sums (double) -> finalised by bn_stats_final_kernel
-    __shared__ float red[4][2 * COUT];
+    __shared__ double red[4][2 * COUT];
+    const float nw = wave_sum(vox_ok ? (float)(z1 - z0) : 0.f);   // voxels this wave summed
 #pragma unroll
     for (int c = 0; c < COUT; ++c) {
-      float u = s1[c], v = s2[c];
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        u += __shfl_xor(u, o);
-        v += __shfl_xor(v, o);
-      }
-      if (lane == 0) {
-        red[tid >> 6][c] = u;
-        red[tid >> 6][COUT + c] = v;
-      }
+      const float u = wave_sum(s1[c]), v = wave_sum(s2[c]);
+      if (lane == 0) wave_unpivot(u, v, nw, piv[c], red[tid >> 6][c], red[tid >> 6][COUT + c]);
     }
     __syncthreads();
-    if (tid < 2 * COUT) {
-      double t = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
-      a.stats_partial[(size_t)blockIdx.x * 2 * COUT + tid] = t;
-    }
+    if (tid < 2 * COUT) a.stats_partial[(size_t)blockIdx.x * 2 * COUT + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   }
   if constexpr (BS != 0) {   // [block][3][COUT] doubles, the layout bn_bwd_final_kernel reads
     __shared__ double bred[4][3 * COUT];

@@ -113,8 +113,7 @@ int launch_tiled_deconv(const ursn_conv_desc& d, ConvPass pass, const float* in,
       a.stats_partial = (stats_partial && last) ? stats_partial : nullptr;
       URSN_TRY(p.mode == 3 ? tdeconv_dispatch_3d(p, a, s) : tdeconv_dispatch_2d(p, a, s));
       if (stats_partial && last)
-        URSN_TRY(launch_bn_stats_final(stats_partial, p.grid, b.pb, b.pb, V, eps, mean + b.pb * bp, rstd + b.pb * bp, s,
-                                       a.out, a.out_cs));
+        URSN_TRY(launch_bn_stats_final(stats_partial, p.grid, b.pb, b.pb, V, eps, mean + b.pb * bp, rstd + b.pb * bp, s));
     }
   if (b.nbk > 1 || b.nbp > 1) ursn_relabel_kernel("tdeconv xB");
   return 0;

@@ -93,9 +93,10 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
     }
   };
 
-  float s1[STATS ? CP : 1], s2[STATS ? CP : 1];
+  // BatchNorm moments around a wave-uniform pivot (wave_pivot.h): piv[] lives in SGPRs
+  float s1[STATS ? CP : 1], s2[STATS ? CP : 1], piv[STATS ? CP : 1];
 #pragma unroll
-  for (int c = 0; c < (STATS ? CP : 1); ++c) s1[c] = s2[c] = 0.f;
+  for (int c = 0; c < (STATS ? CP : 1); ++c) s1[c] = s2[c] = piv[c] = 0.f;
 
   // prologue: planes z0-1, z0  (ring slot of plane z = (z + 3) % 3)
   stage_load(z0 - 1);
@@ -144,6 +145,21 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
         });
       });
     });
+    if constexpr (STATS) {
+      if (z == z0 && a.stats_partial) {   // wave-uniform, once: the pivots = the first valid lane's parity-0 values of this plane
+        const int src = wave_first_valid(vox_ok);
+        if (src >= 0) {
+          const float* op = a.out + ((((size_t)n * (2 * a.Z) + 2 * z) * ((NTY == 3) ? 2 * a.Y : 1) + 2 * gy) * (2 * a.X) + 2 * gx) * a.out_cs;
+#pragma unroll
+          for (int cq = 0; cq < CQ; ++cq) {
+            f32x4 v = acc[0][cq];
+            if (a.accumulate && vox_ok) v += *(const f32x4*)(op + 4 * cq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) piv[4 * cq + j] = wave_lane_value(v[j], src);
+          }
+        }
+      }
+    }
     if (vox_ok) {
 #pragma unroll
       for (int c = 0; c < NCLS; ++c) {
@@ -160,8 +176,9 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
           if constexpr (STATS) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              s1[4 * cq + j] += v[j];
-              s2[4 * cq + j] += v[j] * v[j];
+              const float d = v[j] - piv[4 * cq + j];
+              s1[4 * cq + j] += d;
+              s2[4 * cq + j] = __builtin_fmaf(d, d, s2[4 * cq + j]);
             }
           }
         }
@@ -172,25 +189,15 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
   }
 
   if constexpr (STATS) if (a.stats_partial) {
-    __shared__ float red[4][2 * CP];
+    __shared__ double red[4][2 * CP];
+    const float nw = wave_sum(vox_ok ? (float)(NCLS * (z1 - z0)) : 0.f);   // produced voxels this wave summed
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
-      float u = s1[c], v = s2[c];
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        u += __shfl_xor(u, o);
-        v += __shfl_xor(v, o);
-      }
-      if (lane == 0) {
-        red[tid >> 6][c] = u;
-        red[tid >> 6][CP + c] = v;
-      }
+      const float u = wave_sum(s1[c]), v = wave_sum(s2[c]);
+      if (lane == 0) wave_unpivot(u, v, nw, piv[c], red[tid >> 6][c], red[tid >> 6][CP + c]);
     }
     __syncthreads();
-    if (tid < 2 * CP) {
-      double t = (double)red[0][tid] + (double)red[1][tid] + (double)red[2][tid] + (double)red[3][tid];
-      a.stats_partial[(size_t)blockIdx.x * 2 * CP + tid] = t;
-    }
+    if (tid < 2 * CP) a.stats_partial[(size_t)blockIdx.x * 2 * CP + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
   }
 }
 

@@ -159,17 +159,15 @@ __device__ inline void reduce_partials(const double* __restrict__ partial, int n
   for (int k = 0; k < NS; ++k) out[k] = sm[k][0];
 }
 
-// Partials come from the conv epilogues.  The implicit-GEMM / stride-2 kernels accumulate around per-lane pivots
-// (ursn_common.h: shifted one-pass moments) and are safe at any |mean| / std.  The lane-per-voxel kernels (tconv,
-// tdeconv, pconv) have no registers for pivots and write plain fp32-partial sums, whose  E[z^2] - E[z]^2  loses
-// mean^2 / var digits (measured: rstd off by 2e-5..2.5e-4 at |mean|/std = 1e2, 1e-2 at 1e3).  They pass z: when a
-// channel turns out ill-conditioned (mean^2 > 1e3 var: at most 3e-5 lost before this triggers) its variance is recomputed
-// here EXACTLY as TensorFlow does (two-pass around the mean).  Rare, so the strided walk
-// over one channel of z is acceptable; the well-conditioned case pays one compare.
+// Partials come from the conv epilogues, every one of which sums around pivots before it goes to fp64: per-lane pivots in
+// the implicit-GEMM / stride-2 / bf16 kernels (ursn_common.h: shifted one-pass moments), a wave-uniform pivot in SGPRs in
+// the lane-per-voxel kernels tconv, tdeconv, pconv (wave_pivot.h).  The fp64 sums that arrive here therefore carry only the fp32
+// rounding of centred values at any |mean| / std, and  E[z^2] - E[z]^2  in fp64 keeps 1e-16 * mean^2 / var: no second pass over z.
+// (Up to round 2 the lane-per-voxel kernels wrote plain fp32 sums and this kernel re-walked z with one block per channel
+// when a channel looked ill-conditioned -- which an all-zero event batch triggered on every layer, 1.9x the step time.)
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ partial, int nblocks, int PC,
                                                              int64_t V, float eps, float* __restrict__ mean,
-                                                             float* __restrict__ rstd, const float* __restrict__ z,
-                                                             int zcs, int CB, size_t blk_stride) {
+                                                             float* __restrict__ rstd, int CB, size_t blk_stride) {
   // CB > 0: the partials of channel block ct = c / CB start at partial + ct * blk_stride (kernels whose grid.y walks
   // blocks of produced channels): ONE launch finalises the whole layer (it took one per block: 174 instead of 58
   // launches per cfg3 step)
@@ -184,30 +182,6 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __res
   reduce_partials<2>(partial, nblocks, PC, cc, s);
   double mu = s[0] / (double)V;
   double var = s[1] / (double)V - mu * mu;   // every thread holds the same s[]
-  // s[1] == 0: every z of the channel is exactly 0 (an empty event batch, zero-padded inference) -- mean = var = 0 are exact
-  // already, and walking a whole 192^3 x 4 tensor with one block per channel here would stall every layer of such a step
-  if (z != nullptr && s[1] != 0.0 && !(var > 0.0 && mu * mu <= 1e3 * var)) {
-    __shared__ double sm2[2][256];
-    double d1 = 0.0, d2 = 0.0;
-    for (int64_t v = threadIdx.x; v < V; v += 256) {
-      const double d = (double)z[v * zcs + c] - mu;
-      d1 += d;
-      d2 += d * d;
-    }
-    sm2[0][threadIdx.x] = d1;
-    sm2[1][threadIdx.x] = d2;
-    __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-      if (threadIdx.x < st) {
-        sm2[0][threadIdx.x] += sm2[0][threadIdx.x + st];
-        sm2[1][threadIdx.x] += sm2[1][threadIdx.x + st];
-      }
-      __syncthreads();
-    }
-    const double dm = sm2[0][0] / (double)V;
-    var = sm2[1][0] / (double)V - dm * dm;
-    mu += dm;
-  }
   if (threadIdx.x != 0) return;
   if (var < 0.0) var = 0.0;
   mean[c] = (float)mu;
@@ -215,16 +189,15 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __res
 }
 
 int launch_bn_stats_final(const double* partial, int nblocks, int C, int PC, int64_t V, float eps, float* mean,
-                          float* rstd, hipStream_t s, const float* z, int zcs) {
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, partial, nblocks, PC, V, eps, mean, rstd, z, zcs, 0, (size_t)0);
+                          float* rstd, hipStream_t s) {
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, partial, nblocks, PC, V, eps, mean, rstd, 0, (size_t)0);
   URSN_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_bn_stats_final_blocked(const double* partial, int nblocks, int C, int CB, int PC, size_t blk_stride, int64_t V, float eps,
                                   float* mean, float* rstd, hipStream_t s) {
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, partial, nblocks, PC, V, eps, mean, rstd, (const float*)nullptr, 0,
-                     CB, blk_stride);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, partial, nblocks, PC, V, eps, mean, rstd, CB, blk_stride);
   URSN_HIP(hipGetLastError());
   return 0;
 }
@@ -239,7 +212,7 @@ int launch_bn_stats(const float* z, int zcs, int64_t V, int C, float eps, float*
   else hipLaunchKernelGGL(bn_stats_partial_kernel<1>, dim3(m.grid), dim3(256), 0, s, z, zcs, V, C, m.shift, partial);
   URSN_HIP(hipGetLastError());
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, (const double*)partial, m.grid, C, V, eps, mean,
-                     rstd, (const float*)nullptr, 0, 0, (size_t)0);   // bn_stats_partial sums in fp64: exact enough as is
+                     rstd, 0, (size_t)0);   // bn_stats_partial sums in fp64
   URSN_HIP(hipGetLastError());
   return 0;
 }

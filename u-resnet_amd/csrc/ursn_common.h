@@ -144,10 +144,9 @@ int reduce_nblocks(int64_t voxels, int channels);
 int launch_bn_stats(const float* z, int zcs, int64_t V, int C, float eps, float* mean, float* rstd,
                     void* scratch, hipStream_t s);
 // finalise [nblocks][2][C] double partials (as written by the conv epilogue) into mean/rstd
-// PC = channel stride of the partials (C padded to 4).  z != nullptr (producers with plain fp32 partial sums): channels
-// whose one-pass variance is ill-conditioned (mean^2 > 1e3 var) are recomputed two-pass from z (channel stride zcs)
+// PC = channel stride of the partials (C padded to 4).  Producers sum around pivots (wave_pivot.h / shifted moments below)
 int launch_bn_stats_final(const double* partial, int nblocks, int C, int PC, int64_t V, float eps, float* mean,
-                          float* rstd, hipStream_t s, const float* z = nullptr, int zcs = 0);
+                          float* rstd, hipStream_t s);
 // partials of channel block ct (CB channels each, PC columns per partial row) start at partial + ct * blk_stride: one launch for all blocks
 int launch_bn_stats_final_blocked(const double* partial, int nblocks, int C, int CB, int PC, size_t blk_stride, int64_t V, float eps,
                                   float* mean, float* rstd, hipStream_t s);
