@@ -67,6 +67,7 @@ SWITCHES = [
     ("fp32", {"URSN_FUSE_BN_BWD_REDUCE": "0", "URSN_FUSE_SHORTCUT_DGRAD": "0", "URSN_RELU_MASK": "0"}),
     ("fp32", {"URSN_SPLIT_CAT": "0", "URSN_NORM_ON_LOAD": "1"}),
     ("fp32", {"URSN_DISABLE_TILED": "1", "URSN_WGRAD_STREAM": "0"}),
+    ("fp32", {"URSN_WGRADQ": "1", "URSN_NORM_ON_LOAD": "1"}),   # 4x4-block weight gradient at level 0 (opt-in, wgradq_tiled_kernel.h)
 ]
 
 

@@ -11,6 +11,7 @@
 #include "conv_tiled_kernel.h"
 #include "wgrad_tiled_kernel.h"
 
+int twgradq_dispatch(const TWPlan& p, const TWgradArgs& a, hipStream_t s);
 int twgrad4_dispatch_3d(const TWPlan& p, const TWgradArgs& a, hipStream_t s);
 int twgrad4_dispatch_2d(const TWPlan& p, const TWgradArgs& a, hipStream_t s);
 int twgradz_dispatch(const TWPlan& p, const TWgradArgs& a, hipStream_t s);
@@ -284,6 +285,14 @@ static bool use_wgradz(const ursn_conv_desc& d) {  // Cout == 8: plane-pair kern
   return v == 1 && d.cout == 8 && (d.cin == 8 || d.cin == 16);
 }
 
+// 3-D Cout == 8: 4x4-block kernel, no padded MFMA rows (wgradq_tiled_kernel.h).  Measured equal to the plane-pair kernel
+// (1.24 vs 1.225 ms at 192^3 x 4), so it is opt-in: URSN_WGRADQ=1
+static bool use_wgradq(const ursn_conv_desc& d) {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("URSN_WGRADQ"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1 && d.ndim == 3 && use_wgradz(d);
+}
+
 static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
   if (tiled_disabled() && d.algo != 3) return false;
   if (d.transposed || d.k != 3 || d.stride != 1) return false;
@@ -320,18 +329,20 @@ static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
     }
     const int py = ty + (p.mode == 3 ? 2 : 0);
     p.lds = ((size_t)6 * PX * py * 8 + (size_t)4 * TX * ty * 8) * sizeof(float) + 256;
+    if (use_wgradq(d)) p.lds = ((size_t)4 * 6 * 8 * 48 + (size_t)2 * 4 * 8 * 48) * sizeof(float);   // QTile::LDS: 4 x planes, 2 dz planes, channel-major rows of 48
     vg = 2;
   } else if (!blocked_shape && use_wgrad4(d, p)) vg = 2;
   {  // the per-wave accumulator copies of the final cross-wave sum reuse the plane rings
     const int taps = p.mode == 3 ? 27 : 9;
-    size_t red = use_wgradz(d) ? (size_t)(p.mode == 3 ? 4 : 8) * 2 * taps * 64 * sizeof(float)
-                               : (size_t)4 * taps * p.cin * p.cout * sizeof(float);
+    size_t red = use_wgradq(d) ? 0
+                 : use_wgradz(d) ? (size_t)(p.mode == 3 ? 4 : 8) * 2 * taps * 64 * sizeof(float)
+                                 : (size_t)4 * taps * p.cin * p.cout * sizeof(float);
     if (red > p.lds) p.lds = red;
   }
   if (p.lds > 160 * 1024) return false;
   if (d.in_mean && (blocked_shape || (!use_wgradz(d) && use_wgrad4(d, p)))) return false;   // kernels without the staging affine
   ursn_pick_zseg(p.grid, p.Z, occ_limit(vg, p.lds), 8, p.zseg, p.nzseg);
-  if (use_wgradz(d)) {
+  if (use_wgradz(d) && !use_wgradq(d)) {
     static const int force_nz = getenv("URSN_WGRADZ_NZ") ? atoi(getenv("URSN_WGRADZ_NZ")) : 0;   // A/B
     if (force_nz > 0) { p.zseg = (p.Z + force_nz - 1) / force_nz; p.nzseg = (p.Z + p.zseg - 1) / p.zseg; }
     if ((p.zseg & 1) && p.nzseg > 1) { p.zseg += 1; p.nzseg = (p.Z + p.zseg - 1) / p.zseg; }   // plane pairs
@@ -352,6 +363,7 @@ size_t tiled_wgrad_scratch_bytes(const ursn_conv_desc& d) {
   if (!make_wplan(d, p, b)) return 0;
   int taps = d.ndim == 3 ? 27 : 9;
   int ci = (b.nbi > 1 || b.nbo > 1) ? 16 : d.cin, co = (b.nbi > 1 || b.nbo > 1) ? 16 : d.cout;
+  if (use_wgradq(d)) return (size_t)p.grid * taps * 8 * 8 * sizeof(float);
   if (use_wgradz(d)) return (size_t)p.grid * 2 * taps * 8 * 8 * sizeof(float);   // two slabs per workgroup
   return (size_t)p.grid * taps * ci * co * sizeof(float);   // one slab per workgroup
 }
@@ -385,10 +397,12 @@ int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy,
         a.x = d.x2;
         a.x_cs = d.in2_cstride > 0 ? d.in2_cstride : d.cin - d.in_split;
       }
-      URSN_TRY(twgradz_dispatch(p, a, s));
-      if (d.cin == 8) return launch_reduce_accum(dw, (const float*)scratch, (int64_t)taps * 64, p.grid * 2, s);
+      const bool quad = use_wgradq(d);
+      const int nslab = quad ? p.grid : p.grid * 2;
+      URSN_TRY(quad ? twgradq_dispatch(p, a, s) : twgradz_dispatch(p, a, s));
+      if (d.cin == 8) return launch_reduce_accum(dw, (const float*)scratch, (int64_t)taps * 64, nslab, s);
       URSN_TRY(launch_reduce_accum_blocked(dw + (size_t)8 * bi * 8, (const float*)scratch, taps, 8, 8, (int64_t)d.cin * 8,
-                                           8, p.grid * 2, s));
+                                           8, nslab, s));
     }
     return 0;
   }
