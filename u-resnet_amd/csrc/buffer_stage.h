@@ -1,0 +1,21 @@
+// Buffer-instruction staging loads for the z-marching tiled kernels -- gfx950.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// Staging loads go through buffer instructions: out-of-range elements (image border, planes outside the volume) come back
+// as 0 from the hardware bounds check instead of a zero fill + exec-masked branch per element -- on this SIMD every
+// instruction issued costs the matrix pipe ~4.6 cycles (tools/micro/mfma_rate.hip), and those were a third of the staging code.
+// One resource per z plane: num_records = 0 makes the whole plane read as zeros.
+#define URSN_OOB_OFFSET 0x80000000u   // byte offset of an element outside the tile's image footprint: beyond any plane
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ursn_plane_rsrc(const float* plane, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(plane), 0, bytes, 0x00020000);
+}
+typedef float wgb_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wgb_u32x4 __attribute__((ext_vector_type(4)));
+// (the z plane cannot go into the scalar offset with num_records = one plane: measured, planes z > 0 then read as zeros)
+__device__ __forceinline__ wgb_f32x4 ursn_buffer_load_f4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(wgb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ float ursn_buffer_load_f1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}

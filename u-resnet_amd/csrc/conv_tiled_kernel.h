@@ -24,6 +24,7 @@
 
 #include "ursn_common.h"
 #include "wave_pivot.h"
+#include "buffer_stage.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -75,6 +76,11 @@ template <int MODE> struct Tile;
 template <> struct Tile<3> { static constexpr int TX = 32, TY = 8, NTY = 3, NT = 27; };
 template <> struct Tile<2> { static constexpr int TX = 256, TY = 1, NTY = 1, NT = 9; };
 
+// partial accumulators per produced channel quad, used round-robin along the contraction.  Two for a single quad (the 3|4-
+// channel logits layer would otherwise be ONE chain of dependent MFMAs); one otherwise: 4 / 2 per quad (>= 8 independent
+// chains, no s_nop between MFMAs) measured the same at 8 -> 8 and 15 % slower at 16 -> 16 (registers, occupancy 3 -> 2)
+template <int CQ, int BS> struct TConvAcc { static constexpr int N = CQ == 1 ? 2 : 1; };
+
 // CIN = contraction channels, COUT = produced channels (already swapped for the data gradient).
 template <int CIN, int COUT, int MODE, bool FLIP, bool AFF = false, int BS = 0>
 __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kernel(TConvArgs a) {
@@ -86,6 +92,13 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
   constexpr int NQ = CIN / 4, CQ = COUT / 4;
   constexpr int KTOT = NT * CIN, R = (KTOT + 15) / 16;
   constexpr int NSTAGE = (NQ * PS + 255) / 256;
+  constexpr int NACC = TConvAcc<CQ, BS>::N;
+  auto acc_sum = [](const f32x4 (&p)[NACC]) {
+    f32x4 v = p[0];
+#pragma unroll
+    for (int i = 1; i < NACC; ++i) v += p[i];
+    return v;
+  };
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];  // [4 ring slots][NQ][PS]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -156,26 +169,38 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
   }
 
   // ---- plane staging --------------------------------------------------------------------------------------
+  // Loads go through buffer instructions (buffer_stage.h): byte offsets inside a z plane are tabulated once (pinned in
+  // registers -- as plain arithmetic on tid the compiler re-derives them every plane), elements outside the image carry
+  // URSN_OOB_OFFSET and a plane outside the volume gets num_records = 0: both read as 0 without a branch or a zero fill.
   f32x4 stage[NSTAGE];
   unsigned stage_inb = 0;   // which staged elements are real voxels (the affine must not touch the zero padding)
-  auto stage_load = [&](int zin) {
-    stage_inb = 0;
+  unsigned soff[NSTAGE], sin_mask = 0;
 #pragma unroll
-    for (int i = 0; i < NSTAGE; ++i) {
-      int idx = tid + i * 256;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < NQ * PS) {
-        int q = idx / PS, s = idx - q * PS;
-        int yy = s / PX, xx = s - yy * PX;
-        int py = y0 + yy - (NTY == 3 ? 1 : 0), px = x0 + xx - 1;
-        if (zin >= 0 && zin < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X) {
-          const float* src = a.in + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.in_cs + 4 * q;
-          if (a.cin_w == 1 && !FLIP) v[0] = *src;   // single-channel input (conv0): scalar fetch, lanes 1..3 stay 0
-          else v = *(const f32x4*)src;
-          if constexpr (aff) stage_inb |= 1u << i;
-        }
-      }
-      stage[i] = v;
+  for (int i = 0; i < NSTAGE; ++i) {
+    const int idx = tid + i * 256;
+    const int q = idx / PS, s = idx - q * PS;
+    const int yy = s / PX, xx = s - yy * PX;
+    const int py = y0 + yy - (NTY == 3 ? 1 : 0), px = x0 + xx - 1;
+    const bool ok = idx < NQ * PS && py >= 0 && py < a.Y && px >= 0 && px < a.X;
+    soff[i] = ok ? (unsigned)((py * a.X + px) * a.in_cs + 4 * q) * 4u : URSN_OOB_OFFSET;
+    if (ok) sin_mask |= 1u << i;
+    asm volatile("" : "+v"(soff[i]));
+  }
+  asm volatile("" : "+v"(sin_mask));
+  const ptrdiff_t in_plane = (ptrdiff_t)a.Y * a.X * a.in_cs;
+  const unsigned in_plane_bytes = (unsigned)in_plane * 4u;
+  const float* in_img = a.in + (size_t)n * a.Z * in_plane;
+  const bool scalar_in = a.cin_w == 1 && !FLIP;   // single-channel input (conv0): scalar fetch, lanes 1..3 stay 0
+  auto stage_load = [&](int zin) {
+    const bool zok = zin >= 0 && zin < a.Z;
+    if constexpr (aff) stage_inb = zok ? sin_mask : 0u;
+    const __amdgpu_buffer_rsrc_t r = ursn_plane_rsrc(in_img + (ptrdiff_t)zin * in_plane, zok ? in_plane_bytes : 0u);
+    if (scalar_in) {
+#pragma unroll
+      for (int i = 0; i < NSTAGE; ++i) stage[i] = (f32x4){ursn_buffer_load_f1(r, soff[i]), 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+      for (int i = 0; i < NSTAGE; ++i) stage[i] = ursn_buffer_load_f4(r, soff[i]);
     }
   };
   auto stage_store = [&](int slot) {
@@ -216,12 +241,11 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
   const int lane_slot = ty * PX + tx;  // top-left of the lane's 3x3 window in a plane
   for (int z = z0; z < z1; ++z) {
     stage_load(z + 2);
-    f32x4 acc[CQ];
+    f32x4 acc[CQ][NACC];   // NACC partial accumulators per quad (TConvAcc)
 #pragma unroll
-    for (int cq = 0; cq < CQ; ++cq) acc[cq] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // one produced channel quad (the 3|4-channel logits layer) would be a single chain of dependent MFMAs: split the
-    // contraction over a second accumulator
-    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+    for (int cq = 0; cq < CQ; ++cq)
+#pragma unroll
+      for (int p = 0; p < NACC; ++p) acc[cq][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 pv[(FLIP && CIN <= 16) ? NQ : 1];
     if constexpr (FLIP && CIN <= 16) {
       if (a.pw_in) {  // this lane's voxel of the shortcut gradient (clamped for out-of-range lanes: MFMA needs all lanes)
@@ -272,10 +296,7 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
             }
             static_for<CQ>([&](auto C) {
               constexpr int cq = decltype(C)::value;
-              if constexpr (CQ == 1 && (k & 1))
-                acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[cq][k / 16], xv[j], acc2, 4, k % 16, 0);
-              else
-                acc[cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[cq][k / 16], xv[j], acc[cq], 4, k % 16, 0);
+              acc[cq][k % NACC] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[cq][k / 16], xv[j], acc[cq][k % NACC], 4, k % 16, 0);
             });
           });
         });
@@ -287,7 +308,7 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
           constexpr int k = decltype(K)::value;
           static_for<CQ>([&](auto C) {
             constexpr int cq = decltype(C)::value;
-            acc[cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wpw[cq], pv[k / 4][k % 4], acc[cq], 4, k, 0);
+            acc[cq][k % NACC] = __builtin_amdgcn_mfma_f32_4x4x1f32(wpw[cq], pv[k / 4][k % 4], acc[cq][k % NACC], 4, k, 0);
           });
         });
       }
@@ -299,8 +320,7 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
           const float* op = a.out + ((((size_t)n * a.Z + z) * a.Y + gy) * a.X + gx) * a.out_cs;
 #pragma unroll
           for (int cq = 0; cq < CQ; ++cq) {
-            f32x4 v = acc[cq];
-            if constexpr (CQ == 1) v += acc2;
+            f32x4 v = acc_sum(acc[cq]);
             if (a.accumulate && vox_ok) v += *(const f32x4*)(op + 4 * cq);
 #pragma unroll
             for (int j = 0; j < 4; ++j) piv[4 * cq + j] = wave_lane_value(v[j], src);
@@ -312,8 +332,7 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
       float* op = a.out + ((((size_t)n * a.Z + z) * a.Y + gy) * a.X + gx) * a.out_cs;
 #pragma unroll
       for (int cq = 0; cq < CQ; ++cq) {
-        f32x4 v = acc[cq];
-        if constexpr (CQ == 1) v += acc2;
+        f32x4 v = acc_sum(acc[cq]);
         if constexpr (BS != 0) {
           if (a.accumulate) v += bold[cq];
         } else {

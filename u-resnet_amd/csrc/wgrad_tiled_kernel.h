@@ -16,6 +16,7 @@
 #include <utility>
 
 #include "ursn_common.h"
+#include "buffer_stage.h"
 
 typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
 

@@ -22,7 +22,8 @@ template <int MODE> struct ZTile;
 template <> struct ZTile<3> { static constexpr int TX = 32, TY = 4, NTY = 3, NT = 27, NW = 4; };
 template <> struct ZTile<2> { static constexpr int TX = 256, TY = 1, NTY = 1, NT = 9, NW = 8; };
 
-template <int MODE>
+// AFF: normalise-on-load of x compiled in (a.aff_* set); the plain instantiation carries none of its selects and branches
+template <int MODE, bool AFF>
 __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgradArgs a) {
   constexpr int CIN = 8, COUT = 8;
   using TL = ZTile<MODE>;
@@ -63,9 +64,9 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
 
   // normalise-on-load of x: this thread always stages channel quad (tid & 1)
   __shared__ wg_f32x4 aff_st[2 * XQ];
-  const bool aff = a.aff_mean != nullptr;
+  constexpr bool aff = AFF;
   wg_f32x4 aff_s4 = {1.f, 1.f, 1.f, 1.f}, aff_t4 = {0.f, 0.f, 0.f, 0.f};
-  if (aff) {
+  if constexpr (aff) {
     if (tid < CIN) {
       const float r = a.aff_rstd[tid];
       ((float*)aff_st)[tid] = r;
@@ -77,16 +78,17 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
     aff_t4 = aff_st[XQ + (tid & 1)];
   }
   // staging tables: the tile's (y, x) footprint is the same for every plane, only the plane base moves
-  int xgo[NSX], dgo[NSD];
-  bool xok[NSX], dok[NSD];
+  // byte offsets inside a z plane; elements outside the image carry URSN_OOB_OFFSET and read as 0 (wgrad_tiled_kernel.h)
+  unsigned xgo[NSX], dgo[NSD], xin = 0;
 #pragma unroll
   for (int i = 0; i < NSX; ++i) {
     int idx = tid + i * NTHR;
     int sl = idx / XQ, q = idx - sl * XQ;
     int yy = sl / PX, xx = sl - yy * PX;
     int py = y0 + yy - (NTY == 3 ? 1 : 0), px = x0 + xx - 1;
-    xok[i] = idx < XQ * PS && py >= 0 && py < a.Y && px >= 0 && px < a.X;
-    xgo[i] = (py * a.X + px) * a.x_cs + 4 * q;
+    const bool ok = idx < XQ * PS && py >= 0 && py < a.Y && px >= 0 && px < a.X;
+    xgo[i] = ok ? (unsigned)((py * a.X + px) * a.x_cs + 4 * q) * 4u : URSN_OOB_OFFSET;
+    if (ok) xin |= 1u << i;
   }
 #pragma unroll
   for (int i = 0; i < NSD; ++i) {
@@ -94,50 +96,53 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
     int sl = idx / DQ, q = idx - sl * DQ;
     int yy = sl / TX, xx = sl - yy * TX;
     int py = y0 + yy, px = x0 + xx;
-    dok[i] = idx < DQ * TX * TY && py < a.Y && px < a.X;
-    dgo[i] = (py * a.X + px) * a.dz_cs + 4 * q;
+    const bool ok = idx < DQ * TX * TY && py < a.Y && px < a.X;
+    dgo[i] = ok ? (unsigned)((py * a.X + px) * a.dz_cs + 4 * q) * 4u : URSN_OOB_OFFSET;
   }
+  // pin the tables in registers: as plain arithmetic on tid the compiler re-derives them inside the z loop (+200 instructions)
+#pragma unroll
+  for (int i = 0; i < NSX; ++i) asm volatile("" : "+v"(xgo[i]));
+#pragma unroll
+  for (int i = 0; i < NSD; ++i) asm volatile("" : "+v"(dgo[i]));
+  asm volatile("" : "+v"(xin));
+  // one resource per z plane (num_records = 0 for a plane outside the volume); inside the loop the plane pointers advance by
+  // two planes per step instead of being rebuilt from (n, z) with 64-bit multiplies
+  const unsigned xplane_bytes = (unsigned)a.Y * a.X * a.x_cs * 4u, dplane_bytes = (unsigned)a.Y * a.X * a.dz_cs * 4u;
+  const ptrdiff_t xplane_floats = (ptrdiff_t)a.Y * a.X * a.x_cs, dplane_floats = (ptrdiff_t)a.Y * a.X * a.dz_cs;
+  const float* ximg = a.x + (size_t)n * a.Z * a.Y * a.X * a.x_cs;
+  const float* dimg = a.dz + (size_t)n * a.Z * a.Y * a.X * a.dz_cs;
 
   wg_f32x4 acc[NA];
 #pragma unroll
   for (int m = 0; m < NA; ++m) acc[m] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto xslot = [](int p) { return (p + 6) % 6; };
+  // x ring: plane p sits at float offset ((p + 6) % 6) * XPLANE.  The mod is taken once (z0 - 1); inside the loop the four
+  // live offsets rotate through scalar registers (add, compare, select) instead of a divide-by-6 chain per plane
+  auto xnext = [](int off) { return off + XPLANE == 6 * XPLANE ? 0 : off + XPLANE; };
   auto load_x = [&](int zin, wg_f32x4 (&sx)[NSX], unsigned& inb) {
     const bool zok = zin >= 0 && zin < a.Z;
-    inb = 0;
-    const float* base = a.x + ((size_t)n * a.Z + (zok ? zin : 0)) * a.Y * a.X * a.x_cs;
+    inb = zok ? xin : 0u;
+    const __amdgpu_buffer_rsrc_t r = ursn_plane_rsrc(ximg + (ptrdiff_t)zin * xplane_floats, zok ? xplane_bytes : 0u);
 #pragma unroll
-    for (int i = 0; i < NSX; ++i) {
-      wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (zok && xok[i]) {
-        v = *(const wg_f32x4*)(base + xgo[i]);
-        inb |= 1u << i;
-      }
-      sx[i] = v;
-    }
+    for (int i = 0; i < NSX; ++i) sx[i] = ursn_buffer_load_f4(r, xgo[i]);
   };
-  auto store_x = [&](int zin, const wg_f32x4 (&sx)[NSX], unsigned inb) {
+  auto store_x = [&](int slot_off, const wg_f32x4 (&sx)[NSX], unsigned inb) {
 #pragma unroll
     for (int i = 0; i < NSX; ++i) {
       int idx = tid + i * NTHR;
       if (idx < XQ * PS) {
         wg_f32x4 v = sx[i];
-        if (aff && ((inb >> i) & 1u)) v = v * aff_s4 + aff_t4;   // normalise-on-load, applied at the store: loads stay in flight
-        *(wg_f32x4*)(xr + (size_t)xslot(zin) * XPLANE + idx * 4) = v;
+        if constexpr (aff) if ((inb >> i) & 1u) v = v * aff_s4 + aff_t4;   // normalise-on-load, applied at the store: loads stay in flight
+        *(wg_f32x4*)(xr + slot_off + idx * 4) = v;
       }
     }
   };
 
   auto load_d = [&](int zin, wg_f32x4 (&sd)[NSD]) {
     const bool zok = zin < z1;
-    const float* base = a.dz + ((size_t)n * a.Z + (zok ? zin : 0)) * a.Y * a.X * a.dz_cs;
+    const __amdgpu_buffer_rsrc_t r = ursn_plane_rsrc(dimg + (ptrdiff_t)zin * dplane_floats, zok ? dplane_bytes : 0u);
 #pragma unroll
-    for (int i = 0; i < NSD; ++i) {
-      wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (zok && dok[i]) v = *(const wg_f32x4*)(base + dgo[i]);
-      sd[i] = v;
-    }
+    for (int i = 0; i < NSD; ++i) sd[i] = ursn_buffer_load_f4(r, dgo[i]);
   };
   auto store_d = [&](int zin, const wg_f32x4 (&sd)[NSD]) {
 #pragma unroll
@@ -149,9 +154,14 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
 
   wg_f32x4 sxa[NSX], sxb[NSX], sda[NSD], sdb[NSD];
   unsigned inba = 0, inbb = 0;
+  int sb[4];   // offsets of planes z - 1 .. z + 2
+  sb[0] = ((z0 + 5) % 6) * XPLANE;
+#pragma unroll
+  for (int j = 1; j < 4; ++j) sb[j] = xnext(sb[j - 1]);
+#pragma unroll
   for (int p = -1; p <= 2; ++p) {
     load_x(z0 + p, sxa, inba);
-    store_x(z0 + p, sxa, inba);
+    store_x(sb[p + 1], sxa, inba);
   }
   for (int p = 0; p <= 1; ++p) {
     load_d(z0 + p, sda);
@@ -166,9 +176,7 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
     load_d(z + 3, sdb);
     // ring slot bases of the 4 x planes of this step (uniform); tile m's two taps sit in plane (2m)/(3 NTY) and
     // (2m+1)/(3 NTY) -- known at compile time, so a tile costs one add (or select + add where the pair straddles)
-    int sb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sb[j] = xslot(z - 1 + j) * XPLANE;
+    const int sb4 = xnext(sb[3]), sb5 = xnext(sb4);   // where planes z + 3, z + 4 go
     int abase[NA];
     wg_static_for<NA>([&](auto M) {
       constexpr int m = decltype(M)::value;
@@ -197,10 +205,11 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
 #endif
-    store_x(z + 3, sxa, inba);
-    store_x(z + 4, sxb, inbb);
+    store_x(sb4, sxa, inba);
+    store_x(sb5, sxb, inbb);
     store_d(z + 2, sda);
     store_d(z + 3, sdb);
+    sb[0] = sb[2]; sb[1] = sb[3]; sb[2] = sb4; sb[3] = sb5;
     __syncthreads();
   }
 
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
 
 template <int MODE>
 static int launch_twz(const TWPlan& p, const TWgradArgs& a, hipStream_t s) {
-  auto kern = twgradz_kernel<MODE>;
+  auto kern = a.aff_mean ? twgradz_kernel<MODE, true> : twgradz_kernel<MODE, false>;
   static size_t attr_lds = 48 * 1024;
   if (p.lds > attr_lds) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
