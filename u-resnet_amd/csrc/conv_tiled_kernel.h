@@ -77,8 +77,9 @@ template <> struct Tile<3> { static constexpr int TX = 32, TY = 8, NTY = 3, NT =
 template <> struct Tile<2> { static constexpr int TX = 256, TY = 1, NTY = 1, NT = 9; };
 
 // partial accumulators per produced channel quad, used round-robin along the contraction.  Two for a single quad (the 3|4-
-// channel logits layer would otherwise be ONE chain of dependent MFMAs); one otherwise: 4 / 2 per quad (>= 8 independent
-// chains, no s_nop between MFMAs) measured the same at 8 -> 8 and 15 % slower at 16 -> 16 (registers, occupancy 3 -> 2)
+// channel logits layer would otherwise be ONE chain of dependent MFMAs); one otherwise: 2 or 4 per quad remove the
+// s_nop between dependent MFMAs (148 per plane at 8 -> 8) but measure the same at 8 -> 8 and 15 % slower at 16 -> 16
+// (registers, occupancy) -- the nops sit in the shadow of the previous MFMA
 template <int CQ, int BS> struct TConvAcc { static constexpr int N = CQ == 1 ? 2 : 1; };
 
 // CIN = contraction channels, COUT = produced channels (already swapped for the data gradient).
@@ -239,7 +240,11 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
   __syncthreads();
 
   const int lane_slot = ty * PX + tx;  // top-left of the lane's 3x3 window in a plane
-  for (int z = z0; z < z1; ++z) {
+  // the lane's voxel index in plane z, carried through the loop (rebuilt from (n, z, y, x) it costs a chain of 64-bit
+  // multiplies per plane); lanes outside the image never dereference it
+  const size_t plane_vox = (size_t)a.Y * a.X;
+  size_t zvox = (((size_t)n * a.Z + z0) * a.Y + gy) * a.X + gx;
+  for (int z = z0; z < z1; ++z, zvox += plane_vox) {
     stage_load(z + 2);
     f32x4 acc[CQ][NACC];   // NACC partial accumulators per quad (TConvAcc)
 #pragma unroll
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
     if constexpr (FLIP && CIN <= 16) {
       if (a.pw_in) {  // this lane's voxel of the shortcut gradient (clamped for out-of-range lanes: MFMA needs all lanes)
         const int cy = gy < a.Y ? gy : a.Y - 1, cx = gx < a.X ? gx : a.X - 1;
-        const float* pp = a.pw_in + ((((size_t)n * a.Z + z) * a.Y + cy) * a.X + cx) * a.pw_in_cs;
+        const float* pp = a.pw_in + (zvox - (size_t)(gy - cy) * a.X - (size_t)(gx - cx)) * a.pw_in_cs;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) pv[q] = *(const f32x4*)(pp + 4 * q);
       }
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
     unsigned bmw[BS ? 4 : 1], bvlo = 0;
     if constexpr (BS != 0) {
       if (vox_ok) {
-        const size_t vox = (((size_t)n * a.Z + z) * a.Y + gy) * a.X + gx;
+        const size_t vox = zvox;
 #pragma unroll
         for (int cq = 0; cq < CQ; ++cq) {
           bz[cq] = *(const f32x4*)(a.bs_z + vox * a.bs_z_cs + 4 * cq);
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
       if (z == z0 && a.stats_partial) {   // wave-uniform, once: the pivots = the first valid lane's values of this plane
         const int src = wave_first_valid(vox_ok);
         if (src >= 0) {
-          const float* op = a.out + ((((size_t)n * a.Z + z) * a.Y + gy) * a.X + gx) * a.out_cs;
+          const float* op = a.out + zvox * a.out_cs;
 #pragma unroll
           for (int cq = 0; cq < CQ; ++cq) {
             f32x4 v = acc_sum(acc[cq]);
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
       }
     }
     if (vox_ok) {
-      float* op = a.out + ((((size_t)n * a.Z + z) * a.Y + gy) * a.X + gx) * a.out_cs;
+      float* op = a.out + zvox * a.out_cs;
 #pragma unroll
       for (int cq = 0; cq < CQ; ++cq) {
         f32x4 v = acc_sum(acc[cq]);

@@ -69,21 +69,27 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
       }
   }
 
+  // staging through buffer loads (buffer_stage.h): tabulated byte offsets, out-of-range elements read as 0
   f32x4 stage[NSTAGE];
-  auto stage_load = [&](int zin) {
+  unsigned soff[NSTAGE];
 #pragma unroll
-    for (int i = 0; i < NSTAGE; ++i) {
-      int idx = tid + i * 256;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < NQ * PS) {
-        int q = idx / PS, s = idx - q * PS;
-        int yy = s / PX, xx = s - yy * PX;
-        int py = y0 + yy - HY, px = x0 + xx - 1;
-        if (zin >= 0 && zin < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
-          v = *(const f32x4*)(a.in + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.in_cs + 4 * q);
-      }
-      stage[i] = v;
-    }
+  for (int i = 0; i < NSTAGE; ++i) {
+    const int idx = tid + i * 256;
+    const int q = idx / PS, s = idx - q * PS;
+    const int yy = s / PX, xx = s - yy * PX;
+    const int py = y0 + yy - HY, px = x0 + xx - 1;
+    const bool ok = idx < NQ * PS && py >= 0 && py < a.Y && px >= 0 && px < a.X;
+    soff[i] = ok ? (unsigned)((py * a.X + px) * a.in_cs + 4 * q) * 4u : URSN_OOB_OFFSET;
+    asm volatile("" : "+v"(soff[i]));
+  }
+  const ptrdiff_t in_plane = (ptrdiff_t)a.Y * a.X * a.in_cs;
+  const unsigned in_plane_bytes = (unsigned)in_plane * 4u;
+  const float* in_img = a.in + (size_t)n * a.Z * in_plane;
+  auto stage_load = [&](int zin) {
+    const bool zok = zin >= 0 && zin < a.Z;
+    const __amdgpu_buffer_rsrc_t r = ursn_plane_rsrc(in_img + (ptrdiff_t)zin * in_plane, zok ? in_plane_bytes : 0u);
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) stage[i] = ursn_buffer_load_f4(r, soff[i]);
   };
   auto stage_store = [&](int slot) {
 #pragma unroll

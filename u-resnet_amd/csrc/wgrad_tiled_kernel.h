@@ -112,26 +112,44 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
     }
     __syncthreads();
   }
+  // staging through buffer loads (buffer_stage.h): tabulated byte offsets, out-of-range elements read as 0
   wg_f32x4 sx[NSX], sd[NSD];
   unsigned sx_inb = 0;   // staged x elements that are real voxels
+  unsigned xgo[NSX], dgo[NSD], xin_mask = 0;
+#pragma unroll
+  for (int i = 0; i < NSX; ++i) {
+    const int idx = tid + i * 256;
+    const int s = idx / XQ, q = idx - s * XQ;
+    const int yy = s / PX, xx = s - yy * PX;
+    const int py = y0 + yy - (NTY == 3 ? 1 : 0), px = x0 + xx - 1;
+    const bool ok = idx < XQ * PS && py >= 0 && py < a.Y && px >= 0 && px < a.X;
+    xgo[i] = ok ? (unsigned)((py * a.X + px) * a.x_cs + 4 * q) * 4u : URSN_OOB_OFFSET;
+    if (ok) xin_mask |= 1u << i;
+    asm volatile("" : "+v"(xgo[i]));
+  }
+  asm volatile("" : "+v"(xin_mask));
+#pragma unroll
+  for (int i = 0; i < NSD; ++i) {
+    const int idx = tid + i * 256;
+    const int s = idx / DQ, q = idx - s * DQ;
+    const int yy = s / TX, xx = s - yy * TX;
+    const int py = y0 + yy, px = x0 + xx;
+    const bool ok = idx < DQ * TX * TY && py < a.Y && px < a.X;
+    dgo[i] = ok ? (unsigned)((py * a.X + px) * a.dz_cs + 4 * q) * 4u : URSN_OOB_OFFSET;
+    asm volatile("" : "+v"(dgo[i]));
+  }
+  const ptrdiff_t xplane_f = (ptrdiff_t)a.Y * a.X * a.x_cs, dplane_f = (ptrdiff_t)a.Y * a.X * a.dz_cs;
+  const unsigned xplane_b = (unsigned)xplane_f * 4u, dplane_b = (unsigned)dplane_f * 4u;
+  const float* ximg = a.x + (size_t)n * a.Z * xplane_f;
+  const float* dimg = a.dz + (size_t)n * a.Z * dplane_f;
   auto load_x = [&](int zin) {
-    sx_inb = 0;
+    const bool zok = zin >= 0 && zin < a.Z;
+    sx_inb = zok ? xin_mask : 0u;
+    const __amdgpu_buffer_rsrc_t r = ursn_plane_rsrc(ximg + (ptrdiff_t)zin * xplane_f, zok ? xplane_b : 0u);
 #pragma unroll
     for (int i = 0; i < NSX; ++i) {
-      int idx = tid + i * 256;
-      wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < XQ * PS) {
-        int s = idx / XQ, q = idx - s * XQ;
-        int yy = s / PX, xx = s - yy * PX;
-        int py = y0 + yy - (NTY == 3 ? 1 : 0), px = x0 + xx - 1;
-        if (zin >= 0 && zin < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X) {
-          const float* src = a.x + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.x_cs + 4 * q;
-          if (CIN == 1) v[0] = *src;
-          else v = *(const wg_f32x4*)src;
-          sx_inb |= 1u << i;
-        }
-      }
-      sx[i] = v;
+      if constexpr (CIN == 1) sx[i] = (wg_f32x4){ursn_buffer_load_f1(r, xgo[i]), 0.f, 0.f, 0.f};
+      else sx[i] = ursn_buffer_load_f4(r, xgo[i]);
     }
   };
   auto store_x = [&](int slot) {
@@ -149,19 +167,10 @@ __global__ __launch_bounds__(256, 1) void twgrad_kernel(TWgradArgs a) {
     }
   };
   auto load_d = [&](int zin) {
+    const bool zok = zin < z1;
+    const __amdgpu_buffer_rsrc_t r = ursn_plane_rsrc(dimg + (ptrdiff_t)zin * dplane_f, zok ? dplane_b : 0u);
 #pragma unroll
-    for (int i = 0; i < NSD; ++i) {
-      int idx = tid + i * 256;
-      wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < DQ * TX * TY) {
-        int s = idx / DQ, q = idx - s * DQ;
-        int yy = s / TX, xx = s - yy * TX;
-        int py = y0 + yy, px = x0 + xx;
-        if (zin < z1 && py < a.Y && px < a.X)
-          v = *(const wg_f32x4*)(a.dz + ((((size_t)n * a.Z + zin) * a.Y + py) * a.X + px) * a.dz_cs + 4 * q);
-      }
-      sd[i] = v;
-    }
+    for (int i = 0; i < NSD; ++i) sd[i] = ursn_buffer_load_f4(r, dgo[i]);
   };
   auto store_d = [&](int slot) {
 #pragma unroll
