@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "bf16_common.h"
+#include "buffer_stage.h"
 
 namespace {
 
@@ -104,23 +105,29 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) A[m][mt] = *(const bfx8*)(a.wp + ((size_t)((m * MT + mt) * 64 + lane)) * 8);
 
-  // staging geometry of this thread's pieces of a plane: fixed over z
-  int srel[G::NST];
+  // staging geometry of this thread's pieces of a plane: fixed over z.  Byte offsets inside the plane (fp32 scalar input:
+  // half the byte offset); a piece outside the image carries URSN_OOB_BYTES and reads as zeros through the buffer bounds
+  // check (buffer_stage.h) -- no select, no 64-bit address per piece, and this kernel is bound by instruction issue
+  unsigned sob[G::NST];
   unsigned sval = 0;
 #pragma unroll
   for (int i = 0; i < G::NST; ++i) {
     const int idx = tid + 256 * i;
-    srel[i] = 0;
+    sob[i] = URSN_OOB_BYTES;
     if (idx < G::PIECES) {
       const int vi = idx / CPV, hp = idx - vi * CPV;
       const int yy = vi / PX, xx = vi - yy * PX;
       const int gy = y0 + yy - 1, gx = x0 + xx - 1;
       if (gy >= 0 && gy < a.Y && gx >= 0 && gx < a.X) {
         sval |= 1u << i;
-        srel[i] = (gy * a.X + gx) * a.in_cs + hp * 8;
+        sob[i] = (unsigned)((gy * a.X + gx) * a.in_cs + hp * 8) * 2u;
       }
     }
+    asm volatile("" : "+v"(sob[i]));
   }
+  const size_t in_plane = (size_t)a.Y * a.X * a.in_cs;          // elements
+  const unsigned in_plane_bytes = (unsigned)in_plane * 2u;
+  const bf16_t* in_img = a.in + (size_t)n * a.Z * in_plane;
   u32x4 st[G::NST], stpw = {0u, 0u, 0u, 0u};
   unsigned stin = 0;   // AFF: which staged pieces are real voxels
   float asc[8], ash[8];
@@ -136,40 +143,34 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
   // shortcut plane (PW): interior voxels only, one piece per thread (32 x 8 tile), kept at the x plane's coordinates
   const int pwy = tid >> 5, pwx = tid & 31;
   const bool pwok = PW && y0 + pwy < a.Y && x0 + pwx < a.X;
-  const int pwrel = PW ? ((y0 + pwy) * a.X + x0 + pwx) * a.pw_cs : 0;
-  auto stage_dma = [&](int p, int slot) {   // plane p -> LDS slot, straight from global memory; padding reads the zero piece
+  const unsigned pwob = pwok ? (unsigned)(((y0 + pwy) * a.X + x0 + pwx) * a.pw_cs) * 2u : URSN_OOB_BYTES;
+  auto stage_dma = [&](int p, int slot) {   // plane p -> LDS slot, straight from global memory; padding arrives as zeros
     const bool pz = p >= 0 && p < a.Z;
-    const bf16_t* base = a.in + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
+    const __amdgpu_buffer_rsrc_t r = ursn_rsrc(in_img + (ptrdiff_t)p * (ptrdiff_t)in_plane, pz ? in_plane_bytes : 0u);
     unsigned char* dst = lds + slot * SLOT + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < G::NST; ++i) {
-      const bf16_t* src = (pz && ((sval >> i) & 1u)) ? base + srel[i] : a.wp + G::WPACK;
-      __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
-    }
+    for (int i = 0; i < G::NST; ++i) ursn_bload_lds_b128(r, dst + i * 4096, sob[i]);
   };
   auto stage_load = [&](int p, u32x4 (&arr)[G::NST]) {
     const bool pz = p >= 0 && p < a.Z;
-    const bf16_t* base = a.in + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
     if (CI == 8 && a.in_f32) {   // scalar fp32 input (in_cs = 1): uniform branch
-      const float* fb = a.in_f32 + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X;
+      const __amdgpu_buffer_rsrc_t r = ursn_rsrc(a.in_f32 + ((ptrdiff_t)n * a.Z + p) * (ptrdiff_t)a.Y * a.X, pz ? (unsigned)a.Y * a.X * 4u : 0u);
 #pragma unroll
       for (int i = 0; i < G::NST; ++i) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (pz && ((sval >> i) & 1u)) v[0] = (unsigned)f2bf(fb[srel[i]]);
-        arr[i] = v;
+        unsigned cv = (unsigned)f2bf(__uint_as_float(ursn_bload_b32(r, sob[i] * 2u)));
+        asm volatile("" : "+v"(cv));   // keeps the vectoriser from pairing the conversions (it then fails to select the build_vector)
+        arr[i] = (u32x4){cv, 0u, 0u, 0u};
       }
     } else {
+      const __amdgpu_buffer_rsrc_t r = ursn_rsrc(in_img + (ptrdiff_t)p * (ptrdiff_t)in_plane, pz ? in_plane_bytes : 0u);
 #pragma unroll
-      for (int i = 0; i < G::NST; ++i) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (pz && ((sval >> i) & 1u)) v = *(const u32x4*)(base + srel[i]);
-        arr[i] = v;
-      }
+      for (int i = 0; i < G::NST; ++i) arr[i] = ursn_bload_b128(r, sob[i]);
     }
     if constexpr (AFF) stin = pz ? sval : 0u;
     if constexpr (PW) {
-      stpw = (u32x4){0u, 0u, 0u, 0u};
-      if (pz && pwok) stpw = *(const u32x4*)(a.pw + ((size_t)n * a.Z + p) * a.Y * a.X * a.pw_cs + pwrel);
+      const __amdgpu_buffer_rsrc_t r = ursn_rsrc(a.pw + ((ptrdiff_t)n * a.Z + p) * (ptrdiff_t)a.Y * a.X * a.pw_cs,
+                                                 pz ? (unsigned)a.Y * a.X * a.pw_cs * 2u : 0u);
+      stpw = ursn_bload_b128(r, pwob);
     }
   };
   auto stage_store = [&](int slot, u32x4 (&arr)[G::NST]) {
@@ -227,20 +228,32 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
 
   // DMA + accumulate: the old values of the plane that completes at the end of an iteration are requested at its start, in
   // front of that iteration's DMA (read inside the epilogue they would make it wait for every DMA in flight)
+  // The lane's voxel of row nt inside a z plane (Y X for a lane outside the image: every offset built from it is out of
+  // range, so its loads read 0 and its stores are dropped -- no bounds branch, no 64-bit address per row and plane)
+  unsigned vrow[RPW];
+  unsigned rowok = 0;
+#pragma unroll
+  for (int nt = 0; nt < RPW; ++nt) {
+    const int gy = y0 + RPW * wave + nt, gx = x0 + c;
+    const bool ok = gy < a.Y && gx < a.X;
+    vrow[nt] = ok ? (unsigned)(gy * a.X + gx) : (unsigned)(a.Y * a.X);
+    if (ok) rowok |= 1u << nt;
+    asm volatile("" : "+v"(vrow[nt]));
+  }
+  const size_t plane_vox = (size_t)a.Y * a.X;
+  const unsigned out_plane_bytes = (unsigned)plane_vox * a.out_cs * 2u;
+  const unsigned out2_plane_bytes = (CO == 16 && a.out2) ? (unsigned)plane_vox * a.out2_cs * 2u : 0u;
+  auto out_rsrc = [&](int q) { return ursn_rsrc(a.out + ((size_t)n * a.Z + q) * plane_vox * a.out_cs, out_plane_bytes); };
+  auto out2_rsrc = [&](int q) { return ursn_rsrc(a.out2 + ((size_t)n * a.Z + q) * plane_vox * a.out2_cs, out2_plane_bytes); };
   u32x2 oldv[RPW][NCH];
   auto old_load = [&](int q) {
+    const __amdgpu_buffer_rsrc_t ro = out_rsrc(q);
 #pragma unroll
     for (int nt = 0; nt < RPW; ++nt) {
-      const int gy = y0 + RPW * wave + nt, gx = x0 + c;
 #pragma unroll
       for (int cb = 0; cb < NCH; ++cb) {
-        oldv[nt][cb] = (u32x2){0u, 0u};
-        if (gy < a.Y && gx < a.X) {
-          const size_t vox = (((size_t)n * a.Z + q) * a.Y + gy) * a.X + gx;
-          const bf16_t* o = a.out + vox * a.out_cs + h * 4 + 8 * cb;
-          if (CO == 16 && cb == 1 && a.out2) o = a.out2 + vox * a.out2_cs + h * 4;
-          oldv[nt][cb] = *(const u32x2*)o;
-        }
+        if (CO == 16 && cb == 1 && a.out2) oldv[nt][cb] = ursn_bload_b64(out2_rsrc(q), vrow[nt] * (unsigned)(a.out2_cs * 2) + h * 8);
+        else oldv[nt][cb] = ursn_bload_b64(ro, vrow[nt] * (unsigned)(a.out_cs * 2) + h * 8 + 16 * cb);
       }
     }
   };
@@ -253,15 +266,19 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
     if constexpr (BS != 0) {
       const int q = p - 1;
       if (q >= z0 && q < z1) {
+        const size_t pv = ((size_t)n * a.Z + q) * plane_vox;
+        const __amdgpu_buffer_rsrc_t rz = ursn_rsrc(a.bs_z + pv * a.bs_z_cs, (unsigned)plane_vox * a.bs_z_cs * 2u);
 #pragma unroll
-        for (int nt = 0; nt < RPW; ++nt) {
-          const int gy = y0 + RPW * wave + nt, gx = x0 + c;
-          if (gy < a.Y && gx < a.X) {
-            const size_t vox = (((size_t)n * a.Z + q) * a.Y + gy) * a.X + gx;
-            pz[nt] = *(const u32x2*)(a.bs_z + vox * a.bs_z_cs + 4 * h);
-            if constexpr (BS == 2) pz2[nt] = *(const u32x2*)(a.bs_z2 + vox * a.bs_z2_cs + 4 * h);
-            if (a.bs_mode == 3) pm[nt] = a.bs_maskb[vox];
-          }
+        for (int nt = 0; nt < RPW; ++nt) pz[nt] = ursn_bload_b64(rz, vrow[nt] * (unsigned)(a.bs_z_cs * 2) + 8 * h);
+        if constexpr (BS == 2) {
+          const __amdgpu_buffer_rsrc_t rz2 = ursn_rsrc(a.bs_z2 + pv * a.bs_z2_cs, (unsigned)plane_vox * a.bs_z2_cs * 2u);
+#pragma unroll
+          for (int nt = 0; nt < RPW; ++nt) pz2[nt] = ursn_bload_b64(rz2, vrow[nt] * (unsigned)(a.bs_z2_cs * 2) + 8 * h);
+        }
+        if (a.bs_mode == 3) {
+          const __amdgpu_buffer_rsrc_t rm = ursn_rsrc(a.bs_maskb + pv, (unsigned)plane_vox);
+#pragma unroll
+          for (int nt = 0; nt < RPW; ++nt) pm[nt] = ursn_bload_u8(rm, vrow[nt]);
         }
       }
     }
@@ -297,30 +314,30 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
     }
     const int q = p - 1;   // complete: it has seen input planes q - 1, q, q + 1
     if (q >= z0 && q < z1) {
+      const __amdgpu_buffer_rsrc_t ro = out_rsrc(q);
+      const __amdgpu_buffer_rsrc_t ro2 = (CO == 16 && a.out2) ? out2_rsrc(q) : ro;
 #pragma unroll
       for (int nt = 0; nt < RPW; ++nt) {
-        const int gy = y0 + RPW * wave + nt, gx = x0 + c;
-        if (gy < a.Y && gx < a.X) {
-          bf16_t* ob = a.out + ((((size_t)n * a.Z + q) * a.Y + gy) * a.X + gx) * a.out_cs + h * 4;
+        {
 #pragma unroll
           for (int cb = 0; cb < NCH; ++cb) {   // channels 8 cb + 4 h + (0..3): registers 8 + i (CO = 8) | 4 cb + i of tile 1
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = CO == 8 ? acc[nt][0][8 + i] : acc[nt][1][4 * cb + i];
-            u32x2* o = (u32x2*)(ob + 8 * cb);
-            if constexpr (CO == 16) {
-              if (cb == 1 && a.out2) o = (u32x2*)(a.out2 + ((((size_t)n * a.Z + q) * a.Y + gy) * a.X + gx) * a.out2_cs + h * 4);
-            }
+            const bool second = CO == 16 && cb == 1 && a.out2;
+            const __amdgpu_buffer_rsrc_t rr = second ? ro2 : ro;
+            const unsigned oo = second ? vrow[nt] * (unsigned)(a.out2_cs * 2) + h * 8 : vrow[nt] * (unsigned)(a.out_cs * 2) + h * 8 + 16 * cb;
             if (a.accumulate) {
               u32x2 e;
-              if constexpr (DMA) e = oldv[nt][cb]; else e = *o;
+              if constexpr (DMA) e = oldv[nt][cb]; else e = ursn_bload_b64(rr, oo);
               v[0] += __uint_as_float(e[0] << 16); v[1] += __uint_as_float(e[0] & 0xffff0000u);
               v[2] += __uint_as_float(e[1] << 16); v[3] += __uint_as_float(e[1] & 0xffff0000u);
             }
             u32x2 pk;
             pk[0] = pack_bf2(v[0], v[1]);
             pk[1] = pack_bf2(v[2], v[3]);
-            *o = pk;
+            ursn_bstore_b64(pk, rr, oo);
+            if (!((rowok >> nt) & 1u)) continue;   // sums below: real voxels only
             if constexpr (STATS) {   // moments of the STORED (rounded) tensor: that is what BatchNorm will normalise
               const float rv[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
                                    __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
               }
             }
           }
-          if constexpr (STATS) nacc += 1.f;
+          if constexpr (STATS) if ((rowok >> nt) & 1u) nacc += 1.f;
         }
       }
     }
@@ -377,11 +394,9 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
     }
   } else {
     // VM operations retire in issue order.  At the end of iteration p everything up to the DMA of plane p + 1 must have landed;
-    // younger than it are this wave's stores of the last AHEAD output planes (one per valid row and 8-channel group, none while
+    // younger than it are this wave's stores of the last AHEAD output planes (one per row and 8-channel group, none while
     // a plane lies outside the segment) and the DMAs of planes p + 2 .. p + AHEAD (NST each): exactly those may stay in flight.
-    int krow = 0;
-#pragma unroll
-    for (int nt = 0; nt < RPW; ++nt) krow += (y0 + RPW * wave + nt < a.Y) ? NCH : 0;
+    constexpr int krow = RPW * NCH;   // every row issues its stores (out-of-range ones are dropped by the bounds check, but count)
     auto wait_vm = [&](int keep) {   // s_waitcnt takes an immediate; a smaller count than necessary only waits for more
       switch (keep) {
 #define B3W(n_) case n_: asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory"); break;
