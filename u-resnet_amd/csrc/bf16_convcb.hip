@@ -7,7 +7,7 @@
 // roofline at 64^3 / 128^3.  Here a workgroup owns an 8 x 32 voxel column and walks it through z:
 //   * the packed weights of its block of 32 produced channels, all 27 taps (27 | 54 KB), are DMA'd into LDS ONCE;
 //   * every input plane (+ 1 halo ring in y / x: 1.33x) is DMA'd into LDS exactly once, into one of two slots, while the
-//     previous plane computes (global_load_lds, per-lane source address: padding voxels read a zero piece);
+//     previous plane computes (LDS-DMA through the buffer path: padding voxels are out of range and arrive as zeros);
 //   * a staged input plane p feeds the THREE output planes p + 1, p, p - 1 (tap planes dz = -1, 0, +1): a B operand (32
 //     voxels x 16 channels of one in-plane tap) is read from LDS once and used by three MFMAs whose A operands are the three
 //     tap planes' weights; after a plane the complete accumulator set is rounded to bf16 once and stored and the other two
@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "bf16_common.h"
+#include "buffer_stage.h"
 
 namespace {
 
@@ -150,52 +151,46 @@ __global__ __launch_bounds__(256, 1) void bcbconv_kernel(CBArgs a) {
   }
 
   // ---- staging geometry of this thread's pieces of a plane (fixed over z): LDS piece index i * 256 + tid = (piece, y, x) ----
-  int srel[G::NST];
-  unsigned sval = 0;
+  // byte offsets inside a z plane; a piece outside the image carries URSN_OOB_BYTES and arrives as zeros through the buffer
+  // bounds check (buffer_stage.h): no per-piece select between the voxel and a zero piece, no 64-bit address
+  unsigned srel[G::NST];
 #pragma unroll
   for (int i = 0; i < G::NST; ++i) {
     const int idx = tid + 256 * i;
-    srel[i] = 0;
+    srel[i] = URSN_OOB_BYTES;
     if (idx < G::PIECES) {
       const int hp = idx / G::PVOX, vi = idx - hp * G::PVOX;
       const int yy = vi / PX, xx = vi - yy * PX;
       const int gy = y0 + yy - 1, gx = x0 + xx - 1;
-      if (gy >= 0 && gy < a.Y && gx >= 0 && gx < a.X) {
-        sval |= 1u << i;
-        srel[i] = (gy * a.X + gx) * a.in_cs + hp * 8;
-      }
+      if (gy >= 0 && gy < a.Y && gx >= 0 && gx < a.X) srel[i] = (unsigned)((gy * a.X + gx) * a.in_cs + hp * 8) * 2u;
     }
+    asm volatile("" : "+v"(srel[i]));
   }
   const size_t plane_stride = (size_t)a.Y * a.X * a.in_cs;
+  const bf16_t* in_img = a.in + (size_t)n * a.Z * plane_stride;
   // PW: this thread's pieces of the shortcut plane (interior voxels): LDS piece index i * 256 + tid = (piece, y, x)
-  int prel[PW ? G::NSTPW : 1];
-  unsigned pval = 0;
+  unsigned prel[PW ? G::NSTPW : 1];
   if constexpr (PW) {
 #pragma unroll
     for (int i = 0; i < G::NSTPW; ++i) {
       const int idx = tid + 256 * i, hp = idx / (G::TY * 32), vi = idx - hp * (G::TY * 32);
       const int gy = y0 + vi / 32, gx = x0 + (vi & 31);
-      prel[i] = 0;
-      if (gy < a.Y && gx < a.X) { pval |= 1u << i; prel[i] = (gy * a.X + gx) * a.pw_cs + hp * 8; }
+      prel[i] = (gy < a.Y && gx < a.X) ? (unsigned)((gy * a.X + gx) * a.pw_cs + hp * 8) * 2u : URSN_OOB_BYTES;
+      asm volatile("" : "+v"(prel[i]));
     }
   }
   auto stage = [&](int p, int slot) {   // plane p -> LDS slot; planes outside the tensor are zero planes
     const bool pz = p >= 0 && p < a.Z;
-    const bf16_t* base = a.in + ((size_t)n * a.Z + (pz ? p : 0)) * plane_stride;
+    const __amdgpu_buffer_rsrc_t r = ursn_rsrc(in_img + (ptrdiff_t)p * (ptrdiff_t)plane_stride, pz ? (unsigned)plane_stride * 2u : 0u);
     unsigned char* dst = lds + slot * SLOT + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < G::NST; ++i) {
-      const bf16_t* src = (pz && ((sval >> i) & 1u)) ? base + srel[i] : a.zero;
-      __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
-    }
+    for (int i = 0; i < G::NST; ++i) ursn_bload_lds_b128(r, dst + i * 4096, srel[i]);
     if constexpr (PW) {   // the shortcut's dz of the same plane (used by the middle role only: planes of the segment)
       const bool pq = p >= z0 && p < z1;
-      const bf16_t* pbase = a.pw + ((size_t)n * a.Z + (pq ? p : 0)) * (size_t)a.Y * a.X * a.pw_cs;
+      const size_t pplane = (size_t)a.Y * a.X * a.pw_cs;
+      const __amdgpu_buffer_rsrc_t rp = ursn_rsrc(a.pw + ((ptrdiff_t)n * a.Z + p) * (ptrdiff_t)pplane, pq ? (unsigned)pplane * 2u : 0u);
 #pragma unroll
-      for (int i = 0; i < G::NSTPW; ++i) {
-        const bf16_t* src = (pq && ((pval >> i) & 1u)) ? pbase + prel[i] : a.zero;
-        __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(dst + G::PLANE + i * 4096), 16, 0, 0);
-      }
+      for (int i = 0; i < G::NSTPW; ++i) ursn_bload_lds_b128(rp, dst + G::PLANE + i * 4096, prel[i]);
     }
   };
 
@@ -215,20 +210,26 @@ __global__ __launch_bounds__(256, 1) void bcbconv_kernel(CBArgs a) {
   for (int k = 0; k < 16; ++k) piv[k] = s1[k] = s2[k] = 0.f;
 
   // ---- epilogue geometry (fixed over z): this lane's voxel of row nt, its four 8-byte channel groups 8 qd + 4 h ----
-  int orel[RPW];
-  unsigned omask = 0;   // bit nt * 4 + qd: the lane stores that group
+  // orel: byte offset of the lane's first group inside a z plane, URSN_OOB_BYTES for a lane outside the image (its stores are
+  // dropped and its loads read 0: buffer_stage.h).  Channel groups at or beyond Cout (a multiple of 8) are skipped by a
+  // scalar branch; omask keeps the per-lane validity for the statistics only.
+  unsigned orel[RPW];
+  unsigned omask = 0;   // bit nt * 4 + qd: the lane owns that group
 #pragma unroll
   for (int nt = 0; nt < RPW; ++nt) {
     const int gy = y0 + RPW * wave + nt, gx = x0 + c;
-    orel[nt] = 0;
+    orel[nt] = URSN_OOB_BYTES;
     if (gy < a.Y && gx < a.X) {
-      orel[nt] = (gy * a.X + gx) * a.out_cs + cob * 32 + 4 * h;
+      orel[nt] = (unsigned)((gy * a.X + gx) * a.out_cs + cob * 32 + 4 * h) * 2u;
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd)
         if (cob * 32 + 8 * qd + 4 * h < a.Cout) omask |= 1u << (nt * 4 + qd);
     }
+    asm volatile("" : "+v"(orel[nt]));
   }
   const size_t oplane = (size_t)a.Y * a.X * a.out_cs;
+  const bf16_t* out_img = a.out + (size_t)n * a.Z * oplane;
+  auto out_rsrc = [&](int q) { return ursn_rsrc(out_img + (ptrdiff_t)q * (ptrdiff_t)oplane, (unsigned)oplane * 2u); };
   // A complete plane is rounded to bf16 right after its last MFMA (pend) but STORED at the start of the next plane
   // iteration, in front of that iteration's DMA: the wait that ends an iteration then finds the stores a whole MFMA block old
   // instead of paying the HBM write latency every plane.  accumulate: the old values are requested a plane ahead.
@@ -236,14 +237,15 @@ __global__ __launch_bounds__(256, 1) void bcbconv_kernel(CBArgs a) {
   int pend_q = -1;
   auto flush = [&]() {   // store the pending plane, take the moments of what was stored (what BatchNorm will normalise)
     if (pend_q < 0) return;
-    bf16_t* ob = a.out + ((size_t)n * a.Z + pend_q) * oplane;
+    const __amdgpu_buffer_rsrc_t ro = out_rsrc(pend_q);
 #pragma unroll
     for (int nt = 0; nt < RPW; ++nt) {
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
+        if (cob * 32 + 8 * qd >= a.Cout) continue;   // wave-uniform
+        const u32x2 pk = pend[nt][qd];
+        ursn_bstore_b64(pk, ro, orel[nt] + 16 * qd);
         if ((omask >> (nt * 4 + qd)) & 1u) {
-          const u32x2 pk = pend[nt][qd];
-          *(u32x2*)(ob + orel[nt] + 8 * qd) = pk;
           if constexpr (STATS) {
             const float rv[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
                                  __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
@@ -261,13 +263,13 @@ __global__ __launch_bounds__(256, 1) void bcbconv_kernel(CBArgs a) {
   };
   auto prefetch_old = [&](int q) {
     if (!a.accumulate) return;
-    const bf16_t* ob = a.out + ((size_t)n * a.Z + q) * oplane;
+    const __amdgpu_buffer_rsrc_t ro = out_rsrc(q);
 #pragma unroll
     for (int nt = 0; nt < RPW; ++nt)
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         oldv[nt][qd] = (u32x2){0u, 0u};
-        if ((omask >> (nt * 4 + qd)) & 1u) oldv[nt][qd] = *(const u32x2*)(ob + orel[nt] + 8 * qd);
+        if (cob * 32 + 8 * qd < a.Cout) oldv[nt][qd] = ursn_bload_b64(ro, orel[nt] + 16 * qd);
       }
   };
   auto finish = [&](int q, cb_f32x16 (&acc)[RPW]) {   // output plane q has seen its three input planes

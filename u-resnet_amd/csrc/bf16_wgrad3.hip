@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "bf16_common.h"
+#include "buffer_stage.h"
 
 namespace {
 
@@ -71,30 +72,37 @@ __global__ __launch_bounds__(256, 2) void b3wgrad_kernel(W3Args a) {
   const int z1 = z0 + a.zseg < a.Z ? z0 + a.zseg : a.Z;
 
   // staging geometry (fixed over z)
-  int xrel[G::NXS], drel[G::NDS];
-  unsigned xval = 0, dval = 0;
+  // byte offsets inside a z plane; a piece outside the image carries URSN_OOB_BYTES and reads as zeros through the buffer
+  // bounds check (buffer_stage.h): no zero fill, no branch, no 64-bit address per piece
+  unsigned xrel[G::NXS], drel[G::NDS];
+  unsigned xval = 0;
 #pragma unroll
   for (int i = 0; i < G::NXS; ++i) {
     const int idx = tid + 256 * i;
-    xrel[i] = 0;
+    xrel[i] = URSN_OOB_BYTES;
     if (idx < G::XPIECES) {
       const int vi = idx / CPV, hp = idx - vi * CPV;
       const int yy = vi / PX, xx = vi - yy * PX;
       const int gy = y0 + yy - 1, gx = x0 + xx - 1;
-      if (gy >= 0 && gy < a.Y && gx >= 0 && gx < a.X) { xval |= 1u << i; xrel[i] = (gy * a.X + gx) * a.in_cs + hp * 8; }
+      if (gy >= 0 && gy < a.Y && gx >= 0 && gx < a.X) { xval |= 1u << i; xrel[i] = (unsigned)((gy * a.X + gx) * a.in_cs + hp * 8) * 2u; }
     }
+    asm volatile("" : "+v"(xrel[i]));
   }
 #pragma unroll
   for (int i = 0; i < G::NDS; ++i) {
     const int idx = tid + 256 * i;
-    drel[i] = 0;
+    drel[i] = URSN_OOB_BYTES;
     if (idx < G::DPIECES) {
       const int vi = idx / DPV, hp = idx - vi * DPV;
       const int yy = vi >> 5, xx = vi & 31;
       const int gy = y0 + yy, gx = x0 + xx;
-      if (gy < a.Y && gx < a.X) { dval |= 1u << i; drel[i] = (gy * a.X + gx) * a.out_cs + hp * 8; }
+      if (gy < a.Y && gx < a.X) drel[i] = (unsigned)((gy * a.X + gx) * a.out_cs + hp * 8) * 2u;
     }
+    asm volatile("" : "+v"(drel[i]));
   }
+  const size_t x_plane = (size_t)a.Y * a.X * a.in_cs, d_plane = (size_t)a.Y * a.X * a.out_cs;
+  const bf16_t* x_img = a.S + (size_t)n * a.Z * x_plane;
+  const bf16_t* d_img = a.C + (size_t)n * a.Z * d_plane;
   u32x4 xs[G::NXS], ds[G::NDS];
   unsigned xin = 0;
   float asc[8], ash[8];
@@ -109,13 +117,9 @@ __global__ __launch_bounds__(256, 2) void b3wgrad_kernel(W3Args a) {
   }
   auto load_x = [&](int p) {
     const bool pz = p >= 0 && p < a.Z;
-    const bf16_t* base = a.S + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
+    const __amdgpu_buffer_rsrc_t r = ursn_rsrc(x_img + (ptrdiff_t)p * (ptrdiff_t)x_plane, pz ? (unsigned)x_plane * 2u : 0u);
 #pragma unroll
-    for (int i = 0; i < G::NXS; ++i) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (pz && ((xval >> i) & 1u)) v = *(const u32x4*)(base + xrel[i]);
-      xs[i] = v;
-    }
+    for (int i = 0; i < G::NXS; ++i) xs[i] = ursn_bload_b128(r, xrel[i]);
     if constexpr (AFF) xin = pz ? xval : 0u;
   };
   auto store_x = [&](int p) {   // plane p lives in ring slot (p + 1) & 3
@@ -140,13 +144,9 @@ __global__ __launch_bounds__(256, 2) void b3wgrad_kernel(W3Args a) {
   };
   auto load_d = [&](int q) {
     const bool qz = q < z1;
-    const bf16_t* base = a.C + ((size_t)n * a.Z + (qz ? q : 0)) * a.Y * a.X * a.out_cs;
+    const __amdgpu_buffer_rsrc_t r = ursn_rsrc(d_img + (ptrdiff_t)q * (ptrdiff_t)d_plane, qz ? (unsigned)d_plane * 2u : 0u);
 #pragma unroll
-    for (int i = 0; i < G::NDS; ++i) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (qz && ((dval >> i) & 1u)) v = *(const u32x4*)(base + drel[i]);
-      ds[i] = v;
-    }
+    for (int i = 0; i < G::NDS; ++i) ds[i] = ursn_bload_b128(r, drel[i]);
   };
   auto store_d = [&](int q) {
     unsigned char* dst = dbuf + (q & 1) * G::DPLANE;
@@ -307,24 +307,27 @@ __global__ __launch_bounds__(256, 3) void b3wgradz_kernel(W3Args a) {
   const int x0 = tx * 32, y0 = ty * TY, z0 = zs * a.zseg;
   const int z1 = z0 + a.zseg < a.Z ? z0 + a.zseg : a.Z;
 
-  int xrel[G::NXS], drel;
+  // byte offsets inside a z plane (fp32 scalar input: half the byte offset); URSN_OOB_BYTES outside the image (buffer_stage.h)
+  unsigned xrel[G::NXS], drel;
   unsigned xval = 0;
-  bool dval = false;
 #pragma unroll
   for (int i = 0; i < G::NXS; ++i) {
     const int idx = tid + 256 * i;
-    xrel[i] = 0;
+    xrel[i] = URSN_OOB_BYTES;
     if (idx < G::XPIECES) {
       const int yy = idx / PX, xx = idx - yy * PX;
       const int gy = y0 + yy - 1, gx = x0 + xx - 1;
-      if (gy >= 0 && gy < a.Y && gx >= 0 && gx < a.X) { xval |= 1u << i; xrel[i] = (gy * a.X + gx) * a.in_cs; }
+      if (gy >= 0 && gy < a.Y && gx >= 0 && gx < a.X) { xval |= 1u << i; xrel[i] = (unsigned)((gy * a.X + gx) * a.in_cs) * 2u; }
     }
+    asm volatile("" : "+v"(xrel[i]));
   }
   {
     const int gy = y0 + (tid >> 5), gx = x0 + (tid & 31);
-    dval = gy < a.Y && gx < a.X;
-    drel = dval ? (gy * a.X + gx) * a.out_cs : 0;
+    drel = (gy < a.Y && gx < a.X) ? (unsigned)((gy * a.X + gx) * a.out_cs) * 2u : URSN_OOB_BYTES;
   }
+  const size_t x_plane = (size_t)a.Y * a.X * a.in_cs, d_plane = (size_t)a.Y * a.X * a.out_cs;
+  const bf16_t* x_img = a.S + (size_t)n * a.Z * x_plane;
+  const bf16_t* d_img = a.C + (size_t)n * a.Z * d_plane;
   float asc[8], ash[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -335,22 +338,18 @@ __global__ __launch_bounds__(256, 3) void b3wgradz_kernel(W3Args a) {
   unsigned xin[2] = {0u, 0u};
   auto load_x = [&](int p, int k) {
     const bool pz = p >= 0 && p < a.Z;
-    const bf16_t* base = a.S + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X * a.in_cs;
     if (a.S_f32) {   // in_cs = 1
-      const float* fb = a.S_f32 + ((size_t)n * a.Z + (pz ? p : 0)) * a.Y * a.X;
+      const __amdgpu_buffer_rsrc_t r = ursn_rsrc(a.S_f32 + ((ptrdiff_t)n * a.Z + p) * (ptrdiff_t)a.Y * a.X, pz ? (unsigned)a.Y * a.X * 4u : 0u);
 #pragma unroll
       for (int i = 0; i < G::NXS; ++i) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (pz && ((xval >> i) & 1u)) v[0] = (unsigned)f2bf(fb[xrel[i]]);
-        xs[k][i] = v;
+        unsigned cv = (unsigned)f2bf(__uint_as_float(ursn_bload_b32(r, xrel[i] * 2u)));
+        asm volatile("" : "+v"(cv));   // see b3conv: keeps the vectoriser from pairing the conversions
+        xs[k][i] = (u32x4){cv, 0u, 0u, 0u};
       }
     } else {
+      const __amdgpu_buffer_rsrc_t r = ursn_rsrc(x_img + (ptrdiff_t)p * (ptrdiff_t)x_plane, pz ? (unsigned)x_plane * 2u : 0u);
 #pragma unroll
-      for (int i = 0; i < G::NXS; ++i) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (pz && ((xval >> i) & 1u)) v = *(const u32x4*)(base + xrel[i]);
-        xs[k][i] = v;
-      }
+      for (int i = 0; i < G::NXS; ++i) xs[k][i] = ursn_bload_b128(r, xrel[i]);
     }
     xin[k] = pz ? xval : 0u;
   };
@@ -375,9 +374,7 @@ __global__ __launch_bounds__(256, 3) void b3wgradz_kernel(W3Args a) {
     }
   };
   auto load_d = [&](int q, int k) {
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (q < z1 && dval) v = *(const u32x4*)(a.C + ((size_t)n * a.Z + q) * a.Y * a.X * a.out_cs + drel);
-    ds[k] = v;
+    ds[k] = ursn_bload_b128(ursn_rsrc(d_img + (ptrdiff_t)q * (ptrdiff_t)d_plane, q < z1 ? (unsigned)d_plane * 2u : 0u), drel);
   };
   auto store_d = [&](int q, int k) { *(u32x4*)(dbuf + (q & 3) * G::DPLANE + tid * 16) = ds[k]; };
 
