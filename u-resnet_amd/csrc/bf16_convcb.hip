@@ -409,6 +409,11 @@ CBPlan cb_plan(const GatherGeom& g) {
 bool bcbconv_ok(const GatherGeom& g) {
   static const bool off = getenv("URSN_BCB") && getenv("URSN_BCB")[0] == '0';
   if (off) return false;
+  {   // buffer-path staging (buffer_stage.h): a z plane of either tensor must stay below the out-of-range marker
+    const int64_t pv = (int64_t)g.in_d[1] * g.in_d[2], qv = (int64_t)g.out_d[1] * g.out_d[2];
+    const int64_t cs = g.in_cs > g.out_cs ? g.in_cs : g.out_cs;
+    if ((pv > qv ? pv : qv) * cs * 2 >= (int64_t)0x40000000) return false;
+  }
   if ((g.K != 16 && g.K != 32) || g.Nn < 16 || (g.Nn & 7) || g.ntaps != 27 || (g.in_cs & 7) || (g.out_cs & 7)) return false;
   if (b3conv_ok(g)) return false;   // 16 -> 16 and below: all weights in registers
   for (int j = 0; j < 3; ++j) {

@@ -483,6 +483,11 @@ W3Plan w3_plan(const GatherGeom& g) {
 bool b3wgrad_ok(const GatherGeom& g) {
   static const bool off = getenv("URSN_B3WGRAD") && getenv("URSN_B3WGRAD")[0] == '0';
   if (off) return false;
+  {   // buffer-path staging (buffer_stage.h): a z plane of either tensor must stay below the out-of-range marker
+    const int64_t pv = (int64_t)g.in_d[1] * g.in_d[2], qv = (int64_t)g.out_d[1] * g.out_d[2];
+    const int64_t cs = g.in_cs > g.out_cs ? g.in_cs : g.out_cs;
+    if ((pv > qv ? pv : qv) * cs * 2 >= (int64_t)0x40000000) return false;
+  }
   if (!((g.K == 8 && g.Nn == 8) || (g.K == 16 && (g.Nn == 8 || g.Nn == 16)))) return false;
   if (g.ntaps != 27 || (g.in_cs & 7) || (g.out_cs & 7)) return false;
   for (int j = 0; j < 3; ++j)

@@ -54,6 +54,10 @@ static bool make_igplan(const ursn_conv_desc& d, ConvPass pass, IGPlan& p, int& 
   p.alltaps = (at && p.bm == 16) || (at >= 1 && at != 16 && p.bm == 32);   // URSN_IGEMM_ALLTAPS: 0 off, 16 only BM=16, 1 both
   if (d.pw_dy && !(p.flip && p.alltaps)) return false;   // the fused shortcut term lives in the all-taps data-gradient kernel
   if (p.alltaps) {
+    {   // the all-taps kernel stages through buffer loads with 32-bit offsets inside one image (buffer_stage.h)
+      const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+      if ((int64_t)p.Z * p.Y * p.X * (p.flip ? ocs : ics) * 4 >= (int64_t)0x80000000ll) return false;
+    }
     const int kc = p.bm == 16 ? 16 : 8;
     p.lds = ((size_t)(kc / 4) * HZ * HY * HX * 4 + (size_t)(p.mode == 3 ? 27 : 9) * kc * p.bm) * sizeof(float);
     if (d.pw_dy) {   // fused shortcut term: the box's voxels of the shortcut gradient + the KC x BM slab of its weights

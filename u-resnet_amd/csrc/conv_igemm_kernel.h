@@ -13,6 +13,7 @@
 #include <utility>
 
 #include "ursn_common.h"
+#include "buffer_stage.h"
 
 typedef float ig_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -239,19 +240,45 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[v][m] = (ig_f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto load_h = [&](int ci0, ig_f32x4 (&hv)[NH]) {
+  // Halo and weight-slab loads go through buffer instructions with byte offsets tabulated ONCE (buffer_stage.h): rebuilt per
+  // chunk from idx they were ~40 instructions per element (divisions by HX / HY, five bounds tests, a 64-bit address), and every
+  // issued instruction costs this SIMD's matrix pipe its slot.  The chunk's first channel moves the resource base.
+  unsigned hoff[NH], woff[NW];
 #pragma unroll
-    for (int i = 0; i < NH; ++i) {
-      const int idx = tid + i * 256;
-      const int s = idx / NQ, q = idx % NQ;
-      const int hx = s % HX, r = s / HX;
-      const int hy = r % HY, hz = r / HY;
-      const int pz = z0 + hz - (KZ == 3 ? 1 : 0), py = y0 + hy - 1, px = x0 + hx - 1;
-      ig_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < NQ * PS && pz >= 0 && pz < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
-        v = *(const ig_f32x4*)(a.in + ((((size_t)n * a.Z + pz) * a.Y + py) * a.X + px) * a.in_cs + ci0 + 4 * q);
-      hv[i] = v;
+  for (int i = 0; i < NH; ++i) {
+    const int idx = tid + i * 256;
+    const int s = idx / NQ, q = idx % NQ;
+    const int hx = s % HX, r = s / HX;
+    const int hy = r % HY, hz = r / HY;
+    const int pz = z0 + hz - (KZ == 3 ? 1 : 0), py = y0 + hy - 1, px = x0 + hx - 1;
+    const bool ok = idx < NQ * PS && pz >= 0 && pz < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X;
+    hoff[i] = ok ? (unsigned)(((pz * a.Y + py) * a.X + px) * a.in_cs + 4 * q) * 4u : URSN_OOB_OFFSET;
+    asm volatile("" : "+v"(hoff[i]));
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int idx = tid + i * 256;
+    const int t = idx / (KC * BM / 4), rem = idx % (KC * BM / 4);
+    bool ok = idx < NWF;
+    unsigned off;
+    if (!FLIP) {
+      const int k = rem / (BM / 4), c4 = (rem % (BM / 4)) * 4;
+      ok = ok && co0 + c4 < a.cout;
+      off = (unsigned)((t * a.cin_w + k) * a.cout_w + co0 + c4) * 4u;
+    } else {
+      const int nn = rem / (KC / 4), k4 = (rem % (KC / 4)) * 4;
+      ok = ok && co0 + nn < a.cout;
+      off = (unsigned)(((NT - 1 - t) * a.cin_w + co0 + nn) * a.cout_w + k4) * 4u;
     }
+    woff[i] = ok ? off : URSN_OOB_OFFSET;
+    asm volatile("" : "+v"(woff[i]));
+  }
+  const float* in_img = a.in + (size_t)n * a.Z * a.Y * a.X * a.in_cs;
+  const unsigned in_img_bytes = (unsigned)a.Z * a.Y * a.X * a.in_cs * 4u, w_bytes = (unsigned)NT * a.cin_w * a.cout_w * 4u;
+  auto load_h = [&](int ci0, ig_f32x4 (&hv)[NH]) {
+    const __amdgpu_buffer_rsrc_t r = ursn_plane_rsrc(in_img + ci0, in_img_bytes);
+#pragma unroll
+    for (int i = 0; i < NH; ++i) hv[i] = ursn_buffer_load_f4(r, hoff[i]);
   };
   auto store_h = [&](const ig_f32x4 (&hv)[NH]) {
 #pragma unroll
@@ -262,22 +289,9 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
   };
   // weights: float4 index of the [NT][KC][BM] slab; FLIP loads along the contraction (contiguous in memory)
   auto load_w = [&](int ci0, ig_f32x4 (&wv)[NW]) {
+    const __amdgpu_buffer_rsrc_t r = ursn_plane_rsrc(a.w + (FLIP ? (size_t)ci0 : (size_t)ci0 * a.cout_w), w_bytes);
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int idx = tid + i * 256;
-      ig_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < NWF) {
-        const int t = idx / (KC * BM / 4), rem = idx % (KC * BM / 4);
-        if (!FLIP) {
-          const int k = rem / (BM / 4), c4 = (rem % (BM / 4)) * 4;
-          if (co0 + c4 < a.cout) v = *(const ig_f32x4*)(a.w + ((size_t)t * a.cin_w + ci0 + k) * a.cout_w + co0 + c4);
-        } else {
-          const int nn = rem / (KC / 4), k4 = (rem % (KC / 4)) * 4;
-          if (co0 + nn < a.cout) v = *(const ig_f32x4*)(a.w + ((size_t)(NT - 1 - t) * a.cin_w + co0 + nn) * a.cout_w + ci0 + k4);
-        }
-      }
-      wv[i] = v;
-    }
+    for (int i = 0; i < NW; ++i) wv[i] = ursn_buffer_load_f4(r, woff[i]);
   };
   auto store_w = [&](const ig_f32x4 (&wv)[NW]) {
 #pragma unroll

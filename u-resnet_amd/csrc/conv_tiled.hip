@@ -101,6 +101,10 @@ static int twgrad_vgpr_waves(int mode, int cin, int cout) {
 static bool spatial_tiles(const ursn_conv_desc& d, int& Z, int& Y, int& X, int& ntx, int& nty) {
   if (d.ndim == 3) { Z = d.in_sp[0]; Y = d.in_sp[1]; X = d.in_sp[2]; }
   else { Z = d.in_sp[0]; Y = 1; X = d.in_sp[1]; }
+  {   // buffer-path staging (buffer_stage.h): a z plane (2-D: a row) must stay below the out-of-range marker
+    const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+    if ((int64_t)Y * X * (ics > ocs ? ics : ocs) * 4 >= (int64_t)0x80000000ll) return false;
+  }
   const int TX = d.ndim == 3 ? 32 : 256, TY = d.ndim == 3 ? 8 : 1;
   if (X < TX / 2 || Y < TY || Z < 8) return false;  // only worth it when tiles are reasonably full
   ntx = (X + TX - 1) / TX;
