@@ -12,6 +12,7 @@
 #include <utility>
 
 #include "ursn_common.h"
+#include "buffer_stage.h"
 
 typedef float iw_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -68,7 +69,35 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(IGWArgs a) {
   }
   const int b_lane = ((il >> 2) * DSP + kl + (SPLITK ? 4 * wave : 0)) * 4 + (il & 3);   // + (m*4*DSP + voxel slot of quad start)*4
 
-  // staging in two phases (loads of box b+1 are in flight during the MFMAs of box b)
+  // staging in two phases (loads of box b+1 are in flight during the MFMAs of box b).  Buffer loads (buffer_stage.h): the
+  // element's offset is box origin + a per-thread constant tabulated once; planes outside the volume fall outside the
+  // image's byte range by themselves (an origin below the image wraps to a huge unsigned offset), rows and columns outside it
+  // are two range compares per element -- instead of rebuilding (z, y, x) from idx, five bounds tests and a 64-bit address
+  // per element and box.
+  unsigned xrel[NHX], xyx[NHX], drel[NHD], dyx[NHD];   // byte offset relative to the box origin; (row | column << 16) in the box
+#pragma unroll
+  for (int i = 0; i < NHX; ++i) {
+    const int idx = tid + i * 256;
+    const int s = idx >> 2, q = idx & 3;
+    const int hx = s % HX, r = s / HX;
+    const int hy = r % HY, hz = r / HY;
+    xrel[i] = (unsigned)(((hz * a.Y + hy) * a.X + hx) * a.x_cs + 4 * q) * 4u;
+    xyx[i] = idx < 4 * PS ? (unsigned)hy | ((unsigned)hx << 16) : 0xffffffffu;   // past the halo: never in range
+    asm volatile("" : "+v"(xrel[i]));
+    asm volatile("" : "+v"(xyx[i]));
+  }
+#pragma unroll
+  for (int i = 0; i < NHD; ++i) {
+    const int idx = tid + i * 256;
+    const int s = idx / (BN / 4), q = idx % (BN / 4);
+    const int vx = s % BX, r = s / BX;
+    const int vy = r % BY, vz = r / BY;
+    drel[i] = (unsigned)(((vz * a.Y + vy) * a.X + vx) * a.dz_cs + 4 * q) * 4u;
+    dyx[i] = idx < BN / 4 * DS ? (unsigned)vy | ((unsigned)vx << 16) : 0xffffffffu;
+    asm volatile("" : "+v"(drel[i]));
+    asm volatile("" : "+v"(dyx[i]));
+  }
+  const unsigned x_img_bytes = (unsigned)a.Z * a.Y * a.X * a.x_cs * 4u, d_img_bytes = (unsigned)a.Z * a.Y * a.X * a.dz_cs * 4u;
   auto load_box = [&](int box, iw_f32x4 (&xv)[NHX], iw_f32x4 (&dv)[NHD]) {
     int bid = box;
     const int bx = bid % a.nbx; bid /= a.nbx;
@@ -76,29 +105,23 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(IGWArgs a) {
     const int bz = bid % a.nbz;
     const int n = bid / a.nbz;
     const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
+    const __amdgpu_buffer_rsrc_t rx = ursn_plane_rsrc(a.x + (size_t)n * a.Z * a.Y * a.X * a.x_cs + ci0, x_img_bytes);
+    const __amdgpu_buffer_rsrc_t rd = ursn_plane_rsrc(a.dz + (size_t)n * a.Z * a.Y * a.X * a.dz_cs + co0, d_img_bytes);
+    // halo origin (z0 - 1 | z0, y0 - 1, x0 - 1); rows hy in [ylo, yhi) and columns hx in [xlo, xhi) of the halo are inside the image
+    const unsigned xorg = (unsigned)((((z0 - (KZ == 3 ? 1 : 0)) * a.Y + y0 - 1) * a.X + x0 - 1) * a.x_cs) * 4u;
+    const unsigned ylo = y0 == 0 ? 1u : 0u, yn = (unsigned)(a.Y - y0 + 1 < HY ? a.Y - y0 + 1 : HY) - ylo;
+    const unsigned xlo = x0 == 0 ? 1u : 0u, xn = (unsigned)(a.X - x0 + 1 < HX ? a.X - x0 + 1 : HX) - xlo;
 #pragma unroll
     for (int i = 0; i < NHX; ++i) {
-      const int idx = tid + i * 256;
-      const int s = idx >> 2, q = idx & 3;
-      const int hx = s % HX, r = s / HX;
-      const int hy = r % HY, hz = r / HY;
-      const int pz = z0 + hz - (KZ == 3 ? 1 : 0), py = y0 + hy - 1, px = x0 + hx - 1;
-      iw_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < 4 * PS && pz >= 0 && pz < a.Z && py >= 0 && py < a.Y && px >= 0 && px < a.X)
-        v = *(const iw_f32x4*)(a.x + ((((size_t)n * a.Z + pz) * a.Y + py) * a.X + px) * a.x_cs + ci0 + 4 * q);
-      xv[i] = v;
+      const bool ok = ((xyx[i] & 0xffffu) - ylo) < yn && ((xyx[i] >> 16) - xlo) < xn;
+      xv[i] = ursn_buffer_load_f4(rx, ok ? xorg + xrel[i] : URSN_OOB_OFFSET);
     }
+    const unsigned dorg = (unsigned)(((z0 * a.Y + y0) * a.X + x0) * a.dz_cs) * 4u;
+    const unsigned dyn = (unsigned)(a.Y - y0), dxn = (unsigned)(a.X - x0);
 #pragma unroll
     for (int i = 0; i < NHD; ++i) {
-      const int idx = tid + i * 256;
-      const int s = idx / (BN / 4), q = idx % (BN / 4);
-      const int vx = s % BX, r = s / BX;
-      const int vy = r % BY, vz = r / BY;
-      const int pz = z0 + vz, py = y0 + vy, px = x0 + vx;
-      iw_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (idx < BN / 4 * DS && pz < a.Z && py < a.Y && px < a.X)
-        v = *(const iw_f32x4*)(a.dz + ((((size_t)n * a.Z + pz) * a.Y + py) * a.X + px) * a.dz_cs + co0 + 4 * q);
-      dv[i] = v;
+      const bool ok = (dyx[i] & 0xffffu) < dyn && (dyx[i] >> 16) < dxn;
+      dv[i] = ursn_buffer_load_f4(rd, ok ? dorg + drel[i] : URSN_OOB_OFFSET);
     }
   };
   auto store_box = [&](const iw_f32x4 (&xv)[NHX], const iw_f32x4 (&dv)[NHD]) {
@@ -229,6 +252,8 @@ static bool make_igwplan(const ursn_conv_desc& d, IGWPlan& p) {
   p.mode = d.ndim;
   if (d.ndim == 3) { p.Z = d.in_sp[0]; p.Y = d.in_sp[1]; p.X = d.in_sp[2]; }
   else { p.Z = 1; p.Y = d.in_sp[0]; p.X = d.in_sp[1]; }
+  // buffer-path staging (buffer_stage.h): 32-bit byte offsets inside one image, below the out-of-range marker
+  if ((int64_t)p.Z * p.Y * p.X * (ics > ocs ? ics : ocs) * 4 >= (int64_t)0x80000000ll) return false;
   static const int min_x = getenv("URSN_IGEMM_MINX") ? atoi(getenv("URSN_IGEMM_MINX")) : 12;
   if (p.X < min_x && d.algo != 4) return false;
   p.var = (p.mode == 3 && (p.X % 16) != 0 && (p.X % 16) <= 12 && (p.X % 12) == 0) ? 1 : 0;
