@@ -330,6 +330,11 @@ class FullSize(object):
         return np.maximum(y, 0.0) if relu else y
 
     def staged(self, lname, n, a, b, relu):
+        if not self.bf16:   # fp32 plan (normalise-on-load is its default from round 3 on): the affine in fp32, no rounding step
+            z = self.t(lname + ":z")[n, a:b].astype(np.float64)
+            r = self.t(lname + ":rstd").astype(np.float64)
+            y = z * r + (self.beta(lname).astype(np.float64) - self.t(lname + ":mean").astype(np.float64) * r)
+            return np.maximum(y, 0.0) if relu else y
         return staged_bn(self.t(lname + ":z")[n, a:b], self.t(lname + ":mean"), self.t(lname + ":rstd"), self.beta(lname), relu)
 
     def check_stats(self, lname):

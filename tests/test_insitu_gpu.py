@@ -65,9 +65,9 @@ SWITCHES = [
     ("bf16", {"URSN_B3CONV_PW": "0", "URSN_BF16_NORM_ON_LOAD": "0", "URSN_BF16_SKIP0_OWN": "0"}),   # no fused shortcut term, materialised activations, skip inside the concat buffer
     ("bf16", {"URSN_B3CONV": "0", "URSN_B3WGRAD": "0", "URSN_BDECONV": "0", "URSN_BPW": "0"}),      # generic kernels everywhere
     ("fp32", {"URSN_FUSE_BN_BWD_REDUCE": "0", "URSN_FUSE_SHORTCUT_DGRAD": "0", "URSN_RELU_MASK": "0"}),
-    ("fp32", {"URSN_SPLIT_CAT": "0", "URSN_NORM_ON_LOAD": "1"}),
+    ("fp32", {"URSN_SPLIT_CAT": "0", "URSN_NORM_ON_LOAD": "0"}),    # concat buffer, materialised resnet_conv1 activations
     ("fp32", {"URSN_DISABLE_TILED": "1", "URSN_WGRAD_STREAM": "0"}),
-    ("fp32", {"URSN_WGRADQ": "1", "URSN_NORM_ON_LOAD": "1"}),   # 4x4-block weight gradient at level 0 (opt-in, wgradq_tiled_kernel.h)
+    ("fp32", {"URSN_WGRADQ": "1", "URSN_NORM_ON_LOAD": "2"}),   # 4x4-block weight gradient at level 0 (opt-in, wgradq_tiled_kernel.h)
 ]
 
 
@@ -99,13 +99,12 @@ def _full_size_checks(net, P, bf16, ns=5):
     q = fs.q
 
     def stored_or_bn(name, relu):
-        """rows of activation `name`; when the bf16 plan never writes it, what its consumers stage (_insitu.staged_bn)"""
+        """rows of activation `name`; when the plan never writes it, what its consumers stage (FullSize.staged)"""
         try:
             a = fs.t(name)
             return lambda n, lo, hi: a[n, lo:hi].astype(np.float64)
         except Exception as e:
             assert "not materialised" in str(e), e
-            assert bf16
             return lambda n, lo, hi: fs.staged(name, n, lo, hi, relu)
 
     # A: module2/resnet_conv2 of the last decoder unit (8 -> 8), x = bn(z of resnet_conv1), g = the join's masked gradient

@@ -239,11 +239,13 @@ int plan(ursn_net* n, Arena& A) {
     const int cin = in.C + (in2 ? in2->C : 0);
     if (!(cin == co && s == 1)) u.sc = add_layer(n, A, scope + "/shortcut", 0, 1, s, cin, co, in.lvl, lout, poff);
     u.c1 = add_layer(n, A, scope + "/resnet_conv1", 0, 3, s, cin, co, in.lvl, lout, poff);
-    {  // normalise-on-load (URSN_NORM_ON_LOAD=1, off by default): resnet_conv1's BatchNorm has no activation, so where
-       // conv2 (forward + weight gradient) runs on the tiled kernels they can apply it while staging and a1 is never
-       // written.  Measured at cfg3: -0.7 ms of bn_act passes, +0.3..0.5 ms in the MFMA-bound conv kernels (the staging
-       // VALU work is not free there) -> within run-to-run noise, so the plain plan stays the default.
+    {  // normalise-on-load (URSN_NORM_ON_LOAD=0 turns it off, =2 extends it to 16 channels): resnet_conv1's BatchNorm has no
+       // activation, so where conv2 (forward + weight gradient) runs on the tiled kernels they apply it while staging and a1
+       // is never written.  Rounds 1-2 measured it neutral (-0.7 ms of bn_act passes, +0.3..0.5 ms in the conv kernels) and
+       // left it off; with the buffer-path staging of round 3 the affine instantiations lost their spills and gained a
+       // workgroup per CU: 65.2 -> 65.9 images/s at cfg3, on by default.
       const char* e = getenv("URSN_NORM_ON_LOAD");
+      const int nol = e ? atoi(e) : 1;
       ursn_conv_desc d2;
       memset(&d2, 0, sizeof(d2));
       d2.ndim = c.ndim; d2.n = c.max_batch;
@@ -252,8 +254,8 @@ int plan(ursn_net* n, Arena& A) {
       d2.in_mean = d2.in_rstd = d2.in_beta = n->layers[u.c1].mean;   // placeholders: only "non-null" matters here
       ursn_conv_desc d2p = d2;
       d2p.in_mean = d2p.in_rstd = d2p.in_beta = nullptr;
-      // 8-channel layers only: the 16 -> 16 kernel has no registers to spare (245 VGPRs; measured +28 % with the affine)
-      u.a1_virtual = (e && e[0] == '1') && co == 8 && tiled_conv_supported(d2, PASS_FWD) &&
+      // 8-channel layers by default: the 16 -> 16 kernel has no registers to spare (246 VGPRs with the affine)
+      u.a1_virtual = nol >= 1 && (co == 8 || (nol >= 2 && co == 16)) && tiled_conv_supported(d2, PASS_FWD) &&
                      !igemm_conv_supported(d2p, PASS_FWD) && (!tr || tiled_wgrad_supported(d2));
     }
     u.a1 = make_act(n, A, lout, co, tr, u.a1_virtual);
