@@ -14,7 +14,7 @@ ROUND = os.environ.get("URSN_ROUND", "r03")
 BF16 = len(sys.argv) > 1 and sys.argv[1] == "bf16"   # python tools/pmc_traffic.py bf16 -> profiles/r02_pmc_traffic_cfg5_bf16.json
 
 LABEL = [  # rocprof kernel name (regex) -> bench.py kernel label
-    (r"twgradz_kernel<3>", "twgradz<8,8>"),
+    (r"twgradz_kernel<3", "twgradz<8,8>"),
     (r"tconv_kernel<8, 8, 3, false", "tconv<8,8>"), (r"tconv_kernel<8, 8, 3, true", "tconv_dgrad<8,8>"),
     (r"tconv_kernel<16, 16, 3, false", "tconv<16,16>"), (r"tconv_kernel<16, 16, 3, true", "tconv_dgrad<16,16>"),
     (r"twgrad_kernel<16, 16, 3>", "twgrad<16,16>"),
