@@ -17,6 +17,15 @@
 
 typedef float ig_f32x4 __attribute__((ext_vector_type(4)));
 
+template <int... Is, class F>
+__device__ __forceinline__ void ig_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void ig_static_for(F&& f) {
+  ig_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
 struct IGemmArgs {
   const float* in;
   const float* w;
@@ -383,15 +392,18 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
       load_w((ch + 1) * KC, wv);
       if (pw) load_pw((ch + 1) * KC, px, pq);
     }
-#pragma unroll 3
-    for (int t = 0; t < NT; ++t) {
-      const int tz = (KZ == 3) ? t / 9 : 0, ty = (t / 3) % 3, tx = t % 3;
-      const int toff = ((tz * HY + ty) * HX + tx) * 4;
+    // all taps unrolled: every tap offset is an immediate of the ds_read.  Unrolled by 3 with runtime t the loop spent 45
+    // scalar instructions (t / 9, t % 3 by multiply-and-shift) and 12 address adds per 48 MFMAs, and every instruction issued
+    // costs the matrix pipe its slot (DESIGN.md s3 "Round 3")
+    ig_static_for<NT>([&](auto T) {
+      constexpr int t = decltype(T)::value;
+      constexpr int tz = (KZ == 3) ? t / 9 : 0, ty = (t / 3) % 3, tx = t % 3;
+      constexpr int toff = ((tz * HY + ty) * HX + tx) * 4;
 #pragma unroll
       for (int s = 0; s < NQ; ++s) {
         float av[MT], bv[TPW];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) av[m] = wl[wb + (((size_t)m * NT + t) * KC + 4 * s) * 16];
+        for (int m = 0; m < MT; ++m) av[m] = wl[wb + ((m * NT + t) * KC + 4 * s) * 16];
 #pragma unroll
         for (int v = 0; v < TPW; ++v) bv[v] = hal[hb[v] + toff + s * PS * 4];
 #pragma unroll
@@ -399,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void igemm_at_kernel(IGemmArgs a) {
 #pragma unroll
           for (int m = 0; m < MT; ++m) acc[v][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[v], acc[v][m], 0, 0, 0);
       }
-    }
+    });
     if (pw) {   // one more "tap": the shortcut's 1x1 weights on the box's own voxels
 #pragma unroll
       for (int s = 0; s < NQ; ++s) {

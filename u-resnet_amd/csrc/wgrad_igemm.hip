@@ -16,6 +16,15 @@
 
 typedef float iw_f32x4 __attribute__((ext_vector_type(4)));
 
+template <int... Is, class F>
+__device__ __forceinline__ void iw_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void iw_static_for(F&& f) {
+  iw_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
 struct IGWArgs {
   const float* x;
   const float* dz;
@@ -148,9 +157,11 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(IGWArgs a) {
     __syncthreads();
     if (box + 1 < box_end) load_box(box + 1, xv, dv);
     // 3-D: every wave sweeps the 16 rows x 4 quads of the box for its taps; 2-D (SPLITK): wave w takes quad w of every row
-#pragma unroll 2
-    for (int row = 0; row < BZ * BY; ++row) {
-      const int vz = (MODE == 3) ? row / BY : 0, vy = (MODE == 3) ? row % BY : row;
+    // all rows unrolled: every LDS offset is an immediate (by 2 with runtime row the loop paid row / BY, row % BY and the
+    // address adds per row; every instruction issued costs the matrix pipe its slot, DESIGN.md s3 "Round 3")
+    iw_static_for<BZ * BY>([&](auto ROW) {
+      constexpr int row = decltype(ROW)::value;
+      constexpr int vz = (MODE == 3) ? row / BY : 0, vy = (MODE == 3) ? row % BY : row;
       const float* xr = xl + ((vz * HY + vy) * HX) * 4;
       const float* dr = dl + (row * BX) * 4;
 #pragma unroll
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(IGWArgs a) {
           for (int m = 0; m < MT; ++m) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[m], acc[i][m], 0, 0, 0);
         }
       }
-    }
+    });
   }
 
   // D: row = ci (4*kl + r), col = co (il)
