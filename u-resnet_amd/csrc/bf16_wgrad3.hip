@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void b3wgrad_kernel(W3Args a) {
     unsigned sb[MTW];
 #pragma unroll
     for (int m = 0; m < MTW; ++m) sb[m] = (unsigned)(((q + dzm[m]) & 3) * G::XPLANE) + aoff[m];   // plane q - 1 + dz -> slot (q + dz) & 3
-#pragma unroll 2
+#pragma unroll   // all rows: every LDS offset an immediate
     for (int r = 0; r < TY; ++r) {
       const unsigned char* bp = db + boff + r * (32 * DPV * 16);
       const bfx8 B = w3_tr_pair(bp, bp + 4 * DPV * 16);
@@ -406,9 +406,15 @@ __global__ __launch_bounds__(256, 3) void b3wgradz_kernel(W3Args a) {
     load_d(q + 2, 0); load_d(q + 3, 1);
     const unsigned char* db = dbuf + ((q + bhalf) & 3) * G::DPLANE + boff;
     unsigned sb[MTW];
+    // plane q - 1 + s -> slot (q + s) % 6: the four live slot offsets, the remainder taken once per step (was once per tile)
+    const int q6 = q % 6;
+    unsigned so[4];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) sb[m] = (unsigned)(((q + sm[m] + 6) % 6) * G::XPLANE) + aoff[m];   // plane q - 1 + s -> slot (q + s) % 6
-#pragma unroll 2
+    for (int j = 0; j < 4; ++j) so[j] = (unsigned)((q6 + j >= 6 ? q6 + j - 6 : q6 + j) * G::XPLANE);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) sb[m] = (sm[m] == 0 ? so[0] : sm[m] == 1 ? so[1] : sm[m] == 2 ? so[2] : so[3]) + aoff[m];
+    // rows fully unrolled: every LDS offset of the 96 transposing reads is an immediate
+#pragma unroll
     for (int r = 0; r < TY; ++r) {
       const unsigned char* bp = db + r * (32 * 16);
       const bfx8 B = w3_tr_pair(bp, bp + 4 * 16);
