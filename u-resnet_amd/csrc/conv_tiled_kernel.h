@@ -188,13 +188,18 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
     asm volatile("" : "+v"(soff[i]));
   }
   asm volatile("" : "+v"(sin_mask));
+  if constexpr (aff) {   // an element outside the image arrives as 0 and must stay 0: its shift is zeroed once, the store has no per-element test
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i)
+      if (!((sin_mask >> i) & 1u)) treg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   const ptrdiff_t in_plane = (ptrdiff_t)a.Y * a.X * a.in_cs;
   const unsigned in_plane_bytes = (unsigned)in_plane * 4u;
   const float* in_img = a.in + (size_t)n * a.Z * in_plane;
   const bool scalar_in = a.cin_w == 1 && !FLIP;   // single-channel input (conv0): scalar fetch, lanes 1..3 stay 0
   auto stage_load = [&](int zin) {
     const bool zok = zin >= 0 && zin < a.Z;
-    if constexpr (aff) stage_inb = zok ? sin_mask : 0u;
+    if constexpr (aff) stage_inb = zok ? 1u : 0u;   // wave-uniform: a plane outside the volume skips the affine
     const __amdgpu_buffer_rsrc_t r = ursn_plane_rsrc(in_img + (ptrdiff_t)zin * in_plane, zok ? in_plane_bytes : 0u);
     if (scalar_in) {
 #pragma unroll
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
         f32x4 v = stage[i];
         // normalise-on-load is applied here, not at the load: the loads stay in flight during the MFMA block
         if constexpr (aff) {
-          if ((stage_inb >> i) & 1u) v = v * sreg[i] + treg[i];
+          if (stage_inb) v = v * sreg[i] + treg[i];
         }
         lds[(size_t)slot * NQ * PS + idx] = v;
       }

@@ -105,6 +105,13 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
 #pragma unroll
   for (int i = 0; i < NSD; ++i) asm volatile("" : "+v"(dgo[i]));
   asm volatile("" : "+v"(xin));
+  // normalise-on-load: an element outside the image arrives as 0 and must stay 0 -- its shift is zeroed here, once, so the
+  // store applies v * s + t_i without a per-element test (a plane outside the volume skips the affine by a scalar branch)
+  wg_f32x4 aff_ti[aff ? NSX : 1];
+  if constexpr (aff) {
+#pragma unroll
+    for (int i = 0; i < NSX; ++i) aff_ti[i] = ((xin >> i) & 1u) ? aff_t4 : (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   // one resource per z plane (num_records = 0 for a plane outside the volume); inside the loop the plane pointers advance by
   // two planes per step instead of being rebuilt from (n, z) with 64-bit multiplies
   const unsigned xplane_bytes = (unsigned)a.Y * a.X * a.x_cs * 4u, dplane_bytes = (unsigned)a.Y * a.X * a.dz_cs * 4u;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
   auto xnext = [](int off) { return off + XPLANE == 6 * XPLANE ? 0 : off + XPLANE; };
   auto load_x = [&](int zin, wg_f32x4 (&sx)[NSX], unsigned& inb) {
     const bool zok = zin >= 0 && zin < a.Z;
-    inb = zok ? xin : 0u;
+    inb = zok ? 1u : 0u;
     const __amdgpu_buffer_rsrc_t r = ursn_plane_rsrc(ximg + (ptrdiff_t)zin * xplane_floats, zok ? xplane_bytes : 0u);
 #pragma unroll
     for (int i = 0; i < NSX; ++i) sx[i] = ursn_buffer_load_f4(r, xgo[i]);
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
       int idx = tid + i * NTHR;
       if (idx < XQ * PS) {
         wg_f32x4 v = sx[i];
-        if constexpr (aff) if ((inb >> i) & 1u) v = v * aff_s4 + aff_t4;   // normalise-on-load, applied at the store: loads stay in flight
+        if constexpr (aff) if (inb) v = v * aff_s4 + aff_ti[i];   // normalise-on-load, applied at the store: loads stay in flight (inb: wave-uniform)
         *(wg_f32x4*)(xr + slot_off + idx * 4) = v;
       }
     }
