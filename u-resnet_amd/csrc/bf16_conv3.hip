@@ -421,12 +421,18 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
       if (p < z1) {
         // younger than the DMA of plane p + 1 (issued AHEAD - 1 iterations ago): the stores of output planes p - AHEAD .. p - 1
         // and the DMAs of planes p + 2 .. p + AHEAD
-        int kst = 0, nd = 0;
+        if (p - AHEAD >= z0 && p + AHEAD <= z1) {   // steady state: every plane of the window exists -> a constant count
+          constexpr int STEADY = AHEAD * krow + G::NST * (AHEAD - 1);
+          static_assert(STEADY <= 63, "vmcnt immediate");
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY) : "memory");
+        } else {
+          int kst = 0, nd = 0;
 #pragma unroll
-        for (int k = 1; k <= AHEAD; ++k) kst += (p - k >= z0 && p - k < z1) ? krow : 0;
+          for (int k = 1; k <= AHEAD; ++k) kst += (p - k >= z0 && p - k < z1) ? krow : 0;
 #pragma unroll
-        for (int k = 2; k <= AHEAD; ++k) nd += (p + k <= z1) ? 1 : 0;
-        wait_vm(kst + G::NST * nd);
+          for (int k = 2; k <= AHEAD; ++k) nd += (p + k <= z1) ? 1 : 0;
+          wait_vm(kst + G::NST * nd);
+        }
         __builtin_amdgcn_s_barrier();   // plane p + 1 is in LDS for every wave; nobody reads this slot any more
       }
       slot = slot + 1 == NSLOT ? 0 : slot + 1;
