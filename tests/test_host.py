@@ -144,6 +144,20 @@ def test_query_sizes_and_errors():
     assert lib.ursn_conv_wgrad_scratch_bytes(ctypes.byref(d)) > 0
 
 
+def test_buffer_path_kernels_refuse_planes_beyond_their_offset_range():
+    """The z-marching tiled kernels stage through buffer instructions with 32-bit byte offsets inside one z plane and an
+    out-of-range marker at 2 GB (csrc/buffer_stage.h): the host plan must hand a layer whose plane reaches the marker to the
+    generic kernels instead (plan query only, nothing runs)."""
+    lib = _lib.load()
+    d = _lib.ursn_conv_desc()
+    d.ndim, d.n, d.cin, d.cout, d.k, d.stride = 3, 1, 8, 8, 3, 1
+    d.in_sp[0] = 8
+    d.in_sp[1] = d.in_sp[2] = 4096          # 4096^2 x 8 channels x 4 B = 512 MB per plane
+    assert lib.ursn_conv_bs_blocks(ctypes.byref(d)) > 0
+    d.in_sp[1] = d.in_sp[2] = 8192          # 2 GB per plane: at the marker
+    assert lib.ursn_conv_bs_blocks(ctypes.byref(d)) == 0
+
+
 # ---- synthetic IO (larcv_threadio protocol) ------------------------------------------------------------------------
 def test_synthetic_threadio_protocol():
     io_ = sio.synthetic_threadio()
