@@ -31,6 +31,16 @@ BMap make_bmap(int64_t V, int C) {
 }
 
 __device__ __forceinline__ u32x4 ld16(const bf16_t* p) { return __builtin_nontemporal_load((const u32x4*)p); }
+#ifndef URSN_BEW_NT_STORE
+#define URSN_BEW_NT_STORE 1
+#endif
+__device__ __forceinline__ void st16(bf16_t* p, u32x4 v) {
+#if URSN_BEW_NT_STORE
+  __builtin_nontemporal_store(v, (u32x4*)p);
+#else
+  *(u32x4*)p = v;
+#endif
+}
 
 // NS x 8 per-thread fp32 sums -> partial[block][NS][C] doubles.  Lanes that share a channel piece (lane & (CP - 1)) are summed
 // with shuffles in fp64, then the four waves (CP <= 32) or the 256 / CP threads of a piece (CP >= 64) through LDS in a FIXED
@@ -134,8 +144,8 @@ __global__ __launch_bounds__(256) void bbn_act_kernel(BBnActArgs a, int shift) {
             if (relu) { t = fmaxf(t, 0.f); t2 = fmaxf(t2, 0.f); }
             y[j] = t; y2[j] = t2;
           }
-          *(u32x4*)(a.y + v * a.ycs) = pack8(y);
-          *(u32x4*)(a.y + v * a.ycs + 8) = pack8(y2);
+          st16(a.y + v * a.ycs, pack8(y));
+          st16(a.y + v * a.ycs + 8, pack8(y2));
           continue;
         }
 #pragma unroll
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256) void bbn_act_kernel(BBnActArgs a, int shift) {
           if (relu) t = fmaxf(t, 0.f);
           y[j] = t;
         }
-        *(u32x4*)(a.y + v * a.ycs + c) = pack8(y);
+        st16(a.y + v * a.ycs + c, pack8(y));
         if (a.mask_out) {
           unsigned bits = 0;
 #pragma unroll
@@ -286,9 +296,9 @@ __global__ __launch_bounds__(256) void bbn_bwd_apply_kernel(BBnBwdArgs a, int sh
           if constexpr (HAS2) dz2[j] = rs2[j] * (gj - mg[j] - (z2[j] - mu2[j]) * rs2[j] * mgx2[j]);
           if constexpr (DRES) dr[j] = dacc ? dr[j] + gj : gj;
         }
-        *(u32x4*)(a.dz + v * a.dzcs + c) = pack8(dz);
-        if constexpr (HAS2) *(u32x4*)(a.dz2 + v * a.dz2cs + c) = pack8(dz2);
-        if constexpr (DRES) *(u32x4*)(a.dres + v * a.drescs + c) = pack8(dr);
+        st16(a.dz + v * a.dzcs + c, pack8(dz));
+        if constexpr (HAS2) st16(a.dz2 + v * a.dz2cs + c, pack8(dz2));
+        if constexpr (DRES) st16(a.dres + v * a.drescs + c, pack8(dr));
       }
     };
     if ((ch + 1) * chunkv <= a.V) body(std::true_type{});
