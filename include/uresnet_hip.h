@@ -161,6 +161,9 @@ int ursn_profile_read(ursn_net* net, ursn_prof_rec* out, int64_t max_recs, int64
  * on = 0 serialises them on the caller's stream (per-kernel timing: concurrent kernels time-slice, so event intervals
  * would include the partner's work). */
 int ursn_set_wgrad_overlap(ursn_net* net, int32_t on);
+/* Name of the kernel the calling thread's last op-level / net-level dispatch chose (e.g. "tconv<8,8>", "bcbconv_bf16+pw"):
+ * what ursn_prof_rec.kernel is filled from; the dispatch tests assert it.  Static storage, never NULL. */
+const char* ursn_last_kernel_name(void);
 
 /* ---- op-level entry points (unit parity tests; same kernels the net-level calls use) ----- */
 typedef struct ursn_conv_desc {
@@ -237,6 +240,11 @@ int ursn_conv_backward_weight(const ursn_conv_desc* d, const float* x, const flo
 size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d);
 /* Blocks of bs_partial a data-gradient call with fused BatchNorm-backward reductions writes (0: shape not supported). */
 int32_t ursn_conv_bs_blocks(const ursn_conv_desc* d);
+
+/* "Explain plan": name of the kernel family the dispatcher hands this descriptor to (pass: 0 forward, 1 data gradient,
+ * 2 weight gradient), e.g. "tconv", "igemm", "bdconv", "gconv_mfma".  Host logic only -- no device access, nothing runs:
+ * what the plan-guard tests and tools/ query. */
+int ursn_conv_plan(const ursn_conv_desc* d, int32_t pass, char* out, size_t cap);
 
 /* Batch-statistics BatchNorm (beta only) + optional residual + optional ReLU:
  * y = act((z-mu)*rsqrt(var+eps)+beta [+ res]); stats_out (optional) gets {mean[C], rstd[C]} as fp32. */

@@ -44,6 +44,15 @@ CASES = [
     ("k3s1_32_16_cb", 3, 1, (12, 18, 40), 32, 16, 3, 1, 0),     # its data gradient contracts 16 channels
     ("k3s1_32_64_cb", 3, 1, (5, 8, 32), 32, 64, 3, 1, 0),
     ("k3s1_16_24_cb", 3, 2, (7, 11, 33), 16, 24, 3, 1, 0),
+    # weight-streaming split-K kernel of the deep levels (bf16_convdeep.hip): >= 64 contraction channels; 8^3 / 16^3 / 6^3
+    # levels (split over workgroups where voxels are few), 2C -> C decoder layers (two rounds of chunks), ragged boxes
+    ("k3s1_64_64_dp", 3, 4, (8, 8, 8), 64, 64, 3, 1, 0),
+    ("k3s1_128_128_dp", 3, 2, (16, 16, 16), 128, 128, 3, 1, 0),
+    ("k3s1_256_256_dp", 3, 4, (8, 8, 8), 256, 256, 3, 1, 0),
+    ("k3s1_256_256_6_dp", 3, 2, (6, 6, 6), 256, 256, 3, 1, 0),
+    ("k3s1_256_128_dp", 3, 1, (8, 8, 8), 256, 128, 3, 1, 0),
+    ("k3s1_128_64_rag_dp", 3, 1, (5, 12, 21), 128, 64, 3, 1, 0),
+    ("k3s1_64_96_dp", 3, 1, (6, 10, 34), 64, 96, 3, 1, 0),       # produced channels not a multiple of 64; its data gradient contracts 96
     ("k3s2_8_16", 3, 2, (8, 12, 36), 8, 16, 3, 2, 0),
     ("k3s2_odd", 3, 1, (7, 9, 21), 16, 32, 3, 2, 0),            # odd sizes: TF SAME pad-before = 1
     ("k1s1_16_8", 3, 2, (7, 9, 37), 16, 8, 1, 1, 0),            # 1x1 between 8 / 16 channels: operands straight from global memory
@@ -80,11 +89,16 @@ def test_bf16_conv_forward_data_and_weight_gradients(case):
     if tag.endswith("_cb"):   # the dispatch really took the channel-block kernel
         lib.ursn_last_kernel_name.restype = ctypes.c_char_p
         assert lib.ursn_last_kernel_name().startswith(b"bcbconv_bf16"), lib.ursn_last_kernel_name()
+    if tag.endswith("_dp"):   # ... the deep-level kernel
+        lib.ursn_last_kernel_name.restype = ctypes.c_char_p
+        assert lib.ursn_last_kernel_name().startswith(b"bdconv_bf16"), lib.ursn_last_kernel_name()
     dxg = torch.full(x.shape, float("nan"), dtype=torch.bfloat16, device="cuda")
     _lib.check(lib.ursn_conv_backward_data(ctypes.byref(d), P(dyg), P(wg), P(dxg), 0, stream()))
     torch.cuda.synchronize()
     e = np.abs(dxg.float().cpu().numpy() - dx).max() / np.abs(dx).max()
     assert e <= BF_TOL, ("dgrad", e)
+    if tag.endswith("_dp") and co % 64 == 0:   # the contraction splits over 2 | 4 waves: an even number of 32-channel chunks
+        assert lib.ursn_last_kernel_name().startswith(b"bdconv_bf16"), lib.ursn_last_kernel_name()
     base, baseg = bf(rng.standard_normal(x.shape))
     _lib.check(lib.ursn_conv_backward_data(ctypes.byref(d), P(dyg), P(wg), P(baseg), 1, stream()))
     torch.cuda.synchronize()
@@ -99,7 +113,7 @@ def test_bf16_conv_forward_data_and_weight_gradients(case):
         assert rel_err(dwg.cpu().numpy(), rep * dw) < 2e-5, ("wgrad", rep)
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if not c[8]][:22], ids=[c[0] for c in CASES if not c[8]][:22])
+@pytest.mark.parametrize("case", [c for c in CASES if not c[8]][:29], ids=[c[0] for c in CASES if not c[8]][:29])
 def test_bf16_conv_forward_fused_statistics(case):
     tag, ndim, N, S, ci, co, k, st, tr = case
     lib = _lib.load()

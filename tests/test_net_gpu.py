@@ -352,8 +352,10 @@ def test_split_concat_matches_materialised_concat(monkeypatch):
                      net._sizes.workspace_bytes if hasattr(net, "_sizes") else 0)
     assert abs(out["0"][0] - out["1"][0]) <= 1e-5 * abs(out["0"][0])
     assert max_rel(out["1"][2], out["0"][2]) < 1e-5
-    for k, g0 in out["0"][1].items():
-        assert l2_rel(out["1"][1][k], g0) < 2e-3, k   # fp32 summation order + the odd ReLU-mask flip: 1.1e-3 seen
+    errs = sorted(((l2_rel(out["1"][1][k], g0), k) for k, g0 in out["0"][1].items()), reverse=True)
+    print("split vs materialised concat, worst filter-gradient tensors:", ["%s %.2e" % (k, e) for e, k in errs[:4]])
+    for e, k in errs:
+        assert e < 2e-3, k   # fp32 summation order + the odd ReLU-mask flip; the worst tensors are printed above
 
 
 def test_normalise_on_load_plan_matches_default(monkeypatch):
@@ -433,20 +435,34 @@ def test_all_zero_batch_does_not_fall_off_a_cliff():
     dd, ld, wd = (torch.from_numpy(a).cuda() for a in (data, label, weight))
     zd = torch.zeros_like(dd)
 
-    def timed(x):
+    import ctypes
+    from uresnet_amd import _lib
+    lib = _lib.load()
+
+    def launches(x):
+        """(layer, pass, kernel, launches) of every launch group of one step, and the step's wall time (printed only)."""
         for _ in range(2):
             net.zero_gradients(None)
             net.accum_gradients(None, x, ld, wd, fetch=False)
         torch.cuda.synchronize()
+        _lib.check(lib.ursn_profile_enable(net._handle, 1))
         t0 = time.perf_counter()
-        for _ in range(3):
-            net.zero_gradients(None)
-            net.accum_gradients(None, x, ld, wd, fetch=False)
+        net.zero_gradients(None)
+        net.accum_gradients(None, x, ld, wd, fetch=False)
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / 3
-    t_norm, t_zero = timed(dd), timed(zd)
+        dt = time.perf_counter() - t0
+        cnt = ctypes.c_int64(0)
+        _lib.check(lib.ursn_profile_read(net._handle, None, 0, ctypes.byref(cnt)))
+        recs = (_lib.ursn_prof_rec * max(cnt.value, 1))()
+        _lib.check(lib.ursn_profile_read(net._handle, recs, cnt.value, ctypes.byref(cnt)))
+        _lib.check(lib.ursn_profile_enable(net._handle, 0))
+        return [(r.layer, r.pass_, r.kernel, r.launches) for r in recs], dt
+    l_norm, t_norm = launches(dd)
+    l_zero, t_zero = launches(zd)
     m = net.read_metrics()
-    print("128^3 step: %.2f ms on data, %.2f ms on an all-zero batch" % (t_norm * 1e3, t_zero * 1e3))
+    print("128^3 step: %.2f ms on data, %.2f ms on an all-zero batch, %d launch groups" % (t_norm * 1e3, t_zero * 1e3, len(l_zero)))
     assert np.isfinite(m[0]) and np.isnan(m[2])          # acc_nonzero over no pixels (lib/ssnet.py:59-62)
     assert all(np.isfinite(v).all() for v in net.get_gradients().values())
-    assert t_zero < 1.25 * t_norm
+    # the structural property (a wall-clock ratio on a shared box flakes): the all-zero step issues exactly the launches of a
+    # normal step -- same kernels, same launch counts per (layer, pass): no data-dependent re-walk of any tensor
+    assert len(l_zero) > 100 and l_zero == l_norm

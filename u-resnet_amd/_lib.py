@@ -90,6 +90,8 @@ _SIGS = {
     "ursn_conv_backward_weight": (C.c_int, [C.POINTER(ursn_conv_desc), _P, _P, _P, _P, C.c_size_t, _P]),
     "ursn_conv_wgrad_scratch_bytes": (C.c_size_t, [C.POINTER(ursn_conv_desc)]),
     "ursn_conv_bs_blocks": (C.c_int32, [C.POINTER(ursn_conv_desc)]),
+    "ursn_conv_plan": (C.c_int, [C.POINTER(ursn_conv_desc), C.c_int32, C.c_char_p, C.c_size_t]),
+    "ursn_last_kernel_name": (C.c_char_p, []),
     "ursn_bn_forward": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, C.c_int32, _P, _P,
                                   C.c_size_t, _P]),
     "ursn_bn_backward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, C.c_int32, _P,

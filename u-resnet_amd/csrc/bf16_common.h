@@ -57,6 +57,13 @@ int bconv_grid_blocks(const GatherGeom& g);
 size_t bconv_stats_scratch_doubles(const GatherGeom& g);   // for ONE launch; x classes for a transposed conv
 int bconv_stats_finalize(const GatherGeom& g, const double* partial, int total_blocks, int64_t V, float eps, float* mean,
                          float* rstd, hipStream_t s);
+// Buffer-path addressing (buffer_stage.h): EVERY tensor a launch builds a z-plane resource / 32-bit byte offset for -- the
+// auxiliary operands (fused shortcut term, second output, fused BatchNorm-backward operands) as well as in / out -- must
+// keep a z plane below the out-of-range marker.  cs = channel stride in bf16 elements; 0 = operand absent.
+static inline bool ursn_bf16_plane_ok(const GatherGeom& g, int cs) {
+  const int64_t pv = (int64_t)g.in_d[1] * g.in_d[2], qv = (int64_t)g.out_d[1] * g.out_d[2];
+  return (pv > qv ? pv : qv) * (int64_t)cs * 2 < (int64_t)0x40000000;
+}
 // 8 -> 8 channel 3x3x3 stride-1 layers run on the input-stationary kernel of bf16_conv3.hip; the entry points above dispatch
 bool b3conv_ok(const GatherGeom& g);
 size_t b3conv_pack_elems();
@@ -96,6 +103,16 @@ bool bcbconv_pw_ok(const GatherGeom& g);
 int launch_bcbconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                    double* stats_partial, hipStream_t s, const bf16_t* pw = nullptr, int pw_cs = 0, const float* pw_w = nullptr);
 int bcbconv_stats_finalize(const GatherGeom& g, const double* partial, int64_t V, float eps, float* mean, float* rstd, hipStream_t s);
+// 3x3x3 stride-1 layers with >= 64 contraction channels (levels 3-5 of an F = 8 network): weight-streaming kernel with the
+// contraction split inside the workgroup, over workgroups too where voxels are few (bf16_convdeep.hip); launch_bconv and the
+// bconv_* helpers dispatch.  Its packed-weight scratch (bdconv_pack_elems) includes the fp32 slabs of a split-K launch.
+bool bdconv_ok(const GatherGeom& g);
+size_t bdconv_pack_elems(const GatherGeom& g);
+int bdconv_grid_blocks(const GatherGeom& g);
+size_t bdconv_stats_scratch_doubles(const GatherGeom& g);
+int launch_bdconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
+                  double* stats_partial, hipStream_t s);
+int bdconv_stats_finalize(const GatherGeom& g, const double* partial, int64_t V, float eps, float* mean, float* rstd, hipStream_t s);
 // 1x1 stride-1 conv between 8 / 16 channel tensors, operands straight from global memory (bf16_pointwise.hip)
 bool bpw_ok(const GatherGeom& g);
 int bpw_grid_blocks(const GatherGeom& g);

@@ -449,6 +449,7 @@ size_t bconv_pack_elems(const GatherGeom& g) {
   if (bpw_ok(g)) return 8;
   if (b3conv_ok(g)) return b3conv_pack_elems();
   if (bcbconv_ok(g)) return bcbconv_pack_elems(g);
+  if (bdconv_ok(g)) return bdconv_pack_elems(g);
   BPlan p;
   if (!bconv_plan(g, p)) return 0;
   return (size_t)p.ncob * p.nchunks * p.nj * p.cot * 64 * 8 + 8;   // + the zero piece
@@ -458,6 +459,7 @@ size_t bconv_stats_scratch_doubles(const GatherGeom& g) {
   if (bpw_ok(g)) return (size_t)bpw_grid_blocks(g) * 2 * 16;
   if (b3conv_ok(g)) return (size_t)b3conv_grid_blocks(g) * 2 * 16;
   if (bcbconv_ok(g)) return bcbconv_stats_scratch_doubles(g);
+  if (bdconv_ok(g)) return bdconv_stats_scratch_doubles(g);
   BPlan p;
   if (!bconv_plan(g, p)) return 0;
   return (size_t)p.ncob * p.gridx * 2 * 16 * p.cot;
@@ -480,6 +482,7 @@ int bconv_grid_blocks(const GatherGeom& g) {
   if (bpw_ok(g)) return bpw_grid_blocks(g);
   if (b3conv_ok(g)) return b3conv_grid_blocks(g);
   if (bcbconv_ok(g)) return bcbconv_grid_blocks(g);
+  if (bdconv_ok(g)) return bdconv_grid_blocks(g);
   BPlan p;
   return bconv_plan(g, p) ? p.gridx : 0;
 }
@@ -488,6 +491,7 @@ int bconv_stats_finalize(const GatherGeom& g, const double* partial, int total_b
                          float* rstd, hipStream_t s) {
   if (bpw_ok(g) || b3conv_ok(g)) return launch_bn_stats_final(partial, total_blocks, g.Nn, 16, V, eps, mean, rstd, s);
   if (bcbconv_ok(g)) return bcbconv_stats_finalize(g, partial, V, eps, mean, rstd, s);
+  if (bdconv_ok(g)) return bdconv_stats_finalize(g, partial, V, eps, mean, rstd, s);
   BPlan p;
   URSN_REQUIRE(bconv_plan(g, p), "bf16 conv: unsupported geometry");
   URSN_TRY(launch_bn_stats_final_blocked(partial, total_blocks, g.Nn, 16 * p.cot, 16 * p.cot, (size_t)total_blocks * 2 * 16 * p.cot, V, eps,
@@ -503,6 +507,11 @@ int launch_bconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, 
     URSN_REQUIRE(!stats_partial || (stats_off == 0 && (stats_total <= 0 || stats_total == bcbconv_grid_blocks(g))),
                  "bf16 channel-block conv: its statistics partials are one launch's own");
     return launch_bcbconv(g, in, w, Kw, Nw, wpack, out, stats_partial, s);
+  }
+  if (bdconv_ok(g)) {   // >= 64 contraction channels, 3-D k3 s1: the weight-streaming split-K kernel (bf16_convdeep.hip)
+    URSN_REQUIRE(!stats_partial || (stats_off == 0 && (stats_total <= 0 || stats_total == bdconv_grid_blocks(g))),
+                 "bf16 deep conv: its statistics partials are one launch's own");
+    return launch_bdconv(g, in, w, Kw, Nw, wpack, out, stats_partial, s);
   }
   BPlan p;
   URSN_REQUIRE(bconv_plan(g, p), "bf16 conv: unsupported geometry (channels %d -> %d, strides %d / %d)", g.K, g.Nn, g.in_cs, g.out_cs);

@@ -421,16 +421,26 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
       if (p < z1) {
         // younger than the DMA of plane p + 1 (issued AHEAD - 1 iterations ago): the stores of output planes p - AHEAD .. p - 1
         // and the DMAs of planes p + 2 .. p + AHEAD
+        // `accumulate`: the old-value loads of iterations p + 2 - AHEAD .. p (krow each, issued in front of that iteration's
+        // DMA) are younger than the DMA of plane p + 1 as well.  The counts assume what the compiler emits today: ONE
+        // buffer_store_b64 per (row, 8-channel group) and ONE buffer_load_b64 per old value.  More VM operations than counted
+        // (a split store) would only make the wait stricter; fewer cannot happen (a 64-bit value is one instruction at most).
         if (p - AHEAD >= z0 && p + AHEAD <= z1) {   // steady state: every plane of the window exists -> a constant count
           constexpr int STEADY = AHEAD * krow + G::NST * (AHEAD - 1);
+          constexpr int STEADY_ACC = STEADY + (AHEAD - 1) * krow < 63 ? STEADY + (AHEAD - 1) * krow : 63;   // a smaller count only waits for more
           static_assert(STEADY <= 63, "vmcnt immediate");
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY) : "memory");
+          if (a.accumulate) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY_ACC) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY) : "memory");
         } else {
           int kst = 0, nd = 0;
 #pragma unroll
           for (int k = 1; k <= AHEAD; ++k) kst += (p - k >= z0 && p - k < z1) ? krow : 0;
 #pragma unroll
           for (int k = 2; k <= AHEAD; ++k) nd += (p + k <= z1) ? 1 : 0;
+          if (a.accumulate) {
+#pragma unroll
+            for (int k = 0; k <= AHEAD - 2; ++k) kst += (p - k - 1 >= z0 && p - k - 1 < z1) ? krow : 0;   // old_load of iteration p - k
+          }
           wait_vm(kst + G::NST * nd);
         }
         __builtin_amdgcn_s_barrier();   // plane p + 1 is in LDS for every wave; nobody reads this slot any more
@@ -572,6 +582,9 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
                   const float* pw_w, const B3BnRed* bs, const B3Affine* aff, bf16_t* out2, int out2_cs, const float* in_f32) {
   URSN_REQUIRE(b3conv_ok(g), "bf16 3x3x3 conv: unsupported geometry");
   URSN_REQUIRE(!pw || (b3conv_pw_ok(g) && pw_w && !stats_partial && (pw_cs & 7) == 0), "bf16 3x3x3 conv: the fused shortcut term needs the 8 -> 16 data gradient");
+  URSN_REQUIRE((!pw || ursn_bf16_plane_ok(g, pw_cs)) && (!out2 || ursn_bf16_plane_ok(g, out2_cs)) &&
+               (!bs || (ursn_bf16_plane_ok(g, bs->z_cs) && ursn_bf16_plane_ok(g, bs->y_cs) && ursn_bf16_plane_ok(g, bs->z2_cs))),
+               "bf16 3x3x3 conv: a z plane of an auxiliary operand (strides %d / %d) reaches the buffer path's out-of-range marker", pw_cs, out2_cs);
   B3PackArgs k;
   k.pw_w = pw ? pw_w : nullptr;
   k.w = w; k.wp = wpack; k.Kw = Kw > 0 ? Kw : g.K; k.Nw = Nw > 0 ? Nw : g.Nn;

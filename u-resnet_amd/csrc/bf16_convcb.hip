@@ -455,6 +455,7 @@ int launch_bcbconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw
                    double* stats_partial, hipStream_t s, const bf16_t* pw, int pw_cs, const float* pw_w) {
   URSN_REQUIRE(bcbconv_ok(g), "bf16 channel-block conv: unsupported geometry");
   URSN_REQUIRE(!pw || (pw_w && !stats_partial && (pw_cs & 7) == 0 && pw_cs >= g.K), "bf16 channel-block conv: bad fused shortcut arguments");
+  URSN_REQUIRE(!pw || ursn_bf16_plane_ok(g, pw_cs), "bf16 channel-block conv: a z plane of the fused shortcut operand (stride %d) reaches the buffer path's out-of-range marker", pw_cs);
   const CBPlan p = cb_plan(g);
   CBPackArgs k;
   k.w = w; k.wp = wpack; k.Kw = Kw > 0 ? Kw : g.K; k.Nw = Nw > 0 ? Nw : g.Nn;

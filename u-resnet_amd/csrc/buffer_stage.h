@@ -37,3 +37,7 @@ __device__ __forceinline__ void ursn_bstore_b64(bst_u32x2 v, __amdgpu_buffer_rsr
 __device__ __forceinline__ void ursn_bload_lds_b128(__amdgpu_buffer_rsrc_t r, void* lds, unsigned off) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, off, 0, 0, 0);
 }
+// ... with a scalar offset on top of the per-lane one (a channel chunk inside the voxel); the bounds check covers the sum
+__device__ __forceinline__ void ursn_bload_lds_b128_so(__amdgpu_buffer_rsrc_t r, void* lds, unsigned off, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, off, soff, 0, 0);
+}

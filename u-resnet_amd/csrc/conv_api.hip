@@ -495,6 +495,56 @@ int launch_tiled_wgrad(const ursn_conv_desc& d, const float* x, const float* dy,
 
 extern "C" int32_t ursn_conv_bs_blocks(const ursn_conv_desc* d) { return d ? tiled_conv_bs_blocks(*d) : 0; }
 
+// "Explain plan": the kernel family the dispatcher would hand this descriptor / pass to -- host logic only, no device access
+// (CPU-side tests of the plan guards; pass: 0 forward, 1 data gradient, 2 weight gradient).  Follows conv_dispatch /
+// wgrad_dispatch / launch_bconv / launch_bwgrad predicate by predicate.
+extern "C" int ursn_conv_plan(const ursn_conv_desc* d0, int32_t pass_, char* out, size_t cap) {
+  URSN_REQUIRE(d0 && out && cap > 0 && pass_ >= 0 && pass_ <= 2, "conv_plan: bad argument");
+  const ConvPass pass = (ConvPass)pass_;
+  ursn_conv_desc d = *d0;
+  const char* name = "gather";
+  GatherGeom g[8];
+  if (d.dtype == 1) {
+    if (d.cin == 1) { d.cin = 8; d.in_cstride = 8; }
+    const int n = build_geoms(d, pass, g);
+    URSN_REQUIRE(n >= 1, "conv_plan: bad descriptor");
+    int first = 0;
+    while (first < n - 1 && g[first].ntaps == 0) ++first;
+    if (pass == PASS_WGRAD) name = b3wgrad_ok(g[0]) ? "b3wgrad" : (bwgrad_scratch_bytes(g[0]) ? "bwgrad" : "none");
+    else if (bdeconv_ok(g, n)) name = "bdeconv";
+    else if (bpw_ok(g[first])) name = "bpw";
+    else if (b3conv_ok(g[first])) name = "b3conv";
+    else if (bcbconv_ok(g[first])) name = "bcbconv";
+    else if (bdconv_ok(g[first])) name = "bdconv";
+    else name = bconv_pack_elems(g[first]) ? "bconv" : "none";
+    snprintf(out, cap, "%s", name);
+    return 0;
+  }
+  URSN_REQUIRE(build_geoms(d, pass, g) >= 1, "conv_plan: bad descriptor");
+  if (pass == PASS_WGRAD) {
+    if (d.in_mean || (d.in_split && !pointwise_wgrad_supported(d))) name = tiled_wgrad_supported(d) ? "twgrad" : "none";
+    else if (pointwise_wgrad_supported(d)) name = "pwgrad";
+    else if (igemm_wgrad_supported(d)) name = "igemm_wgrad";
+    else if (valu_wgrad_supported(d)) name = "vwgrad";
+    else if (tiled_wgrad_supported(d)) name = "twgrad";
+    else if (stride2_wgrad_supported(d)) name = "s2wgrad";
+    else name = "wgrad_mfma";
+  } else {
+    if (d.bs_partial || (d.in_mean && pass != PASS_DGRAD)) name = tiled_conv_supported(d, pass) ? "tconv" : "none";
+    else if (d.pw_dy) name = (!d.in_split && igemm_conv_supported(d, pass)) ? "igemm" : (tiled_conv_supported(d, pass) ? "tconv" : "none");
+    else if (d.in_split) name = pointwise_conv_supported(d, pass, 0) ? "pconv" : (tiled_conv_supported(d, pass) ? "tconv" : "none");
+    else if (pointwise_conv_supported(d, pass, 0)) name = "pconv";
+    else if (igemm_conv_supported(d, pass)) name = "igemm";
+    else if (tiled_conv_supported(d, pass)) name = "tconv";
+    else if (prefer_lds_scatter(d, pass)) name = "s2scatter";
+    else if (tiled_deconv_supported(d, pass)) name = "tdeconv";
+    else if (stride2_conv_supported(d, pass)) name = "s2conv";
+    else name = "gconv_mfma";
+  }
+  snprintf(out, cap, "%s", name);
+  return 0;
+}
+
 extern "C" size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d) {
   if (!d) return 0;
   GatherGeom g[8];

@@ -102,8 +102,18 @@ static bool spatial_tiles(const ursn_conv_desc& d, int& Z, int& Y, int& X, int& 
   if (d.ndim == 3) { Z = d.in_sp[0]; Y = d.in_sp[1]; X = d.in_sp[2]; }
   else { Z = d.in_sp[0]; Y = 1; X = d.in_sp[1]; }
   {   // buffer-path staging (buffer_stage.h): a z plane (2-D: a row) must stay below the out-of-range marker
-    const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
-    if ((int64_t)Y * X * (ics > ocs ? ics : ocs) * 4 >= (int64_t)0x80000000ll) return false;
+    // ... of EVERY tensor the launch addresses that way: the second input / gradient tensor of a split input, the fused
+    // shortcut gradient and the fused BatchNorm-backward operands as well as x / y
+    int cs = d.in_cstride > 0 ? d.in_cstride : d.cin;
+    const int ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
+    if (ocs > cs) cs = ocs;
+    if (d.in_split > 0) { const int c2 = d.in2_cstride > 0 ? d.in2_cstride : d.cin - d.in_split; if (c2 > cs) cs = c2; }
+    if (d.pw_dy) { const int c2 = d.pw_dy_cstride > 0 ? d.pw_dy_cstride : d.cout; if (c2 > cs) cs = c2; }
+    if (d.bs_partial) {
+      if (d.bs_z_cstride > cs) cs = d.bs_z_cstride;
+      if (d.bs_z2 && d.bs_z2_cstride > cs) cs = d.bs_z2_cstride;
+    }
+    if ((int64_t)Y * X * cs * 4 >= (int64_t)0x80000000ll) return false;
   }
   const int TX = d.ndim == 3 ? 32 : 256, TY = d.ndim == 3 ? 8 : 1;
   if (X < TX / 2 || Y < TY || Z < 8) return false;  // only worth it when tiles are reasonably full

@@ -251,10 +251,11 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
 template <int MODE>
 static int launch_twz(const TWPlan& p, const TWgradArgs& a, hipStream_t s) {
   auto kern = a.aff_mean ? twgradz_kernel<MODE, true> : twgradz_kernel<MODE, false>;
-  static size_t attr_lds = 48 * 1024;
-  if (p.lds > attr_lds) {
+  static size_t attr_lds[2] = {48 * 1024, 48 * 1024};   // one opt-in per instantiation (plain / normalise-on-load): both run in every training process
+  size_t& attr = attr_lds[a.aff_mean ? 1 : 0];
+  if (p.lds > attr) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-    attr_lds = p.lds;
+    attr = p.lds;
   }
   hipLaunchKernelGGL(kern, dim3(p.grid), dim3(ZTile<MODE>::NW * 64), p.lds, s, a);
   URSN_HIP(hipGetLastError());
