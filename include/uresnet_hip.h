@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define URSN_ABI_VERSION 6
+#define URSN_ABI_VERSION 7
 
 typedef struct ursn_net ursn_net; /* opaque */
 
@@ -223,6 +223,18 @@ typedef struct ursn_conv_desc {
   int32_t bs_relu;
   int32_t in_relu;       /* normalise-on-load with the producer's ReLU: stages max(bn(z), 0) (dtype 1 only: conv1 -> conv2,
                           * lib/uresnet.py:103-121)                                                                              */
+  /* Data gradient only (ABI 7): BatchNorm-backward APPLY on load (slim.batch_norm backward of THIS layer, lib/resnet_module.py:49,
+   * lib/uresnet.py:109).  The `dy` argument of ursn_conv_backward_data is then g, the gradient at the BatchNorm's OUTPUT, and
+   * the kernel forms, per channel c, while it stages its operand
+   *     dz = A g' + B (z - mu) + C,    g' = g * (fma(z, S, T) > 0)  if vdz_relu  else g
+   * with vdz_coef = [6][cout] floats {A, B, C, mu, S, T} (A = S = rstd, B = -rstd^2 mean(g' xhat), C = -rstd mean(g'),
+   * T = beta - mu rstd: what ursn_net's BatchNorm-backward finalise writes), uses it for dx and STORES it to vdz_out (same
+   * layout / channel stride as dy): the weight gradient reads dz there and the separate apply pass (read g, z; write dz)
+   * disappears.  3-D k3 s1 layers with cin = cout = 8 on the tiled kernels; z, dy and vdz_out share out_cstride.  NULL: off. */
+  const float* vdz_z;
+  const float* vdz_coef;
+  float* vdz_out;
+  int32_t vdz_relu;
 } ursn_conv_desc;
 
 /* y = conv(x, w).  w layout [k..,Cin,Cout] (transposed: [k..,Cout,Cin]). */

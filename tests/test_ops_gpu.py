@@ -878,6 +878,83 @@ def test_data_gradient_with_fused_bn_backward_reductions(S, co, split, relu, two
     assert lib.ursn_conv_backward_data(ctypes.byref(d2), P(dy2), P(w2), P(dxx), 0, stream()) != 0
 
 
+@pytest.mark.parametrize("relu,fused", [(0, 0), (1, 0), (0, 2), (1, 1)])
+@pytest.mark.parametrize("S", [(8, 16, 32), (9, 11, 37), (21, 8, 40)])
+def test_data_gradient_with_bn_backward_apply_on_load(S, relu, fused):
+    """slim.batch_norm backward of an 8 -> 8 layer (lib/resnet_module.py:49, lib/uresnet.py:109) applied WHILE the layer's data
+    gradient stages its operand (ursn_conv_desc.vdz_*, ABI 7): the kernel is handed g (gradient at the BatchNorm's output), z
+    and the per-channel coefficients, forms dz = A g' + B (z - mu) + C, uses it for dx and stores it for the weight gradient.
+    Checked against the oracle's bn_bwd + conv_bwd: dx and the stored dz (every voxel: interior of every tile, each plane
+    once), with and without the ReLU mask bn(z) > 0, accumulating, and together with the fused reductions of the NEXT
+    BatchNorm backward (fused 1: one z, mask bits; 2: two z)."""
+    N = 2
+    rng = np.random.default_rng(S[0] * 5 + relu + 3 * fused)
+    shp = (N,) + S + (8,)
+    w = _rand(rng, (3, 3, 3, 8, 8)) * 0.2
+    z = _rand(rng, shp) * 1.7 + 0.8
+    g = _rand(rng, shp)
+    beta = _rand(rng, (8,)) * 0.4
+    ax = (0, 1, 2, 3)
+    mean, var = z.mean(axis=ax), z.var(axis=ax)
+    rstd = 1.0 / np.sqrt(var + 1e-3)
+    f32 = lambda a: np.asarray(a, dtype=np.float32)   # noqa: E731
+    S32, T32 = f32(rstd), f32(beta) - f32(mean) * f32(rstd)
+    keep = (f32(z) * S32 + T32) > 0 if relu else np.ones(shp, dtype=bool)   # the kernel's (= the forward's) expression
+    gm = g * keep
+    xhat = (z - mean) * rstd
+    c1, c2 = gm.mean(axis=ax), (gm * xhat).mean(axis=ax)
+    dz = rstd * (gm - c1 - xhat * c2)                                       # oracle.bn_bwd
+    dx = O.conv_bwd(np.zeros(shp), w, 1, dz)[0]
+    coef = np.stack([f32(rstd), -(f32(rstd) * f32(rstd)) * f32(c2), -f32(rstd) * f32(c1), f32(mean), S32, T32]).astype(np.float32)
+    wg, zg, gg, cg = dev(w), dev(z), dev(g), torch.from_numpy(coef).cuda()
+    lib = _lib.load()
+    d = desc(3, N, S, 8, 8, 3, 1)
+    d.vdz_z, d.vdz_coef, d.vdz_relu = zg.data_ptr(), cg.data_ptr(), relu
+    # the consumer of dx: the BatchNorm backward of the layer(s) that produced this layer's input
+    z_t, z2_t = _rand(rng, shp) * 1.2 - 0.1, _rand(rng, shp) * 0.6 + 0.2
+    mt, rt = z_t.mean(axis=ax), 1.0 / np.sqrt(z_t.var(axis=ax) + 1e-3)
+    m2, r2 = z2_t.mean(axis=ax), 1.0 / np.sqrt(z2_t.var(axis=ax) + 1e-3)
+    keep_t = rng.random(shp) < 0.55
+    keepers = [zt_g := dev(z_t), z2g := dev(z2_t), mtg := dev(mt), rtg := dev(rt), m2g := dev(m2), r2g := dev(r2),
+               maskg := torch.from_numpy(_join_mask_words(keep_t).view(np.int64)).cuda()]
+    partial = None
+    if fused:
+        d.bs_z, d.bs_mean, d.bs_rstd, d.bs_z_cstride = zt_g.data_ptr(), mtg.data_ptr(), rtg.data_ptr(), 8
+        d.bs_relu, d.bs_mask = 2, maskg.data_ptr()
+        if fused == 2:
+            d.bs_z2, d.bs_mean2, d.bs_rstd2, d.bs_z2_cstride = z2g.data_ptr(), m2g.data_ptr(), r2g.data_ptr(), 8
+        nb = lib.ursn_conv_bs_blocks(ctypes.byref(d))
+        assert nb > 0
+    buf = ctypes.create_string_buffer(32)
+    _lib.check(lib.ursn_conv_plan(ctypes.byref(d), 1, buf, 32))
+    assert buf.value == b"tconv"
+    for acc in (0, 1):
+        dzg = torch.full(shp, float("nan"), dtype=torch.float32, device="cuda")
+        d.vdz_out = dzg.data_ptr()
+        if fused:
+            partial = torch.full((nb, 3, 8), float("nan"), dtype=torch.float64, device="cuda")
+            d.bs_partial = partial.data_ptr()
+        base = _rand(rng, shp) if acc else np.zeros(shp)
+        got = conv_backward_data(d, gg, wg, shp, accumulate=acc, dx_init=dev(base)).cpu().numpy()
+        assert lib.ursn_last_kernel_name().startswith(b"tconv_dgrad<8,8>+dz")
+        assert rel_err(got, dx + base) < TOL
+        assert rel_err(dzg.cpu().numpy(), dz) < 1e-5                      # every voxel written, none twice with another value
+        if fused:
+            gt = (dx + base) * keep_t
+            sums = partial.cpu().numpy().sum(axis=0)
+            ref = np.stack([gt.sum(axis=ax), (gt * (z_t - mt) * rt).sum(axis=ax), (gt * (z2_t - m2) * r2).sum(axis=ax)])
+            scale = np.abs(gt).sum(axis=ax).max()
+            k = 3 if fused == 2 else 2
+            assert np.abs(sums[:k] - ref[:k]).max() < 1e-6 * scale
+    # no such kernel for 2-D layers or other channel counts: the call is refused
+    d2 = desc(3, N, S, 16, 16, 3, 1)
+    d2.vdz_z, d2.vdz_coef, d2.vdz_out = zg.data_ptr(), cg.data_ptr(), zg.data_ptr()
+    dummy = torch.zeros((N,) + S + (16,), dtype=torch.float32, device="cuda")
+    w16 = torch.zeros((3, 3, 3, 16, 16), dtype=torch.float32, device="cuda")
+    assert lib.ursn_conv_backward_data(ctypes.byref(d2), P(dummy), P(w16), P(dummy), 0, stream()) != 0
+    del keepers
+
+
 @pytest.mark.parametrize("S", [(10, 7, 70), (8, 12, 128)])
 def test_logits_layer_weight_gradient_on_the_vector_pipe(S):
     """conv2 (lib/uresnet.py:94-100, 8 -> 3 channels): its weight gradient runs on v_pk_fma_f32 with a lane per voxel

@@ -39,7 +39,8 @@ class ursn_conv_desc(C.Structure):
                 ("bs_z", C.c_void_p), ("bs_mean", C.c_void_p), ("bs_rstd", C.c_void_p), ("bs_beta", C.c_void_p),
                 ("bs_z2", C.c_void_p), ("bs_mean2", C.c_void_p), ("bs_rstd2", C.c_void_p), ("bs_mask", C.c_void_p),
                 ("bs_partial", C.c_void_p), ("bs_z_cstride", C.c_int32), ("bs_z2_cstride", C.c_int32),
-                ("bs_relu", C.c_int32), ("in_relu", C.c_int32)]
+                ("bs_relu", C.c_int32), ("in_relu", C.c_int32),
+                ("vdz_z", C.c_void_p), ("vdz_coef", C.c_void_p), ("vdz_out", C.c_void_p), ("vdz_relu", C.c_int32)]
 
 
 class ursn_bn_bf16_desc(C.Structure):
@@ -108,7 +109,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS.keys())
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

@@ -20,6 +20,11 @@ __device__ __forceinline__ float ursn_buffer_load_f1(__amdgpu_buffer_rsrc_t r, u
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
 
+// an out-of-range store is dropped by the hardware (no exec-masked branch around it)
+__device__ __forceinline__ void ursn_buffer_store_f4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, wgb_f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wgb_u32x4, v), r, byte_off, 0, 0);
+}
+
 // ---- byte-typed forms (bf16 plan) ---------------------------------------------------------------------------------------
 typedef unsigned bst_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned bst_u32x2 __attribute__((ext_vector_type(2)));

@@ -262,6 +262,10 @@ int launch_tiled_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, c
 
 int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out, int accumulate,
                   hipStream_t s) {
+  if (d.vdz_z) {   // BatchNorm-backward apply on load: tiled 3-D 8 -> 8 data gradient only
+    URSN_REQUIRE(pass == PASS_DGRAD && d.vdz_coef && d.vdz_out && tiled_conv_supported(d, pass), "conv: BatchNorm-backward apply on load (vdz_z) not supported for this shape / pass");
+    return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
+  }
   if (d.bs_partial) {   // fused BatchNorm-backward reductions: tiled data-gradient kernels only
     URSN_REQUIRE(pass == PASS_DGRAD && tiled_conv_supported(d, pass), "conv: fused BatchNorm-backward reductions (bs_partial) not supported for this shape / pass");
     return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
@@ -530,7 +534,7 @@ extern "C" int ursn_conv_plan(const ursn_conv_desc* d0, int32_t pass_, char* out
     else if (stride2_wgrad_supported(d)) name = "s2wgrad";
     else name = "wgrad_mfma";
   } else {
-    if (d.bs_partial || (d.in_mean && pass != PASS_DGRAD)) name = tiled_conv_supported(d, pass) ? "tconv" : "none";
+    if (d.vdz_z || d.bs_partial || (d.in_mean && pass != PASS_DGRAD)) name = tiled_conv_supported(d, pass) ? "tconv" : "none";
     else if (d.pw_dy) name = (!d.in_split && igemm_conv_supported(d, pass)) ? "igemm" : (tiled_conv_supported(d, pass) ? "tconv" : "none");
     else if (d.in_split) name = pointwise_conv_supported(d, pass, 0) ? "pconv" : (tiled_conv_supported(d, pass) ? "tconv" : "none");
     else if (pointwise_conv_supported(d, pass, 0)) name = "pconv";

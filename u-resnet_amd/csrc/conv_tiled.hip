@@ -169,6 +169,7 @@ int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass) {
   // contraction side must not be split into channel blocks (found with URSN_IGEMM=0: 32 -> 16 ran as two blocks and
   // dropped half of the term)
   if (d.pw_dy && !(pass == PASS_DGRAD && p.cin <= 16 && b.nbi == 1)) return 0;
+  if (d.vdz_z && !(pass == PASS_DGRAD && p.mode == 3 && p.cin == 8 && p.cout == 8 && d.cout == 8 && d.cin == 8 && b.nbi == 1 && b.nbo == 1 && !b.split)) return 0;
   if (d.in_mean && pass == PASS_FWD && (b.nbi > 1 || b.nbo > 1 || p.cin != p.cout || !(p.cin == 8 || p.cin == 16))) return 0;   // normalise-on-load: 8->8 / 16->16
   // fused BatchNorm-backward reductions: 3-D data gradients producing 8 channels (per tensor of a split input) from 4 | 8
   if (d.bs_partial && !(pass == PASS_DGRAD && p.mode == 3 && p.cout == 8 && (p.cin == 8 || p.cin == 4) && b.nbi == 1 &&
@@ -209,6 +210,12 @@ static int launch_blocks(const ursn_conv_desc& d, const TPlan& p, const Blocking
   a.aff_mean = a.aff_rstd = a.aff_beta = nullptr;
   a.bs_z = a.bs_mean = a.bs_rstd = a.bs_beta = a.bs_z2 = a.bs_mean2 = a.bs_rstd2 = nullptr;
   a.bs_mask = nullptr; a.bs_partial = nullptr; a.bs_z_cs = a.bs_z2_cs = 0; a.bs_relu = 0;
+  a.dz_z = nullptr; a.dz_coef = nullptr; a.dz_out = nullptr; a.dz_relu = 0;
+  if (d.vdz_z) {
+    URSN_REQUIRE(p.flip && d.vdz_coef && d.vdz_out && b.nbi == 1 && b.nbo == 1 && !b.split && p.mode == 3 && p.cin == 8 && p.cout == 8 && d.cout == 8,
+                 "tiled conv: BatchNorm-backward apply on load (vdz_z) needs the 3-D 8 -> 8 data gradient with coefficients and an output tensor");
+    a.dz_z = d.vdz_z; a.dz_coef = d.vdz_coef; a.dz_out = d.vdz_out; a.dz_relu = d.vdz_relu;
+  }
   if (d.bs_partial) {
     URSN_REQUIRE(p.flip && d.bs_z && d.bs_mean && d.bs_rstd && (d.bs_relu != 1 || d.bs_beta) && (d.bs_relu != 2 || d.bs_mask) &&
                  (!d.bs_z2 || (d.bs_mean2 && d.bs_rstd2)), "tiled conv: incomplete fused BatchNorm-backward arguments");
@@ -249,7 +256,9 @@ static int launch_blocks(const ursn_conv_desc& d, const TPlan& p, const Blocking
         URSN_TRY(launch_bn_stats_final(stats_partial, p.grid, cb, p.cout, V, eps, mean + b.bsz * bo, rstd + b.bsz * bo, s));
       }
     }
-  if (d.bs_partial) {   // own lines in the per-kernel breakdown: the epilogue is not free
+  if (d.vdz_z) {
+    ursn_relabel_kernel(d.bs_partial ? (d.bs_z2 ? "tconv_dgrad<8,8>+dz+bnred2" : "tconv_dgrad<8,8>+dz+bnred") : "tconv_dgrad<8,8>+dz");
+  } else if (d.bs_partial) {   // own lines in the per-kernel breakdown: the epilogue is not free
     if (b.split) ursn_relabel_kernel("tconv_dgrad x2(split)+bnred");
     else if (p.cin == 4) ursn_relabel_kernel("tconv_dgrad<4,8>+bnred");
     else ursn_relabel_kernel(d.bs_z2 ? "tconv_dgrad<8,8>+bnred2" : (d.bs_relu == 2 ? "tconv_dgrad<8,8>+bnred(mask)" : "tconv_dgrad<8,8>+bnred"));

@@ -70,6 +70,15 @@ struct TConvArgs {
   const unsigned long long* bs_mask;
   double* bs_partial;      // [grid][3][COUT]
   int bs_z_cs, bs_z2_cs, bs_relu;
+  // data gradient only (DZL instantiations): `in` is NOT dz but g, the gradient at the output of this layer's BatchNorm
+  // (slim.batch_norm backward, lib/resnet_module.py:49 / lib/uresnet.py:109): the kernel forms
+  //     dz = A g' + B (z - mu) + C,   g' = g [* (fma(z, S, T) > 0)]        per channel, while it stages the operand,
+  // and WRITES the interior of every staged plane to dz_out (the weight gradient reads it there) -- the separate
+  // bn_bwd_apply pass (read g, z; write dz) disappears.  dz_coef: [6][8] floats A, B, C, mu, S, T (bn_bwd_final_kernel).
+  const float* dz_z;
+  const float* dz_coef;
+  float* dz_out;
+  int dz_relu;
 };
 
 template <int MODE> struct Tile;
@@ -83,16 +92,20 @@ template <> struct Tile<2> { static constexpr int TX = 256, TY = 1, NTY = 1, NT 
 template <int CQ, int BS> struct TConvAcc { static constexpr int N = CQ == 1 ? 2 : 1; };
 
 // CIN = contraction channels, COUT = produced channels (already swapped for the data gradient).
-template <int CIN, int COUT, int MODE, bool FLIP, bool AFF = false, int BS = 0>
-__global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kernel(TConvArgs a) {
+template <int CIN, int COUT, int MODE, bool FLIP, bool AFF = false, int BS = 0, bool DZL = false>
+__global__ __launch_bounds__(256, (BS == 2 && CIN == 8 && !DZL) ? 3 : 2) void tconv_kernel(TConvArgs a) {
   static_assert(BS == 0 || (FLIP && COUT == 8 && MODE == 3), "fused BatchNorm-backward reductions: 3-D data gradients producing 8 channels");
+  static_assert(!DZL || (FLIP && CIN == 8 && MODE == 3 && !AFF), "dz-on-load: 3-D data gradients contracting 8 channels");
   constexpr bool STATS = !FLIP;  // the data gradient never feeds a BatchNorm
   using TL = Tile<MODE>;
   constexpr int TX = TL::TX, TY = TL::TY, NTY = TL::NTY, NT = TL::NT;
   constexpr int PX = TX + 2, PY = TY + (NTY == 3 ? 2 : 0), PS = PX * PY;
   constexpr int NQ = CIN / 4, CQ = COUT / 4;
   constexpr int KTOT = NT * CIN, R = (KTOT + 15) / 16;
-  constexpr int NSTAGE = (NQ * PS + 255) / 256;
+  // staging slots: slot i covers LDS elements tid + 256 i of the [quad][y][x] plane image; with DZL a slot stays inside ONE
+  // channel quad (NS2 slots per quad), so that its BatchNorm coefficients are compile-time selected scalars
+  constexpr int NS2 = (PS + 255) / 256;
+  constexpr int NSTAGE = DZL ? NQ * NS2 : (NQ * PS + 255) / 256;
   constexpr int NACC = TConvAcc<CQ, BS>::N;
   auto acc_sum = [](const f32x4 (&p)[NACC]) {
     f32x4 v = p[0];
@@ -174,18 +187,27 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
   // registers -- as plain arithmetic on tid the compiler re-derives them every plane), elements outside the image carry
   // URSN_OOB_OFFSET and a plane outside the volume gets num_records = 0: both read as 0 without a branch or a zero fill.
   f32x4 stage[NSTAGE];
+  f32x4 stage2[DZL ? NSTAGE : 1];   // DZL: z beside g
   unsigned stage_inb = 0;   // which staged elements are real voxels (the affine must not touch the zero padding)
   unsigned soff[NSTAGE], sin_mask = 0;
+  unsigned woff[DZL ? NSTAGE : 1];  // DZL: store offset of the formed dz element: interior voxels of the tile only
+  int sidx[DZL ? NSTAGE : 1];       // DZL: LDS element index of the slot (-1: none)
 #pragma unroll
   for (int i = 0; i < NSTAGE; ++i) {
-    const int idx = tid + i * 256;
-    const int q = idx / PS, s = idx - q * PS;
+    int idx = tid + i * 256, q = idx / PS, s = idx - q * PS;
+    bool have = idx < NQ * PS;
+    if constexpr (DZL) { q = i / NS2; s = tid + (i % NS2) * 256; have = s < PS; idx = q * PS + s; sidx[i] = have ? idx : -1; }
     const int yy = s / PX, xx = s - yy * PX;
     const int py = y0 + yy - (NTY == 3 ? 1 : 0), px = x0 + xx - 1;
-    const bool ok = idx < NQ * PS && py >= 0 && py < a.Y && px >= 0 && px < a.X;
+    const bool ok = have && py >= 0 && py < a.Y && px >= 0 && px < a.X;
     soff[i] = ok ? (unsigned)((py * a.X + px) * a.in_cs + 4 * q) * 4u : URSN_OOB_OFFSET;
     if (ok) sin_mask |= 1u << i;
     asm volatile("" : "+v"(soff[i]));
+    if constexpr (DZL) {
+      const bool interior = ok && yy >= (NTY == 3 ? 1 : 0) && yy < (NTY == 3 ? 1 : 0) + TY && xx >= 1 && xx <= TX;
+      woff[i] = interior ? soff[i] : URSN_OOB_OFFSET;
+      asm volatile("" : "+v"(woff[i]));
+    }
   }
   asm volatile("" : "+v"(sin_mask));
   if constexpr (aff) {   // an element outside the image arrives as 0 and must stay 0: its shift is zeroed once, the store has no per-element test
@@ -196,10 +218,20 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
   const ptrdiff_t in_plane = (ptrdiff_t)a.Y * a.X * a.in_cs;
   const unsigned in_plane_bytes = (unsigned)in_plane * 4u;
   const float* in_img = a.in + (size_t)n * a.Z * in_plane;
+  const float* dzz_img = DZL ? a.dz_z + (size_t)n * a.Z * in_plane : nullptr;   // z and dz_out share g's layout (host-checked)
+  float* dzo_img = DZL ? a.dz_out + (size_t)n * a.Z * in_plane : nullptr;
   const bool scalar_in = a.cin_w == 1 && !FLIP;   // single-channel input (conv0): scalar fetch, lanes 1..3 stay 0
+  int stage_z = 0;   // DZL: the plane the staging registers hold
+  float cf[DZL ? 6 : 1][8];   // DZL: A, B, C, mu, S, T per channel -- uniform, read once: scalar registers
+  if constexpr (DZL) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) cf[k][c] = ((const __attribute__((address_space(4))) float*)a.dz_coef)[k * 8 + c];   // constant address space: s_load
+  }
   auto stage_load = [&](int zin) {
     const bool zok = zin >= 0 && zin < a.Z;
-    if constexpr (aff) stage_inb = zok ? 1u : 0u;   // wave-uniform: a plane outside the volume skips the affine
+    if constexpr (aff || DZL) stage_inb = zok ? 1u : 0u;   // wave-uniform: a plane outside the volume skips the affine
     const __amdgpu_buffer_rsrc_t r = ursn_plane_rsrc(in_img + (ptrdiff_t)zin * in_plane, zok ? in_plane_bytes : 0u);
     if (scalar_in) {
 #pragma unroll
@@ -208,8 +240,40 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
 #pragma unroll
       for (int i = 0; i < NSTAGE; ++i) stage[i] = ursn_buffer_load_f4(r, soff[i]);
     }
+    if constexpr (DZL) {
+      stage_z = zin;
+      const __amdgpu_buffer_rsrc_t rz = ursn_plane_rsrc(dzz_img + (ptrdiff_t)zin * in_plane, zok ? in_plane_bytes : 0u);
+#pragma unroll
+      for (int i = 0; i < NSTAGE; ++i) stage2[i] = ursn_buffer_load_f4(rz, soff[i]);
+    }
   };
   auto stage_store = [&](int slot) {
+    if constexpr (DZL) {
+      // planes z0 .. z1 - 1 are this workgroup's own: their interior goes to dz_out (the halo planes belong to the neighbours)
+      const bool own = stage_z >= z0 && stage_z < z1;
+      const __amdgpu_buffer_rsrc_t ro = ursn_plane_rsrc(dzo_img + (ptrdiff_t)stage_z * in_plane, own ? in_plane_bytes : 0u);
+      static_for<NSTAGE>([&](auto I) {
+        constexpr int i = decltype(I)::value, q = i / NS2;
+        // elements outside the image in y / x keep the zeros written once before the march (below); a plane outside the
+        // volume is all zeros
+        if ((sin_mask >> i) & 1u) {
+          const f32x4 g = stage[i], zv = stage2[i];
+          f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (stage_inb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int c = 4 * q + j;
+              float gj = g[j];
+              if (a.dz_relu) { if (!(__builtin_fmaf(zv[j], cf[4][c], cf[5][c]) > 0.f)) gj = 0.f; }   // bn_act's expression
+              v[j] = __builtin_fmaf(cf[0][c], gj, __builtin_fmaf(cf[1][c], zv[j] - cf[3][c], cf[2][c]));
+            }
+          }
+          lds[(size_t)slot * NQ * PS + sidx[i]] = v;
+          ursn_buffer_store_f4(ro, woff[i], v);   // out of range (halo or foreign plane): dropped
+        }
+      });
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NSTAGE; ++i) {
       int idx = tid + i * 256;
@@ -237,6 +301,14 @@ __global__ __launch_bounds__(256, (BS == 2 && CIN == 8) ? 3 : 2) void tconv_kern
 #pragma unroll
   for (int c = 0; c < (BS == 2 ? CQ : 1); ++c) bgx2[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (DZL) {   // staged elements outside the image (fixed per thread): zero in all four ring slots, never written again
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i)
+      if (sidx[i] >= 0 && !((sin_mask >> i) & 1u)) {
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) lds[(size_t)sl * NQ * PS + sidx[i]] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+  }
   // prologue: planes z0-1, z0, z0+1
   for (int p = -1; p <= 1; ++p) {
     stage_load(z0 + p);
@@ -429,9 +501,9 @@ struct TPlan {
   int grid;
 };
 
-template <int CIN, int COUT, int MODE, bool FLIP, bool AFF = false, int BS = 0>
+template <int CIN, int COUT, int MODE, bool FLIP, bool AFF = false, int BS = 0, bool DZL = false>
 static int launch_t(const TPlan& p, const TConvArgs& a, hipStream_t s) {
-  auto kern = tconv_kernel<CIN, COUT, MODE, FLIP, AFF, BS>;
+  auto kern = tconv_kernel<CIN, COUT, MODE, FLIP, AFF, BS, DZL>;
   static size_t attr_lds = 48 * 1024;  // dynamic LDS above the default limit must be opted into per kernel
   if (p.lds > attr_lds) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
@@ -448,6 +520,14 @@ static int launch_t(const TPlan& p, const TConvArgs& a, hipStream_t s) {
     if (!flip && a.aff_mean) {                           \
       if constexpr (ci == co && (ci == 8 || ci == 16)) return launch_t<ci, co, MODE, false, true>(p, a, s); \
       ursn_set_error("tiled conv: no normalise-on-load instantiation for %d->%d", ci, co); \
+      return 3;                                          \
+    }                                                    \
+    if (flip && a.dz_z) {                                \
+      if constexpr (MODE == 3 && co == 8 && ci == 8) {   \
+        if (!a.bs_partial) return launch_t<ci, co, MODE, true, false, 0, true>(p, a, s);                \
+        return a.bs_z2 ? launch_t<ci, co, MODE, true, false, 2, true>(p, a, s) : launch_t<ci, co, MODE, true, false, 1, true>(p, a, s); \
+      }                                                  \
+      ursn_set_error("tiled conv: no dz-on-load instantiation for %d->%d", ci, co);                     \
       return 3;                                          \
     }                                                    \
     if (flip && a.bs_partial) {                          \

@@ -365,7 +365,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a, int shi
 // finals: [3][C] doubles = mean(g), mean(g*xhat), mean(g*xhat2); dbeta(+2) += sum g
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ partial, int nblocks, int C,
                                                            int64_t V, double* __restrict__ finals,
-                                                           float* __restrict__ dbeta, float* __restrict__ dbeta2, int Cw) {
+                                                           float* __restrict__ dbeta, float* __restrict__ dbeta2, int Cw,
+                                                           float* __restrict__ coef, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ beta) {
   const int c = blockIdx.x;
   double s[3];
   reduce_partials<3>(partial, nblocks, C, c, s);
@@ -373,6 +375,16 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restr
   finals[c] = s[0] / (double)V;
   finals[C + c] = s[1] / (double)V;
   finals[2 * C + c] = s[2] / (double)V;
+  if (coef) {   // dz = A g' + B (z - mu) + C for the data-gradient kernel that applies this BatchNorm backward on load
+    const float r = rstd[c], mu = mean[c];
+    const float mg = (float)finals[c], mgx = (float)finals[C + c];   // the apply kernel's fp32 constants
+    coef[c] = r;
+    coef[C + c] = -(r * r) * mgx;
+    coef[2 * C + c] = -r * mg;
+    coef[3 * C + c] = mu;
+    coef[4 * C + c] = r;
+    coef[5 * C + c] = beta ? beta[c] - mu * r : 0.f;   // bn_act's shift (same expression: the mask must be the forward's)
+  }
   if (c >= Cw) return;   // padded channel of the logits layer: no parameter behind it
   if (dbeta) dbeta[c] += (float)s[0];
   if (dbeta2) dbeta2[c] += (float)s[0];
@@ -449,8 +461,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, int shif
 }
 
 int launch_bn_bwd_final(const double* partial, int nblocks, int C, int64_t V, double* finals, float* dbeta, float* dbeta2,
-                        int Cw, hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, partial, nblocks, C, V, finals, dbeta, dbeta2, Cw);
+                        int Cw, hipStream_t s, float* coef_out, const float* mean, const float* rstd, const float* beta) {
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(256), 0, s, partial, nblocks, C, V, finals, dbeta, dbeta2, Cw, coef_out, mean, rstd,
+                     beta);
   URSN_HIP(hipGetLastError());
   return 0;
 }
@@ -474,9 +487,11 @@ int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(m.grid), dim3(256), 0, s, a, m.shift, partial);
     URSN_HIP(hipGetLastError());
   }
+  if (a.coef_out) URSN_REQUIRE(!a.z2 && !a.dres && !a.mask && !(a.relu && a.y), "bn_bwd: apply-on-load coefficients need a single BatchNorm, no residual share and the bn(z) > 0 mask");
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(a.C), dim3(256), 0, s, (const double*)partial, nblocks, a.C, a.V, finals,
-                     a.dbeta, a.z2 ? a.dbeta2 : nullptr, a.Cw > 0 ? a.Cw : a.C);
+                     a.dbeta, a.z2 ? a.dbeta2 : nullptr, a.Cw > 0 ? a.Cw : a.C, a.coef_out, a.mean, a.rstd, a.relu ? a.beta : nullptr);
   URSN_HIP(hipGetLastError());
+  if (a.coef_out) return 0;   // dz is formed (and stored) by the layer's data-gradient kernel
   if (v4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(m.grid), dim3(256), 0, s, a, m.shift, (const double*)finals);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(m.grid), dim3(256), 0, s, a, m.shift, (const double*)finals);
   URSN_HIP(hipGetLastError());

@@ -49,6 +49,7 @@ struct Layer {
   int64_t w_off = 0, b_off = 0, w_n = 0;
   ursn_conv_desc desc;
   float *z = nullptr, *dz = nullptr, *mean = nullptr, *rstd = nullptr;
+  float* coef = nullptr;   // [6][zcs]: BatchNorm-backward apply coefficients for the data-gradient kernel (ursn_conv_desc.vdz_coef)
   int zcs = 0;  // channel stride of z / dz: cout rounded up to 4 (only conv2's 3|5 classes differ), pad lanes stay 0
 };
 
@@ -88,6 +89,9 @@ struct ursn_net {
   // BatchNorm-backward reductions taken in the epilogue of the data-gradient kernel that finished a layer's output gradient
   double* bs_scratch = nullptr;
   int bs_layer = -1, bs_blocks = 0;   // layer whose (first) reductions are waiting in bs_scratch
+  // BatchNorm-backward apply on load: bn_back left this layer's dz to its data-gradient kernel (coefficients in Layer::coef)
+  int vdz_layer = -1, vdz_relu = 0, vdz_cs = 0;
+  const float* vdz_g = nullptr;
   int64_t adam_t = 0;
   int last_n = 0;
   // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
@@ -160,6 +164,7 @@ int add_layer(ursn_net* n, Arena& A, const std::string& name, int kind, int k, i
   L.dz = n->cfg.trainable ? A.floats(e) : nullptr;
   L.mean = A.floats(L.zcs);   // padded like z: pad entries stay 0 (a BN over the padded channel count yields dz = 0 there)
   L.rstd = A.floats(L.zcs);
+  L.coef = n->cfg.trainable ? A.floats(6 * L.zcs) : nullptr;
   n->layers.push_back(L);
   n->named_z[L.name] = (int)n->layers.size() - 1;
   return (int)n->layers.size() - 1;
@@ -624,6 +629,36 @@ int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStre
              int fused_sc = -1, bool dgrad_done_elsewhere = false, int aff = -1, const BsTarget* bs = nullptr) {
   Layer& L = n->layers[li];
   ursn_conv_desc d = bwd_desc(n, li, in, N, in2, -1, aff);
+  const bool vdz = n->vdz_layer == li;   // dz does not exist yet: this layer's data-gradient kernel forms and stores it
+  n->vdz_layer = -1;
+  if (vdz) {
+    URSN_REQUIRE(need_dgrad && !in2 && fused_sc < 0 && !dgrad_done_elsewhere, "BatchNorm-backward apply on load: %s has no plain data gradient", L.name.c_str());
+    bool acc = take_flag(n, in);
+    ursn_conv_desc t = bwd_desc(n, li, in, N, nullptr, -1);
+    t.vdz_z = L.z; t.vdz_coef = L.coef; t.vdz_out = L.dz; t.vdz_relu = n->vdz_relu;
+    n->bs_layer = -1;
+    static const bool bs_off = getenv("URSN_FUSE_BN_BWD_REDUCE") && getenv("URSN_FUSE_BN_BWD_REDUCE")[0] == '0';
+    if (bs && bs->li >= 0 && !bs_off) {
+      const Layer& T = n->layers[bs->li];
+      ursn_conv_desc u = t;
+      u.bs_z = T.z; u.bs_z_cstride = T.zcs; u.bs_mean = T.mean; u.bs_rstd = T.rstd; u.bs_beta = n->params + T.b_off;
+      u.bs_relu = bs->relu; u.bs_mask = bs->mask;
+      if (bs->li2 >= 0) {
+        const Layer& T2 = n->layers[bs->li2];
+        u.bs_z2 = T2.z; u.bs_z2_cstride = T2.zcs; u.bs_mean2 = T2.mean; u.bs_rstd2 = T2.rstd;
+      }
+      u.bs_partial = n->bs_scratch;
+      const bool fits = T.cout == 8 && T.zcs == 8 && (bs->li2 < 0 || n->layers[bs->li2].zcs == 8) && (bs->relu != 2 || bs->mask);
+      const int blocks = fits ? tiled_conv_bs_blocks(u) : 0;
+      if (blocks > 0 && blocks <= 16384 && tiled_conv_supported(u, PASS_DGRAD)) { t = u; n->bs_layer = bs->li; n->bs_blocks = blocks; }
+    }
+    {
+      ProfScope pd(n, s, li, 1, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
+      URSN_TRY(conv_dispatch(t, PASS_DGRAD, n->vdz_g, n->params + L.w_off, in.g, acc ? 1 : 0, s));
+      pd.done(ursn_last_kernel_name());
+    }
+    need_dgrad = false;   // done; the weight gradient below is ordered behind it (it reads the dz just stored)
+  }
   hipStream_t ws = s;
   if (n->s2) {  // dz is final once the kernels queued so far on the main stream are done
     if (n->sync_used == n->sync_pool.size()) {
@@ -675,8 +710,28 @@ int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStre
   return 0;
 }
 
+// May the apply pass of layer li's BatchNorm backward ride in the layer's own data-gradient kernel?  3-D k3 s1 8 -> 8 layers
+// on the tiled kernels whose input is ONE compact 8-channel tensor (conv1, the resnet_conv1 of an 8-channel unit): the kernel
+// forms dz = A g' + B (z - mu) + C while it stages g and z and stores it for the weight gradient (URSN_FUSE_BN_BWD_APPLY=0: off)
+// Measured (round 4, cfg3): the data gradient pays for the extra staging in matrix-pipe issue slots -- conv1's launch 0.97 ->
+// 1.29 ms for 0.47 ms of apply pass removed (net -0.15 ms), but the launch that ALSO carries the two-z reductions of a
+// residual join below drops from 3 to 2 waves per SIMD (190 VGPRs) and goes 1.18 -> 1.84 ms: by default only launches
+// without a second z take the fusion (URSN_FUSE_BN_BWD_APPLY=2: all, 0: none).
+bool vdz_ok(ursn_net* n, int li, const Act& in, int N, bool two_z_target) {
+  static const int mode = getenv("URSN_FUSE_BN_BWD_APPLY") ? atoi(getenv("URSN_FUSE_BN_BWD_APPLY")) : 1;
+  const bool off = mode == 0 || (mode == 1 && two_z_target);
+  const Layer& L = n->layers[li];
+  if (off || n->cfg.ndim != 3 || L.kind || L.k != 3 || L.stride != 1 || L.cin != 8 || L.cout != 8 || L.zcs != 8 || in.C != 8 || in.cs != 8 || !in.g)
+    return false;
+  ursn_conv_desc d = L.desc;
+  d.n = N; d.in_cstride = in.cs; d.out_cstride = L.zcs;
+  d.vdz_z = L.z; d.vdz_coef = L.coef; d.vdz_out = L.dz;
+  return tiled_conv_supported(d, PASS_DGRAD) != 0;
+}
+
 int bn_back(ursn_net* n, int li, const float* dy, int dycs, const float* y, int ycs, int relu, int li2, float* dres,
-            int drescs, int dres_acc, int N, hipStream_t s, const unsigned long long* mask = nullptr) {
+            int drescs, int dres_acc, int N, hipStream_t s, const unsigned long long* mask = nullptr, const Act* fuse_in = nullptr,
+            bool fuse_two_z = false) {
   Layer& L = n->layers[li];
   BnBwdArgs a;
   memset(&a, 0, sizeof(a));
@@ -694,6 +749,11 @@ int bn_back(ursn_net* n, int li, const float* dy, int dycs, const float* y, int 
   if (L.zcs != L.cout && li2 < 0 && !relu && dycs == L.zcs && !dres) { a.C = L.zcs; a.Cw = L.cout; }   // logits layer: float4 path
   if (n->bs_layer == li && a.C == 8) { a.pre_partial = n->bs_scratch; a.pre_nblocks = n->bs_blocks; }
   n->bs_layer = -1;
+  n->vdz_layer = -1;
+  if (fuse_in && li2 < 0 && !dres && !mask && !y && dycs == L.zcs && vdz_ok(n, li, *fuse_in, N, fuse_two_z)) {
+    a.coef_out = L.coef;
+    n->vdz_layer = li; n->vdz_relu = relu; n->vdz_g = dy; n->vdz_cs = dycs;
+  }
   ProfScope ps(n, s, li, 5, 0.0, 4.0 * a.V * a.C * (2.0 * (2 + (relu && !mask) + (li2 >= 0)) + 1 + (li2 >= 0) + (dres != nullptr)));
   URSN_TRY(launch_bn_bwd(a, s));
   ps.done("bn_bwd");
@@ -717,7 +777,8 @@ int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s, const BsTarget* in_targ
   } else {
     URSN_TRY(conv_bwd(n, u.c2, u.a1, true, N, s, nullptr, -1, false, -1, &t1));
   }
-  URSN_TRY(bn_back(n, u.c1, u.a1.g, u.a1.cs, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
+  URSN_TRY(bn_back(n, u.c1, u.a1.g, u.a1.cs, nullptr, 0, 0, -1, nullptr, 0, 0, N, s, nullptr, (u.in2.C || u.sc >= 0) ? nullptr : &u.in,
+                   in_target && in_target->li2 >= 0));
   const Act* in2 = u.in2.C ? &u.in2 : nullptr;
   // stride-1 shortcut next to a tiled conv1: its data gradient rides in conv1's data-gradient kernel
   bool fuse = false;
@@ -747,7 +808,7 @@ int backward(ursn_net* n, const float* data, int N, hipStream_t s) {
   BsTarget tc;   // consumer of the gradient each data-gradient launch below completes (see BsTarget)
   tc.li = n->conv1; tc.relu = 1;
   URSN_TRY(conv_bwd(n, n->conv2, n->a_conv1, true, N, s, nullptr, -1, false, -1, &tc));
-  URSN_TRY(bn_back(n, n->conv1, n->a_conv1.g, n->a_conv1.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
+  URSN_TRY(bn_back(n, n->conv1, n->a_conv1.g, n->a_conv1.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s, nullptr, &n->a_pre1));
   size_t ui = n->units.size();
   auto join_of = [&](const Unit& u) {
     BsTarget t;
@@ -1108,7 +1169,7 @@ extern "C" int ursn_profile_read(ursn_net* net, ursn_prof_rec* out, int64_t max_
   URSN_REQUIRE(net && n_out, "null argument");
   if (net->bf) return bnet_profile_read(net->bf, out, max_recs, n_out);
   int64_t cnt = 0;
-  for (size_t i = 0; i < net->prof.size() && cnt < max_recs; ++i) {
+  for (size_t i = 0; i < net->prof.size() && (!out || cnt < max_recs); ++i) {   // out == NULL: only counts, all of them
     const ursn_net::ProfRec& r = net->prof[i];
     float ms = 0.f;
     if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;

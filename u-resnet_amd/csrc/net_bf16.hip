@@ -782,7 +782,7 @@ int bnet_profile_enable(ursn_bnet* n, int on) {
 }
 int bnet_profile_read(ursn_bnet* n, ursn_prof_rec* out, int64_t max_recs, int64_t* n_out) {
   int64_t cnt = 0;
-  for (size_t i = 0; i < n->prof.size() && cnt < max_recs; ++i) {
+  for (size_t i = 0; i < n->prof.size() && (!out || cnt < max_recs); ++i) {   // out == NULL: only counts, all of them
     const BProfRec& r = n->prof[i];
     float ms = 0.f;
     if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;

@@ -237,6 +237,10 @@ struct BnBwdArgs {
   // doubles; the reduce pass is skipped
   const double* pre_partial; int pre_nblocks;
   int Cw;  // channels that own a dbeta entry (0 = C); C may be the 4-padded count of the logits layer (pad: mean = rstd = 0)
+  // != nullptr (single z, no dres; relu none or bn(z) > 0): the apply pass is SKIPPED; the finalise writes [6][C] floats
+  // {A, B, C, mu, S, T} with dz = A g' + B (z - mu) + C, g' = g (* (fma(z, S, T) > 0)), and the layer's data-gradient kernel
+  // forms and stores dz while it stages its operand (ursn_conv_desc.vdz_*)
+  float* coef_out;
 };
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
 
@@ -257,7 +261,8 @@ int head_blocks(int n, int64_t pix);
 int launch_head_final(const double* partial, int nblocks, int n, int64_t pix, float* metrics, hipStream_t s);
 // finals [3][C] = mean(g), mean(g xhat), mean(g xhat2) from [nblocks][3][C] partials; dbeta(2)[c < Cw] += sum g
 int launch_bn_bwd_final(const double* partial, int nblocks, int C, int64_t V, double* finals, float* dbeta, float* dbeta2,
-                        int Cw, hipStream_t s);
+                        int Cw, hipStream_t s, float* coef_out = nullptr, const float* mean = nullptr, const float* rstd = nullptr,
+                        const float* beta = nullptr);
 int launch_head(const HeadArgs& a, hipStream_t s);
 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
