@@ -223,6 +223,9 @@ def main():
                          "(lets several ranks share ONE GPU: the N > 1 code path rehearsed on a one-GPU box)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary workload (cfg5 bf16) that the default cfg3 run appends to its JSON line")
+    ap.add_argument("--secondary-workload", default="", choices=[""] + sorted(WORKLOADS),
+                    help="workload of the secondary leg (default: cfg5_3d256_f8_b4_bf16 behind the default cfg3 run; naming one "
+                         "attaches it to any primary workload -- the N > 1 rehearsal uses the tiny pair)")
     ap.add_argument("--cpu-baseline-child", default="")
     ap.add_argument("--cpu-size", type=int, default=192)
     ap.add_argument("--cpu-reps", type=int, default=5)
@@ -308,10 +311,17 @@ def main():
     torch.cuda.synchronize()
     serial_ms_per_step = (time.perf_counter() - tp0) / prof_steps * 1e3
     _lib.check(lib.ursn_set_wgrad_overlap(net._handle, 1))
+    per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own clock over the SAME barrier-bracketed region and the device it bound: a straggler GPU or two ranks
+        # on one device show up in the line (the headline uses the maximum, as the contract asks)
+        mine = torch.tensor([elapsed, float(dev_index)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        el = [float(a[0].item()) for a in allr]
+        per_rank = {"ms_per_step_min": round(min(el) / args.steps * 1e3, 3), "ms_per_step_max": round(max(el) / args.steps * 1e3, 3),
+                    "ms_per_step": [round(e / args.steps * 1e3, 3) for e in el], "device_index": [int(a[1].item()) for a in allr]}
+        elapsed = max(el)
     metrics = net.read_metrics()
 
     # the non-conv parts of the step, each timed alone (Adam and the all-reduce reported separately)
@@ -493,24 +503,42 @@ def main():
         cpu = run_cpu_baseline(int(dims[0]))
 
     secondary = None
-    if rank == 0 and world == 1 and args.workload == "cfg3_3d192_f8_b4" and not args.no_secondary:
-        # BASELINE.json configs[4] (3-D 256^3 bf16) timed by the same invocation: a CHILD process started after this one has
-        # released its workspace (never an exec from a process that holds the GPU); the headline above is untouched
+    sec_wl = args.secondary_workload or ("cfg5_3d256_f8_b4_bf16" if args.workload == "cfg3_3d192_f8_b4" else "")
+    want_secondary = bool(sec_wl) and not args.no_secondary
+    if want_secondary:
+        # every rank releases its workspace; with several ranks the process group ends here, so that the child job below finds
+        # N idle GPUs and no live communicator of this job
         del net
         torch.cuda.empty_cache()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    if rank == 0 and want_secondary:
+        # BASELINE.json configs[4] (3-D 256^3 bf16, "8 x MI355X") timed by the same invocation at the same N: a CHILD job started
+        # after this one has released its workspace (never an exec from a process that holds the GPU).  With N > 1 the child is
+        # `bench.py --gpus N`, which launches its own N ranks (torch.distributed.run) before any of them touches a GPU; the
+        # launcher variables of THIS rank must not leak into it.  The headline above is untouched.
         try:
-            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "cfg5_3d256_f8_b4_bf16", "--steps", str(args.steps),
-                                 "--warmup", str(args.warmup), "--no-cpu-baseline"], stdout=subprocess.PIPE, text=True, timeout=900)
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", sec_wl, "--steps", str(args.steps),
+                   "--warmup", str(args.warmup), "--no-cpu-baseline", "--gpus", str(world), "--backend", args.backend]
+            cenv = {k: v for k, v in os.environ.items()
+                    if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                                 "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+                                 "GROUP_WORLD_SIZE", "ROLE_NAME", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING",
+                                 "TORCHELASTIC_ERROR_FILE")}
+            cp = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, timeout=900, env=cenv)
             line = [x for x in cp.stdout.strip().split("\n") if x.startswith("{")]
             if cp.returncode == 0 and line:
                 c5 = json.loads(line[-1])
                 secondary = {"workload": c5["config"]["workload"], "dtype": c5["dtype"], "metric": c5["metric"], "value": c5["value"],
-                             "unit": c5["unit"], "steps": c5["steps"], "warmup": c5["warmup"], "ms_per_step": c5["ms_per_step"],
-                             "config": c5["config"], "last_metrics": c5["last_metrics"], "roofline": c5["roofline"]}
+                             "unit": c5["unit"], "n_gpus": c5["n_gpus"], "steps": c5["steps"], "warmup": c5["warmup"],
+                             "ms_per_step": c5["ms_per_step"], "config": c5["config"], "last_metrics": c5["last_metrics"],
+                             "ranks_seen": c5.get("ranks_seen"), "per_rank": c5.get("per_rank"), "step_parts": c5.get("step_parts"),
+                             "roofline": c5["roofline"]}
             else:
-                secondary = {"workload": "cfg5_3d256_f8_b4_bf16", "error": "child exited with %d" % cp.returncode}
+                secondary = {"workload": sec_wl, "error": "child exited with %d" % cp.returncode}
         except Exception as e:   # the headline must survive a failing secondary leg
-            secondary = {"workload": "cfg5_3d256_f8_b4_bf16", "error": repr(e)}
+            secondary = {"workload": sec_wl, "error": repr(e)}
 
     if rank == 0:
         out = {
@@ -523,13 +551,13 @@ def main():
                        "batch_per_gpu": batch, "global_batch": batch * world,
                        "step": "zero_gradients+accum_gradients(fwd+loss+bwd)+allreduce+adam",
                        "parallelism": "dp%d" % world, "backend": (args.backend if world > 1 else None)},
-            "ranks_seen": ranks_seen,
+            "ranks_seen": ranks_seen, "per_rank": per_rank,
             "last_metrics": {"loss": metrics[0], "acc_all": metrics[1], "acc_nonzero": metrics[2]},
             "step_parts": parts, "host_feed": host_feed,
             "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 and dist.is_initialized():
         dist.destroy_process_group()
 
 

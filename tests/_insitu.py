@@ -74,6 +74,72 @@ def bf16_ulp(b):
     return np.exp2(np.floor(np.log2(a)) - 7.0)
 
 
+# ---- the oracle's stride-1 3^d convolution primitives, evaluated fast ------------------------------------------------------
+# oracle.uresnet_np.conv_fwd / conv_bwd walk the taps over STRIDED views of the padded tensor (a copy or a strided add per tap)
+# and conv_bwd always forms both gradients: 4 s per 34 x 192 x 192 x 8 slab, 300 s of the GPU suite at full size.  The same sums
+# on the zero-padded tensor FLATTENED to [voxels, channels] -- a tap is then a row offset and every operand of the per-tap
+# matrix product is a contiguous slice -- and one gradient at a time: 1.3-1.5 s per slab.  tests/test_oracle.py holds these three
+# to the oracle's functions (they are its restatement, term for term; only the memory walk differs).
+import itertools as _it
+
+
+def _flat_offsets(psh):
+    strides = [int(np.prod(psh[i + 1:])) for i in range(len(psh))]
+    return [(tap, sum(t * st for t, st in zip(tap, strides))) for tap in _it.product(range(3), repeat=len(psh))]
+
+
+_BLK = 4096   # rows of the flattened tensor per block: the block of every operand stays in cache across the 27 taps (a tap is
+              # a row offset, neighbouring taps re-read almost the same rows): 6-7x over one pass per tap
+
+
+def fast_conv_fwd(x, w):
+    """x [N,*S,Cin], w [3..,Cin,Cout] -> oracle conv_fwd(x, w, 1)."""
+    out = []
+    for xi in x:
+        S = xi.shape[:-1]
+        xp = np.pad(xi, [(1, 1)] * len(S) + [(0, 0)])
+        psh = xp.shape[:-1]
+        xf = xp.reshape(-1, xi.shape[-1])
+        offs = _flat_offsets(psh)
+        L = xf.shape[0] - offs[-1][1]
+        yf = np.zeros((xf.shape[0], w.shape[-1]), dtype=x.dtype)
+        for r0 in range(0, L, _BLK):
+            r1 = min(r0 + _BLK, L)
+            acc = yf[r0:r1]
+            for tap, o in offs:
+                acc += xf[o + r0:o + r1] @ w[tap]
+        out.append(yf.reshape(psh + (w.shape[-1],))[tuple(slice(0, s_) for s_ in S)])
+    return np.stack(out)
+
+
+def fast_conv_dx(dy, w):
+    """dy [N,*S,Cout] -> oracle conv_bwd(., w, 1, dy)[0]: the forward form with the taps flipped and the matrices transposed."""
+    nd = dy.ndim - 2
+    return fast_conv_fwd(dy, np.ascontiguousarray(np.flip(w, axis=tuple(range(nd))).swapaxes(-1, -2)))
+
+
+def fast_conv_dw(x, dy):
+    """x [N,*S,Cin], dy [N,*S,Cout] -> oracle conv_bwd(x, ., 1, dy)[1]."""
+    nd = x.ndim - 2
+    dw = np.zeros((3,) * nd + (x.shape[-1], dy.shape[-1]), dtype=x.dtype)
+    for xi, di in zip(x, dy):
+        S = xi.shape[:-1]
+        xp = np.pad(xi, [(1, 1)] * nd + [(0, 0)])
+        psh = xp.shape[:-1]
+        xf = xp.reshape(-1, xi.shape[-1])
+        dyp = np.zeros(psh + (di.shape[-1],), dtype=x.dtype)
+        dyp[tuple(slice(0, s_) for s_ in S)] = di
+        offs = _flat_offsets(psh)
+        L = xf.shape[0] - offs[-1][1]
+        D = dyp.reshape(-1, di.shape[-1])
+        for r0 in range(0, L, _BLK):
+            r1 = min(r0 + _BLK, L)
+            Db = D[r0:r1]
+            for tap, o in offs:
+                dw[tap] += xf[o + r0:o + r1].T @ Db
+    return dw
+
+
 class Tol(object):
     """fp32: |a-b| <= rel * max|b|.  bf16-stored tensors: |a-b| <= ulps * ulp(b) + 2e-5 * max|b| element-wise."""
 
@@ -161,6 +227,12 @@ class InSitu(object):
 
     # ---- the walk ---------------------------------------------------------------------------------------------------
     def run(self, tag=""):
+        """Every check of _run with the oracle's stride-1 convolutions evaluated slab-parallel (tests/_net.py::parallel_oracle)."""
+        from _net import parallel_oracle
+        with parallel_oracle(min_rows=48):   # measured: 64^3 passes 14.5 -> 12.3 s, 128^3 62 -> 32 s
+            return self._run(tag)
+
+    def _run(self, tag=""):
         self._producer = {}
         for op in self.ops:
             if op[0] == "layer":
@@ -284,6 +356,20 @@ class InSitu(object):
 
 
 # ---- full-size legs: the same local checks on x-slabs of the stored tensors (the fp64 oracle cannot hold 192^3 x 4 at once) ----
+def _timed(fn):
+    import functools
+    import time
+
+    @functools.wraps(fn)
+    def w(self, *a, **k):
+        t0 = time.perf_counter()
+        try:
+            return fn(self, *a, **k)
+        finally:
+            self.times[fn.__name__] = self.times.get(fn.__name__, 0.0) + time.perf_counter() - t0
+    return w
+
+
 class FullSize(object):
     """Level-0 / level-1 layers of a full-size step.  Convolution checks run on slabs along the first spatial axis with a
     one-row halo (exact: SAME padding only adds zeros where the true tensor has none inside the slab's dependency range),
@@ -293,9 +379,11 @@ class FullSize(object):
         self.net, self.P, self.bf16, self.rows, self.workers, self.eps = net, P, bf16, rows, workers, eps
         self.q = O.bf16_round if bf16 else (lambda a: a)
         self.tol = Tol(bf16)
+        self.times = {}
         self.grads = net.get_gradients()
         self._c = {}
 
+    @_timed
     def t(self, name):
         if name not in self._c:
             self._c[name] = self.net.debug_tensor(name)   # float32 [N, *S, C]
@@ -315,8 +403,12 @@ class FullSize(object):
         return self.q(np.asarray(self.P[lname + "/weights"], np.float64))
 
     def _pool(self, fn, tasks):
+        # slabs in parallel threads, each BLAS call single-threaded: concurrent multi-threaded BLAS calls from several Python
+        # threads returned wrong products on the GPU box (a different slab each run) once the per-tap products became plain
+        # contiguous GEMMs (fast_conv_*), and they oversubscribe the cores anyway
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=self.workers) as ex:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1), ThreadPoolExecutor(max_workers=self.workers) as ex:
             return list(ex.map(fn, tasks))
 
     def slabs(self, S, all_rows):
@@ -337,6 +429,7 @@ class FullSize(object):
             return np.maximum(y, 0.0) if relu else y
         return staged_bn(self.t(lname + ":z")[n, a:b], self.t(lname + ":mean"), self.t(lname + ":rstd"), self.beta(lname), relu)
 
+    @_timed
     def check_stats(self, lname):
         z = self.t(lname + ":z")
         N = z.shape[0]
@@ -350,6 +443,7 @@ class FullSize(object):
         assert np.abs(mu - mu_ref).max() <= 1e-5 * (np.abs(mu_ref).max() + np.sqrt(var_ref.max())), ("mean", lname, mu, mu_ref)
         self.tol.check("rstd", lname, r, 1.0 / np.sqrt(var_ref + self.eps), 1e-5, stored_bf16=False)
 
+    @_timed
     def check_forward(self, lname, kind, x_fn):
         """z == conv(x, w) on three slabs per image.  x_fn(n, lo, hi) -> fp64 input rows [lo, hi) of image n."""
         w = self.w(lname)
@@ -364,10 +458,11 @@ class FullSize(object):
                 y = O.deconv_fwd(x_fn(n, lo, b)[None], w)[0][2 * (a - lo):2 * (a - lo) + 2 * (b - a)]
                 return self.tol.check("z", "%s[%d,%d:%d]" % (lname, n, 2 * a, 2 * b), z[n, 2 * a:2 * b], self.q(y), 2e-5)
             lo, hi = max(a - 1, 0), min(b + 1, S)
-            y = O.conv_fwd(x_fn(n, lo, hi)[None], w, 1)[0][a - lo:a - lo + (b - a)]
+            y = fast_conv_fwd(x_fn(n, lo, hi)[None], w)[0][a - lo:a - lo + (b - a)]
             return self.tol.check("z", "%s[%d,%d:%d]" % (lname, n, a, b), z[n, a:b], self.q(y), 2e-5)
         self._pool(one, [(n, ab) for n in range(N) for ab in self.slabs(Sin, False)])
 
+    @_timed
     def check_bn_backward(self, lname, g_fn):
         """dz == bn_bwd(z, g) (oracle.uresnet_np.bn_bwd with the reductions taken over every slab), dbeta == sum g.
         g_fn(n, a, b) -> fp64 gradient at the BatchNorm output, activation mask applied."""
@@ -394,6 +489,7 @@ class FullSize(object):
             return self.tol.check("dz", "%s[%d,%d:%d]" % (lname, n, a, b), dz[n, a:b], self.q(ref), 1e-5)
         self._pool(one, [(n, ab) for n in range(N) for ab in self.slabs(S, False)])
 
+    @_timed
     def check_weight_gradient(self, lname, kind, x_fn):
         """dw == sum over all slabs of conv_bwd(x_slab, w, dz_slab)[1]."""
         w = self.w(lname)
@@ -413,10 +509,11 @@ class FullSize(object):
             x = x_fn(n, lo, hi)
             dy = np.zeros(x.shape[:-1] + (dz.shape[-1],))
             dy[a - lo:a - lo + (b - a)] = dz[n, a:b]
-            return O.conv_bwd(x[None], w, 1, dy[None])[1]
+            return fast_conv_dw(x[None], dy[None])
         dw = sum(self._pool(one, [(n, ab) for n in range(N) for ab in self.slabs(Sin, True)]))
         self.tol.check("dw", lname, self.grads[lname + "/weights"], dw, 2e-5, stored_bf16=False)
 
+    @_timed
     def check_data_gradient(self, label, stored, terms, extra_fn=None, n_terms=1):
         """stored[n, a:b] == sum of conv_bwd(., w, dz)[0] over `terms` = [(layer, kind, channel slice)] (+ extra_fn(n, a, b))
         on three slabs per image.  Stride-1 layers and the transposed conv only."""
@@ -434,8 +531,11 @@ class FullSize(object):
                     dx = O.deconv_bwd(dummy, w, dz[n, 2 * a:2 * hi].astype(np.float64)[None])[0][0][:b - a]
                 else:
                     lo, hi = max(a - 1, 0), min(b + 1, S)
-                    dummy = np.zeros((1, hi - lo) + stored.shape[2:-1] + (w.shape[-2],))
-                    dx = O.conv_bwd(dummy, w, 1, dz[n, lo:hi].astype(np.float64)[None])[0][0][a - lo:a - lo + (b - a)]
+                    if w.shape[0] == 3:
+                        dx = fast_conv_dx(dz[n, lo:hi].astype(np.float64)[None], w)[0][a - lo:a - lo + (b - a)]
+                    else:   # the unit's 1x1 shortcut
+                        dummy = np.zeros((1, hi - lo) + stored.shape[2:-1] + (w.shape[-2],))
+                        dx = O.conv_bwd(dummy, w, 1, dz[n, lo:hi].astype(np.float64)[None])[0][0][a - lo:a - lo + (b - a)]
                 dx = dx[..., csl]
                 tot, mag = tot + dx, mag + np.abs(dx)
             if extra_fn is not None:

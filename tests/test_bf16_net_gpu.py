@@ -22,7 +22,7 @@ import pytest
 import torch
 
 from oracle import uresnet_np as O
-from _net import as_f32_exact, l2_rel, make_inputs, max_rel, oracle_params
+from _net import as_f32_exact, l2_rel, make_inputs, max_rel, oracle_params, parallel_oracle
 from uresnet_amd import uresnet
 
 pytestmark = pytest.mark.gpu
@@ -31,7 +31,8 @@ pytestmark = pytest.mark.gpu
 def _oracle(P, dims, base, data, label, weight, ns, quant):
     O.QUANT = O.bf16_round if quant else None
     try:
-        return O.step_gradients(P, dims, base, data, label, weight, keep_acts=True, num_strides=ns)
+        with parallel_oracle():
+            return O.step_gradients(P, dims, base, data, label, weight, keep_acts=True, num_strides=ns)
     finally:
         O.QUANT = None
 
@@ -45,6 +46,11 @@ CASES = [
     ("2d_f16_ns5", (64, 64, 1), 16, 3, 2, 5),                     # 512 channels at the bottom: 64 pieces per voxel in the BatchNorm reductions                       # 8-channel level 0 in 2-D: own skip tensor + packed concat pass, generic convs
     ("cfg5_model_3d64_f8_ns5", (64, 64, 64, 1), 8, 3, 2, 5),      # BASELINE configs[4]'s model at reduced size
 ]
+
+
+# fraction of ALL voxels whose bf16-plan label equals the unrounded fp64 oracle's, measured in round 4 minus 0.005
+AGREE_FLOOR = {"3d_f8_ns2": 0.9875, "3d_f8_ns3_c5": 0.9827, "2d_f16_ns3": 0.9854, "2d_f8_ns2": 0.9845, "2d_f16_ns5": 0.9817, "cfg5_model_3d64_f8_ns5": 0.9847}
+# (measured 0.9925 / 0.9877 / 0.9904 / 0.9895 / 0.9867 / 0.9897; the emulating oracle itself: 0.9924 / 0.9873 / 0.9899 / 0.9905 / 0.9894 / 0.9896)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
@@ -67,6 +73,10 @@ def test_bf16_accum_gradients_against_emulating_oracle(case):
     srt = np.sort(m_q["logits"], axis=-1)
     safe = (srt[..., -1] - srt[..., -2]) > 0.1
     agree = float((sm.argmax(-1) == m_q["pred"]).mean())
+    # what bf16 costs a user in per-voxel class labels: the fraction of ALL voxels whose label equals the UNROUNDED fp64
+    # oracle's (north_star asks for bit-exact labels of the fp32 semantics; mixed precision cannot give that by construction)
+    agree_x = float((sm.argmax(-1) == m_x["pred"]).mean())
+    agree_emu_x = float((m_q["pred"] == m_x["pred"]).mean())   # the same figure for the emulation itself, oracle vs oracle
     g = net.get_gradients()
     wk = [k for k in g_q if k.endswith("/weights") and np.abs(g_q[k]).max() > 1e-12]
     e_gq = {k: l2_rel(g[k], g_q[k]) for k in wk}
@@ -76,6 +86,8 @@ def test_bf16_accum_gradients_against_emulating_oracle(case):
           "(safe %.3f) | filter grads rel-L2 vs emu: median %.1e max %.1e; vs fp64: median %.1e max %.1e (emu vs fp64 median %.1e)"
           % (tag, e_z0, res[1], m_q["loss"], m_x["loss"], e_sm_q, e_sm_x, agree, safe.mean(), np.median(list(e_gq.values())),
              max(e_gq.values()), np.median(list(e_gx.values())), max(e_gx.values()), np.median(list(e_qx.values()))))
+    print("%s: labels equal to the fp64 oracle's over all voxels: %.4f (emulating oracle vs fp64 oracle: %.4f)" % (tag, agree_x, agree_emu_x))
+    assert agree_x >= AGREE_FLOOR[tag], (agree_x, AGREE_FLOOR[tag])   # measured (round 4) - 0.005
     assert e_z0 <= 2.0 ** -8                      # first layer: one bf16 rounding
     assert abs(res[1] - m_q["loss"]) <= 1e-2 * abs(m_q["loss"])
     assert abs(res[1] - m_x["loss"]) <= 3e-2 * abs(m_x["loss"])

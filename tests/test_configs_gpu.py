@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 
 from oracle import uresnet_np as O
-from _net import as_f32_exact, fp32_noise_floor, l2_rel, make_inputs, max_rel, oracle_params
+from _net import as_f32_exact, fp32_noise_floor, l2_rel, make_inputs, max_rel, oracle_params, parallel_oracle
 from uresnet_amd import uresnet
 
 pytestmark = pytest.mark.gpu
@@ -70,7 +70,8 @@ def test_baseline_config_model_against_oracle(case):
     P = as_f32_exact(oracle_params(dims, base, ncls))
     data, label, weight = make_inputs(dims, ncls, N, seed=17)
     w = weight if use_w else None
-    g_ref, m = O.step_gradients(P, dims, base, data, label, w, keep_acts=True)
+    with parallel_oracle():   # the oracle's own conv functions, slab-parallel (tests/_net.py)
+        g_ref, m = O.step_gradients(P, dims, base, data, label, w, keep_acts=True)
     net = uresnet(dims=list(dims), num_class=ncls, base_num_outputs=base)   # num_strides = 5 as in the reference
     net.construct(trainable=True, use_weight=use_w, learning_rate=1e-3)
     assert net._n_params == {(2, 16, 3): 16858979, (2, 16, 5): 16859269, (3, 8, 3): 12468083}[(len(dims) - 1, base, ncls)]

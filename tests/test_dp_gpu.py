@@ -76,7 +76,8 @@ def test_bench_n2_path_two_ranks_on_one_gpu_over_gloo():
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--workload", "tiny_3d64_f8_b2", "--backend", "gloo"], env=env, cwd=ROOT,
+                        "--no-cpu-baseline", "--workload", "tiny_3d64_f8_b2", "--secondary-workload", "tiny_3d64_f8_b2_bf16",
+                        "--backend", "gloo"], env=env, cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [x for x in p.stdout.split("\n") if x.startswith("{")]
@@ -86,4 +87,14 @@ def test_bench_n2_path_two_ranks_on_one_gpu_over_gloo():
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2" and out["config"]["backend"] == "gloo"
     assert out["scaling"] == "weak" and out["value"] > 0 and abs(out["value"] - 4 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-2 * out["value"]
     assert out["step_parts"]["allreduce_ms"] > 0
-    assert out["roofline"] is not None and out["secondary"] is None and out["cpu_baseline"] is None
+    assert out["roofline"] is not None and out["cpu_baseline"] is None
+    # the line is self-checking for the day 8 GPUs are there: every rank's own clock over the timed region and the device it bound
+    pr = out["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and pr["device_index"] == [0, 0]          # gloo rehearsal: both ranks share device 0
+    assert pr["ms_per_step_min"] <= pr["ms_per_step_max"] and abs(pr["ms_per_step_max"] - out["ms_per_step"]) < 1e-2 * out["ms_per_step"]
+    # the secondary (bf16) leg rides the same N: a child job of two ranks started after this one released its GPUs
+    sec = out["secondary"]
+    assert "error" not in sec, sec
+    assert sec["workload"] == "tiny_3d64_f8_b2_bf16" and sec["dtype"] == "bf16" and sec["n_gpus"] == 2 and sec["ranks_seen"] == 2
+    assert sec["config"]["global_batch"] == 4 and sec["value"] > 0 and sec["step_parts"]["allreduce_ms"] > 0
+    assert len(sec["per_rank"]["ms_per_step"]) == 2

@@ -170,6 +170,7 @@ def _full_size_checks(net, P, bf16, ns=5):
     fs.check_weight_gradient(dec, "deconv", x_e)
     fs.check_data_gradient(m8 + "/module2:grad", gout8, [(dec, "deconv", slice(None))])
     fs.tol.report("full size")
+    print("full-size check seconds:", {k: round(v, 1) for k, v in sorted(fs.times.items(), key=lambda kv: -kv[1])})
     assert set(fs.tol.worst) >= {"z", "rstd", "dz", "dw", "dx"}
 
 

@@ -217,3 +217,47 @@ def test_oracle_topology_against_reference_graph():
     assert G["moments"] == {"has_squared_difference": True, "has_stop_gradient_on_mean": True, "mean_reduction_axes": [0, 1, 2]}
     assert G["moving_average_decay_constants"] == [0.001]                                    # 1 - 0.999 (B-3)
     assert [p["shape"] for p in G["placeholders"]] == [[-1, 262144]] * 3                      # flat [N, 512*512] feeds
+
+
+def test_fast_stride1_conv_helpers_are_the_oracle_primitives():
+    """tests/_insitu.py evaluates the oracle's stride-1 3^d convolution and its two gradients on flattened padded tensors (the
+    full-size in-situ checks spend their time there); the three helpers must BE oracle.conv_fwd / conv_bwd: same terms,
+    fp64 rounding only (2-D and 3-D, ragged sizes, one-voxel axes)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _insitu import fast_conv_dw, fast_conv_dx, fast_conv_fwd
+    rng = np.random.default_rng(5)
+    for S, ci, co in (((5, 6, 7), 3, 4), ((6, 9), 5, 2), ((1, 4, 3), 2, 2), ((8, 8, 8), 8, 8)):
+        x = rng.standard_normal((2,) + S + (ci,))
+        w = rng.standard_normal((3,) * len(S) + (ci, co))
+        dy = rng.standard_normal((2,) + S + (co,))
+        dx, dw = O.conv_bwd(x, w, 1, dy)
+        y = O.conv_fwd(x, w, 1)
+        assert np.abs(fast_conv_fwd(x, w) - y).max() <= 1e-12 * np.abs(y).max()
+        assert np.abs(fast_conv_dx(dy, w) - dx).max() <= 1e-12 * np.abs(dx).max()
+        assert np.abs(fast_conv_dw(x, dy) - dw).max() <= 1e-12 * np.abs(dw).max()
+
+
+def test_slab_parallel_oracle_is_the_oracle():
+    """tests/_net.py::parallel_oracle runs oracle.conv_fwd / conv_bwd per slab of the first spatial axis in threads (the 128^3
+    oracle steps of the GPU suite): same values as the plain functions, 3-D and 2-D, slab counts that do and do not divide."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _net import parallel_oracle
+    rng = np.random.default_rng(6)
+    for S, ci, co in (((21, 40, 40), 4, 3), ((64, 96), 8, 5)):
+        x = rng.standard_normal((2,) + S + (ci,))
+        w = rng.standard_normal((3,) * len(S) + (ci, co))
+        dy = rng.standard_normal((2,) + S + (co,))
+        y0 = O.conv_fwd(x, w, 1)
+        dx0, dw0 = O.conv_bwd(x, w, 1, dy)
+        for rows in (None, 5, 16):
+            with parallel_oracle(workers=4, min_rows=8, rows=rows):
+                y1 = O.conv_fwd(x, w, 1)
+                dx1, dw1 = O.conv_bwd(x, w, 1, dy)
+                assert O.conv_fwd(x[:, :4], w, 1).shape[1] == 4          # small tensors take the plain path
+            assert np.array_equal(y1, y0) and np.array_equal(dx1, dx0)
+            assert np.abs(dw1 - dw0).max() <= 1e-12 * np.abs(dw0).max()
+    assert O.conv_fwd.__module__ == "oracle.uresnet_np"                  # restored

@@ -15,6 +15,7 @@ def _runtime():
 
 
 def memcpy_d2h(host_buf, dev_ptr, nbytes):
-    rc = _runtime().hipMemcpy(ctypes.cast(host_buf, ctypes.c_void_p), ctypes.c_void_p(dev_ptr), nbytes, 2)
+    host = host_buf if isinstance(host_buf, ctypes.c_void_p) else ctypes.cast(host_buf, ctypes.c_void_p)
+    rc = _runtime().hipMemcpy(host, ctypes.c_void_p(dev_ptr), nbytes, 2)
     if rc != 0:
         raise RuntimeError("hipMemcpy D2H failed: %d" % rc)
