@@ -260,6 +260,20 @@ int tiled_conv_supported(const ursn_conv_desc& d, ConvPass pass);
 int launch_tiled_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
                       int accumulate, hipStream_t s);
 
+// scratch of the op-level entry points for kernels that need packed weights / slabs (net-level calls pass the caller's
+// workspace instead): a small library-owned device buffer, grown on demand
+static float* op_scratch_floats(size_t n) {
+  static float* buf = nullptr;
+  static size_t cap = 0;
+  if (n > cap) {
+    if (buf) (void)hipFree(buf);
+    buf = nullptr; cap = 0;
+    if (hipMalloc((void**)&buf, n * sizeof(float)) != hipSuccess) return nullptr;
+    cap = n;
+  }
+  return buf;
+}
+
 int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out, int accumulate,
                   hipStream_t s) {
   if (d.vdz_z) {   // BatchNorm-backward apply on load: tiled 3-D 8 -> 8 data gradient only
@@ -308,6 +322,11 @@ int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const
   if ((d.algo == 0 || d.algo == 5) && pointwise_conv_supported(d, pass, accumulate))
     return launch_pointwise_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
   URSN_REQUIRE(d.algo != 5, "pointwise conv kernel does not support this shape");
+  if (d.algo == 0 && deep_conv_supported(d, pass)) {   // deepest levels (conv_deep.hip)
+    float* sc = op_scratch_floats(deep_conv_scratch_floats(d, pass));
+    URSN_REQUIRE(sc, "conv: no memory for the deep-level kernel's packed weights");
+    return launch_deep_conv(d, pass, in, w, out, accumulate, sc, nullptr, 0.f, nullptr, nullptr, s);
+  }
   if (d.algo == 0 && igemm_conv_supported(d, pass))
     return launch_igemm_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
   if (d.algo == 0 && tiled_conv_supported(d, pass)) return launch_tiled_conv(d, pass, in, w, out, accumulate, s);
@@ -451,6 +470,12 @@ extern "C" int ursn_conv_forward_stats(const ursn_conv_desc* d, const float* x, 
                  "conv_forward_stats: scratch too small");
     return launch_pointwise_conv(*d, PASS_FWD, x, w, y, 0, (double*)scratch, eps, mean, rstd, s);
   }
+  if (d->algo == 0 && deep_conv_supported(*d, PASS_FWD)) {
+    URSN_REQUIRE(deep_conv_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes, "conv_forward_stats: scratch too small");
+    float* sc = op_scratch_floats(deep_conv_scratch_floats(*d, PASS_FWD));
+    URSN_REQUIRE(sc, "conv_forward_stats: no memory for the deep-level kernel's packed weights");
+    return launch_deep_conv(*d, PASS_FWD, x, w, y, 0, sc, (double*)scratch, eps, mean, rstd, s);
+  }
   if ((d->algo == 0 || d->algo == 4) && igemm_conv_supported(*d, PASS_FWD)) {
     URSN_REQUIRE(igemm_stats_scratch_doubles(*d) * sizeof(double) <= scratch_bytes,
                  "conv_forward_stats: scratch too small");
@@ -538,6 +563,7 @@ extern "C" int ursn_conv_plan(const ursn_conv_desc* d0, int32_t pass_, char* out
     else if (d.pw_dy) name = (!d.in_split && igemm_conv_supported(d, pass)) ? "igemm" : (tiled_conv_supported(d, pass) ? "tconv" : "none");
     else if (d.in_split) name = pointwise_conv_supported(d, pass, 0) ? "pconv" : (tiled_conv_supported(d, pass) ? "tconv" : "none");
     else if (pointwise_conv_supported(d, pass, 0)) name = "pconv";
+    else if (deep_conv_supported(d, pass)) name = "dconv";
     else if (igemm_conv_supported(d, pass)) name = "igemm";
     else if (tiled_conv_supported(d, pass)) name = "tconv";
     else if (prefer_lds_scatter(d, pass)) name = "s2scatter";

@@ -86,6 +86,7 @@ struct ursn_net {
   void* head_scratch = nullptr;
   void* wg_scratch = nullptr;
   size_t wg_scratch_bytes = 0;
+  float* dc_scratch = nullptr;   // packed weights (+ split-K slabs) of the deep-level kernel (conv_deep.hip), main stream only
   // BatchNorm-backward reductions taken in the epilogue of the data-gradient kernel that finished a layer's output gradient
   double* bs_scratch = nullptr;
   int bs_layer = -1, bs_blocks = 0;   // layer whose (first) reductions are waiting in bs_scratch
@@ -321,7 +322,7 @@ int plan(ursn_net* n, Arena& A) {
   n->dlog = tr ? A.floats(V0 * n->layers[n->conv2].zcs) : nullptr;   // channel stride = conv2's padded stride
   n->metrics = A.floats(8);
   n->head_scratch = A.take(head_scratch_bytes(c.max_batch, n->lvox[0]) + 64);
-  size_t red = 0, wg = 0;
+  size_t red = 0, wg = 0, dcf = 0;
   for (const Layer& L : n->layers) {
     size_t r = reduce_scratch_bytes((int64_t)c.max_batch * n->lvox[L.lout], L.cout, 3);
     if (r > red) red = r;
@@ -342,6 +343,14 @@ int plan(ursn_net* n, Arena& A) {
       if (rt > red) red = rt;
       rt = lds_scatter_stats_scratch_doubles(d) * sizeof(double);
       if (rt > red) red = rt;
+      rt = deep_conv_stats_scratch_doubles(d) * sizeof(double);
+      if (rt > red) red = rt;
+      {
+        size_t f = deep_conv_scratch_floats(d, PASS_FWD);
+        if (f > dcf) dcf = f;
+        f = deep_conv_scratch_floats(d, PASS_DGRAD);
+        if (f > dcf) dcf = f;
+      }
       if (tr) {
         size_t w = ursn_conv_wgrad_scratch_bytes(&d);
         if (w > wg) wg = w;
@@ -349,6 +358,7 @@ int plan(ursn_net* n, Arena& A) {
     }
   }
   n->red_scratch = A.take(red + 256);
+  n->dc_scratch = dcf ? A.floats((int64_t)dcf + 64) : nullptr;
   {
     size_t red2 = 0;
     for (const Unit& u : n->units) {
@@ -434,6 +444,13 @@ int conv_stats(ursn_net* n, int li, const Act& in, int N, hipStream_t s, const A
     ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
     URSN_TRY(launch_pointwise_conv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, (double*)red_scratch,
                                    n->cfg.bn_eps, L.mean, L.rstd, s));
+    ps.done(ursn_last_kernel_name());
+    return 0;
+  }
+  if (n->dc_scratch && red_scratch == n->red_scratch && deep_conv_supported(d, PASS_FWD)) {  // deepest levels: weight-streaming kernel + moments
+    ProfScope ps(n, s, li, 0, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
+    URSN_TRY(launch_deep_conv(d, PASS_FWD, in.p, n->params + L.w_off, L.z, 0, n->dc_scratch, (double*)red_scratch, n->cfg.bn_eps,
+                              L.mean, L.rstd, s));
     ps.done(ursn_last_kernel_name());
     return 0;
   }
@@ -704,7 +721,10 @@ int conv_bwd(ursn_net* n, int li, const Act& in, bool need_dgrad, int N, hipStre
       if (blocks > 0 && blocks <= 16384) { d = t; n->bs_layer = bs->li; n->bs_blocks = blocks; }
     }
     ProfScope pd(n, s, li, 1, 2.0 * layer_macs(n, L, N), layer_bytes(n, L, N));
-    URSN_TRY(conv_dispatch(d, PASS_DGRAD, L.dz, n->params + L.w_off, in.g, acc ? 1 : 0, s));
+    if (n->dc_scratch && deep_conv_supported(d, PASS_DGRAD))
+      URSN_TRY(launch_deep_conv(d, PASS_DGRAD, L.dz, n->params + L.w_off, in.g, acc ? 1 : 0, n->dc_scratch, nullptr, 0.f, nullptr, nullptr, s));
+    else
+      URSN_TRY(conv_dispatch(d, PASS_DGRAD, L.dz, n->params + L.w_off, in.g, acc ? 1 : 0, s));
     pd.done(ursn_last_kernel_name());
   }
   return 0;

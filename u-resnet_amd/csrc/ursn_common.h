@@ -166,6 +166,13 @@ int igemm_wgrad_supported(const ursn_conv_desc& d);
 size_t igemm_wgrad_scratch_bytes(const ursn_conv_desc& d);
 int launch_igemm_wgrad(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch,
                        size_t scratch_bytes, hipStream_t s);
+// weight-streaming fp32 kernel for the deepest levels (>= 128 channels, <= 16384 voxels; conv_deep.hip): forward (+ fused
+// BatchNorm moments) and data gradient of plain 3-D k3 s1 layers; scratch = packed weights (+ split-K slabs) in floats
+int deep_conv_supported(const ursn_conv_desc& d, ConvPass pass);
+size_t deep_conv_scratch_floats(const ursn_conv_desc& d, ConvPass pass);
+size_t deep_conv_stats_scratch_doubles(const ursn_conv_desc& d);
+int launch_deep_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out, int accumulate,
+                     float* scratch, double* stats_partial, float eps, float* mean, float* rstd, hipStream_t s);
 // pointwise (1x1) shortcut convolutions (conv_pointwise.hip)
 int pointwise_conv_supported(const ursn_conv_desc& d, ConvPass pass, int accumulate);
 size_t pointwise_stats_scratch_doubles(const ursn_conv_desc& d);
