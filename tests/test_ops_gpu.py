@@ -449,11 +449,12 @@ def test_igemm_conv_fwd_dgrad_stats(case):
 
 
 DEEP_CASES = [
-    # N, S, cin, cout: the deepest levels of an F = 8 network (conv_deep.hip): 12^3 x 128, 6^3 x 256 (whole-image boxes, the
+    # N, S, cin, cout (2-D shapes: the 9-tap form, no z halo): the deepest levels of an F = 8 network (conv_deep.hip): 12^3 x 128, 6^3 x 256 (whole-image boxes, the
     # chunks split over workgroups as well), the 2C -> C decoder layers (four rounds of chunks), 8^3, ragged boxes, produced
     # channels that are not a multiple of 64
     (4, (12, 12, 12), 128, 128), (4, (6, 6, 6), 256, 256), (1, (12, 12, 12), 256, 128), (2, (8, 8, 8), 256, 256),
     (1, (5, 7, 9), 128, 64), (2, (6, 6, 6), 128, 256), (1, (16, 16, 16), 128, 128), (1, (4, 6, 10), 192, 80),
+    (4, (32, 32), 128, 128), (4, (16, 16), 256, 256), (4, (8, 8), 512, 512), (2, (16, 16), 512, 256), (1, (9, 21), 128, 64),
 ]
 
 
@@ -462,13 +463,14 @@ def test_deep_level_conv_fwd_dgrad_stats(case):
     """Weight-streaming kernel of the deepest levels (lib/resnet_module.py:43-66 at levels 4-5): forward + fused BatchNorm
     statistics, data gradient, accumulate -- and the dispatcher really hands these shapes to it."""
     N, S, ci, co = case
-    rng = np.random.default_rng(ci * 7 + co + S[2])
+    nd = len(S)
+    rng = np.random.default_rng(ci * 7 + co + S[-1])
     x = _rand(rng, (N,) + S + (ci,))
-    w = _rand(rng, (3, 3, 3, ci, co)) * 0.05
+    w = _rand(rng, (3,) * nd + (ci, co)) * 0.05
     y = O.conv_fwd(x, w, 1)
     dy = _rand(rng, y.shape)
     dx = O.conv_bwd(x, w, 1, dy)[0]
-    d = desc(3, N, S, ci, co, 3, 1)
+    d = desc(nd, N, S, ci, co, 3, 1)
     lib = _lib.load()
     buf = ctypes.create_string_buffer(32)
     for ps, want in ((0, b"dconv"), (1, b"dconv" if co >= 128 and co % 64 == 0 else None)):
@@ -483,7 +485,7 @@ def test_deep_level_conv_fwd_dgrad_stats(case):
     torch.cuda.synchronize()
     assert lib.ursn_last_kernel_name().startswith(b"dconv")
     assert rel_err(yg.cpu().numpy(), y) < TOL
-    ax = (0, 1, 2, 3)
+    ax = tuple(range(y.ndim - 1))
     assert np.abs(mg.cpu().numpy() - y.mean(axis=ax)).max() < 1e-5 * np.sqrt(y.var(axis=ax).max())
     assert rel_err(rg.cpu().numpy(), 1 / np.sqrt(y.var(axis=ax) + 1e-3)) < 1e-5
     assert rel_err(conv_forward(d, xg, wg, y.shape).cpu().numpy(), y) < TOL

@@ -41,12 +41,14 @@ struct DCArgs {
   int gsplit, rounds;      // slices of the chunk list over workgroups; rounds of 4 chunks per workgroup
   int bq[3], nb[3];        // box of produced voxels, boxes per axis
   int tpb;                 // 64-voxel tiles per box
+  int zpad;                // halo planes per side along z: 1, or 0 for 2-D problems (Z = 1)
   int hy, hxp, pp;         // halo image: rows per plane, row stride (voxels), voxels per piece plane (multiple of 64)
   int accumulate;
   int toff[27];            // LDS byte offset of tap t relative to the lane's voxel
 };
 
-template <bool STATS, bool SLAB>
+// NTAP: 27 (3-D) | 9 (2-D problems: Z = 1, the taps of the middle z plane only)
+template <int NTAP, bool STATS, bool SLAB>
 __global__ __launch_bounds__(256, 1) void dconv_kernel(DCArgs a) {
   constexpr int WK = 4, NT = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256, 1) void dconv_kernel(DCArgs a) {
   const int n = box / a.nb[0];
   const int z0 = bz * a.bq[0], y0 = by * a.bq[1], x0 = bx * a.bq[2];
   const int img_bytes = 4 * a.pp * 16;
-  const int hz = a.bq[0] + 2;
+  const int hz = a.bq[0] + 2 * a.zpad;
 
   // ---- staging geometry (fixed over rounds and images): this thread's halo voxels v = j * 256 + tid of a piece plane ----
   unsigned vrel[DC_MAXJ];
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256, 1) void dconv_kernel(DCArgs a) {
     if (v < a.pp) {
       const int hzz = v / (a.hy * a.hxp), r2 = v - hzz * a.hy * a.hxp;
       const int hyy = r2 / a.hxp, hxx = r2 - hyy * a.hxp;
-      const int gz = z0 + hzz - 1, gy = y0 + hyy - 1, gx = x0 + hxx - 1;
+      const int gz = z0 + hzz - a.zpad, gy = y0 + hyy - 1, gx = x0 + hxx - 1;
       if (hzz < hz && hxx < a.bq[2] + 2 && gz >= 0 && gz < a.Z && gy >= 0 && gy < a.Y && gx >= 0 && gx < a.X)
         vrel[j] = (unsigned)(((gz * a.Y + gy) * a.X + gx) * a.in_cs) * 4u;
     }
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void dconv_kernel(DCArgs a) {
     if (round > 0) __syncthreads();   // every wave is done with the images of the previous round
     stage(round);
     const int chunk = __builtin_amdgcn_readfirstlane((ks * a.rounds + round) * WK + wave);
-    const unsigned char* wsrc = (const unsigned char*)a.wp + ((size_t)(cob * a.nchunks + chunk) * 27) * 4096;
+    const unsigned char* wsrc = (const unsigned char*)a.wp + ((size_t)(cob * a.nchunks + chunk) * NTAP) * 4096;
     dc_f32x4 A[3][4];   // fragments two taps ahead of their MFMAs
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -138,13 +140,13 @@ __global__ __launch_bounds__(256, 1) void dconv_kernel(DCArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) B[0][nt] = *(const dc_f32x4*)(img + vbase[nt] + a.toff[0]);
 #pragma unroll
-    for (int t = 0; t < 27; ++t) {
+    for (int t = 0; t < NTAP; ++t) {
       const int cb = t & 1, ca = t % 3;
-      if (t + 2 < 27) {
+      if (t + 2 < NTAP) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) A[(t + 2) % 3][mt] = *(const dc_f32x4*)(wsrc + (t + 2) * 4096 + lane_off + mt * 1024);
       }
-      if (t + 1 < 27) {
+      if (t + 1 < NTAP) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) B[cb ^ 1][nt] = *(const dc_f32x4*)(img + vbase[nt] + a.toff[t + 1]);
       }
@@ -292,26 +294,26 @@ struct DCPackArgs {
   float* wp;
   int cin_w, cout_w;   // the STORED tensor [27][cin_w][cout_w]
   int flip;            // data gradient: contraction = stored cout, produced = stored cin, tap t reads stored tap 26 - t
-  int nchunks, ncob, K, Nn;
+  int nchunks, ncob, K, Nn, ntap;
 };
 __global__ __launch_bounds__(256) void dconv_pack_kernel(DCPackArgs k) {
-  const int64_t total = (int64_t)k.ncob * k.nchunks * 27 * 1024;
+  const int64_t total = (int64_t)k.ncob * k.nchunks * k.ntap * 1024;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int j = (int)(e & 3), lane = (int)((e >> 2) & 63), mt = (int)((e >> 8) & 3);
     int64_t r = e >> 10;
-    const int t = (int)(r % 27); r /= 27;
+    const int t = (int)(r % k.ntap); r /= k.ntap;
     const int ch = (int)(r % k.nchunks), cob = (int)(r / k.nchunks);
     const int kk = ch * 16 + 4 * (lane >> 4) + j, nn = cob * 64 + mt * 16 + (lane & 15);
     float v = 0.f;
     if (kk < k.K && nn < k.Nn)
-      v = k.flip ? k.w[((size_t)(26 - t) * k.cin_w + nn) * k.cout_w + kk] : k.w[((size_t)t * k.cin_w + kk) * k.cout_w + nn];
+      v = k.flip ? k.w[((size_t)(k.ntap - 1 - t) * k.cin_w + nn) * k.cout_w + kk] : k.w[((size_t)t * k.cin_w + kk) * k.cout_w + nn];
     k.wp[e] = v;
   }
 }
 
 struct DCPlan {
   int K, Nn, ics, ocs;   // kernel view (swapped for the data gradient)
-  int Z, Y, X;
+  int Z, Y, X, ntap;
   int bq[3], nb[3], tpb;
   int hy, hxp, pp;
   int nchunks, ncob, gsplit, rounds;
@@ -322,20 +324,26 @@ struct DCPlan {
 
 bool dc_plan(const ursn_conv_desc& d, ConvPass pass, DCPlan& p) {
   static const bool off = getenv("URSN_DCONV") && getenv("URSN_DCONV")[0] == '0';
-  if (off || d.dtype != 0 || d.ndim != 3 || d.transposed || d.k != 3 || d.stride != 1) return false;
+  if (off || d.dtype != 0 || (d.ndim != 3 && d.ndim != 2) || d.transposed || d.k != 3 || d.stride != 1) return false;
   if (pass != PASS_FWD && pass != PASS_DGRAD) return false;
   if (d.in_split || d.in_mean || d.pw_dy || d.bs_partial || d.vdz_z) return false;   // the fused forms stay with their kernels
   const bool flip = pass == PASS_DGRAD;
   const int ics = d.in_cstride > 0 ? d.in_cstride : d.cin, ocs = d.out_cstride > 0 ? d.out_cstride : d.cout;
   p.K = flip ? d.cout : d.cin; p.Nn = flip ? d.cin : d.cout;
   p.ics = flip ? ocs : ics; p.ocs = flip ? ics : ocs;
-  if (p.K < 128 || (p.K & 63) || p.Nn < 64 || (p.Nn & 15) || (p.ics & 3) || (p.ocs & 3)) return false;
-  p.Z = d.in_sp[0]; p.Y = d.in_sp[1]; p.X = d.in_sp[2];
+  static const int mink = getenv("URSN_DCONV_MINK") ? atoi(getenv("URSN_DCONV_MINK")) : 64;
+  if (p.K < mink || (p.K & 63) || p.Nn < 64 || (p.Nn & 15) || (p.ics & 3) || (p.ocs & 3)) return false;
+  if (d.ndim == 3) { p.Z = d.in_sp[0]; p.Y = d.in_sp[1]; p.X = d.in_sp[2]; p.ntap = 27; }
+  else { p.Z = 1; p.Y = d.in_sp[0]; p.X = d.in_sp[1]; p.ntap = 9; }   // 2-D: one z plane, the 9 in-plane taps
   const int Z = p.Z, Y = p.Y, X = p.X;
-  if (Z < 2 || Y < 4 || X < 4) return false;
+  if ((d.ndim == 3 && Z < 2) || Y < 4 || X < 4) return false;
   const int64_t V = (int64_t)d.n * Z * Y * X;
-  static const int64_t maxv = getenv("URSN_DCONV_MAXVOX") ? atoll(getenv("URSN_DCONV_MAXVOX")) : 16384;
-  if (V > maxv) return false;   // larger levels: the all-taps implicit GEMM has enough boxes to fill the chip
+  // measured against the all-taps implicit GEMM (tools/op_bench.py, 128 channels): 3-D 12^3 x 4 1.45x, 16^3 1.08x, 24^3 1.02-1.05x,
+  // 32^3 1.04-1.05x (127-136 TFLOP/s); 2-D 64^2 x 4 1.0x, 32^2 x 16 0.95x, 64^2 x 16 0.92-1.0x: 3-D always, 2-D up to 8192 voxels
+  static const int64_t maxv3 = getenv("URSN_DCONV_MAXVOX") ? atoll(getenv("URSN_DCONV_MAXVOX")) : ((int64_t)1 << 24);
+  static const int64_t maxv2 = getenv("URSN_DCONV_MAXVOX2D") ? atoll(getenv("URSN_DCONV_MAXVOX2D")) : 8192;
+  if (V > (d.ndim == 3 ? maxv3 : maxv2)) return false;
+  if (p.K < 128 && (d.ndim != 3 || V > 65536)) return false;   // 64 contraction channels: 24^3 x 4 1.02-1.06x, 48^3 1.0x, 2-D 0.87x
   if ((int64_t)Z * Y * X * (p.ics > p.ocs ? p.ics : p.ocs) * 4 >= ((int64_t)1 << 31)) return false;
   p.nchunks = p.K / 16;
   p.ncob = (p.Nn + 63) / 64;
@@ -344,13 +352,14 @@ bool dc_plan(const ursn_conv_desc& d, ConvPass pass, DCPlan& p) {
   double best = 1e300;
   int pick[3] = {0, 0, 0};
   for (int bz = 1; bz <= Z && bz <= 16; ++bz)
-    for (int by = 2; by <= Y && by <= 16; ++by)
-      for (int bx = 4; bx <= X && bx <= 16; ++bx) {
+    for (int by = 2; by <= Y && by <= 32; ++by)
+      for (int bx = 4; bx <= X && bx <= 32; ++bx) {
         const int bv = bz * by * bx;
-        if (bv < 48 || (bz + 2) * (by + 2) * (bx + 2) > 1024 - 64) continue;
+        const int hzp = bz + (d.ndim == 3 ? 2 : 0);
+        if (bv < 48 || hzp * (by + 2) * (bx + 2) > 1024 - 64) continue;
         const int nbz = (Z + bz - 1) / bz, nby = (Y + by - 1) / by, nbx = (X + bx - 1) / bx;
         const double tiles = (double)nbz * nby * nbx * ((bv + 63) / 64);
-        const double halo = (double)(bz + 2) * (by + 2) * (bx + 2) / 64.0;   // every tile's workgroup stages the WHOLE box image
+        const double halo = (double)hzp * (by + 2) * (bx + 2) / 64.0;   // every tile's workgroup stages the WHOLE box image
         const double cost = tiles * (1.0 + 0.05 * halo);
         if (cost < best) { best = cost; pick[0] = bz; pick[1] = by; pick[2] = bx; }
       }
@@ -359,7 +368,7 @@ bool dc_plan(const ursn_conv_desc& d, ConvPass pass, DCPlan& p) {
   p.nb[0] = (Z + pick[0] - 1) / pick[0]; p.nb[1] = (Y + pick[1] - 1) / pick[1]; p.nb[2] = (X + pick[2] - 1) / pick[2];
   p.tpb = (pick[0] * pick[1] * pick[2] + 63) / 64;
   p.hy = pick[1] + 2; p.hxp = pick[2] + 2;
-  p.pp = (((pick[0] + 2) * p.hy * p.hxp) + 63) & ~63;
+  p.pp = (((pick[0] + (d.ndim == 3 ? 2 : 0)) * p.hy * p.hxp) + 63) & ~63;
   if (p.pp > 256 * DC_MAXJ) return false;
   const size_t images = (size_t)4 * 4 * p.pp * 16, red = (size_t)4 * 4 * 4 * 1024;
   p.lds = images > red ? images : red;
@@ -395,7 +404,7 @@ int deep_conv_supported(const ursn_conv_desc& d, ConvPass pass) {
 size_t deep_conv_scratch_floats(const ursn_conv_desc& d, ConvPass pass) {
   DCPlan p;
   if (!dc_plan(d, pass, p)) return 0;
-  size_t e = (size_t)p.ncob * p.nchunks * 27 * 1024 + 64;
+  size_t e = (size_t)p.ncob * p.nchunks * p.ntap * 1024 + 64;
   if (p.gsplit > 1) e += (size_t)p.gsplit * d.n * p.Z * p.Y * p.X * p.Nn;
   return e;
 }
@@ -405,9 +414,9 @@ size_t deep_conv_stats_scratch_doubles(const ursn_conv_desc& d) {
   return p.gsplit > 1 ? (size_t)p.red_blocks * 2 * p.Nn : (size_t)p.boxes * p.tpb * p.ncob * 128;
 }
 
-template <bool STATS, bool SLAB>
+template <int NTAP, bool STATS, bool SLAB>
 static int dc_launch(const DCPlan& p, const DCArgs& a, hipStream_t s) {
-  auto kern = dconv_kernel<STATS, SLAB>;
+  auto kern = dconv_kernel<NTAP, STATS, SLAB>;
   static size_t attr = 48 * 1024;
   if (p.lds > attr) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
@@ -424,11 +433,11 @@ int launch_deep_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, co
                      float* scratch, double* stats_partial, float eps, float* mean, float* rstd, hipStream_t s) {
   DCPlan p;
   URSN_REQUIRE(dc_plan(d, pass, p) && scratch, "deep conv: unsupported shape or no scratch");
-  const size_t wtotal = (size_t)p.ncob * p.nchunks * 27 * 1024;
+  const size_t wtotal = (size_t)p.ncob * p.nchunks * p.ntap * 1024;
   {
     DCPackArgs k;
     k.w = w; k.wp = scratch; k.cin_w = d.cin; k.cout_w = d.cout; k.flip = pass == PASS_DGRAD ? 1 : 0;
-    k.nchunks = p.nchunks; k.ncob = p.ncob; k.K = p.K; k.Nn = p.Nn;
+    k.nchunks = p.nchunks; k.ncob = p.ncob; k.K = p.K; k.Nn = p.Nn; k.ntap = p.ntap;
     const int blocks = (int)(cdiv64((int64_t)wtotal, 256) < 4096 ? cdiv64((int64_t)wtotal, 256) : 4096);
     hipLaunchKernelGGL(dconv_pack_kernel, dim3(blocks), dim3(256), 0, s, k);
     URSN_HIP(hipGetLastError());
@@ -440,15 +449,24 @@ int launch_deep_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, co
   a.in_cs = p.ics; a.out_cs = p.ocs; a.Cout = p.Nn;
   a.nchunks = p.nchunks; a.gsplit = p.gsplit; a.rounds = p.rounds;
   for (int j = 0; j < 3; ++j) { a.bq[j] = p.bq[j]; a.nb[j] = p.nb[j]; }
-  a.tpb = p.tpb; a.hy = p.hy; a.hxp = p.hxp; a.pp = p.pp;
+  a.tpb = p.tpb; a.hy = p.hy; a.hxp = p.hxp; a.pp = p.pp; a.zpad = p.ntap == 27 ? 1 : 0;
   a.accumulate = accumulate;
-  for (int t = 0; t < 27; ++t)   // tap t = (tz, ty, tx) reads the voxel at displacement (t* - 1): halo position (+t*)
-    a.toff[t] = (((t / 9) * p.hy + (t / 3) % 3) * p.hxp + t % 3) * 16;
+  for (int t = 0; t < 27; ++t) a.toff[t] = 0;
+  for (int t = 0; t < p.ntap; ++t) {   // tap t = (tz, ty, tx) reads the voxel at displacement (t* - 1): halo position (+t*); 2-D: no z halo
+    const int tz = p.ntap == 27 ? t / 9 : 0, ty = (t / 3) % 3, tx = t % 3;
+    a.toff[t] = ((tz * p.hy + ty) * p.hxp + tx) * 16;
+  }
   const bool slab = p.gsplit > 1, st = stats_partial != nullptr && !slab;
   ursn_note_kernel(pass == PASS_DGRAD ? (slab ? "dconv_dgrad+splitk" : "dconv_dgrad") : (slab ? "dconv+splitk" : "dconv"));
-  if (slab) URSN_TRY((dc_launch<false, true>(p, a, s)));
-  else if (st) URSN_TRY((dc_launch<true, false>(p, a, s)));
-  else URSN_TRY((dc_launch<false, false>(p, a, s)));
+  if (p.ntap == 27) {
+    if (slab) URSN_TRY((dc_launch<27, false, true>(p, a, s)));
+    else if (st) URSN_TRY((dc_launch<27, true, false>(p, a, s)));
+    else URSN_TRY((dc_launch<27, false, false>(p, a, s)));
+  } else {
+    if (slab) URSN_TRY((dc_launch<9, false, true>(p, a, s)));
+    else if (st) URSN_TRY((dc_launch<9, true, false>(p, a, s)));
+    else URSN_TRY((dc_launch<9, false, false>(p, a, s)));
+  }
   const int64_t V = (int64_t)d.n * p.Z * p.Y * p.X;
   if (slab) {
     DCRedArgs r;
