@@ -469,7 +469,7 @@ def test_deep_level_conv_fwd_dgrad_stats(case):
     w = _rand(rng, (3,) * nd + (ci, co)) * 0.05
     y = O.conv_fwd(x, w, 1)
     dy = _rand(rng, y.shape)
-    dx = O.conv_bwd(x, w, 1, dy)[0]
+    dx, dw = O.conv_bwd(x, w, 1, dy)
     d = desc(nd, N, S, ci, co, 3, 1)
     lib = _lib.load()
     buf = ctypes.create_string_buffer(32)
@@ -492,6 +492,14 @@ def test_deep_level_conv_fwd_dgrad_stats(case):
     assert rel_err(conv_backward_data(d, dyg, wg, x.shape).cpu().numpy(), dx) < TOL
     base = _rand(rng, x.shape)
     assert rel_err(conv_backward_data(d, dyg, wg, x.shape, accumulate=1, dx_init=dev(base)).cpu().numpy(), dx + base) < TOL
+    # weight gradient: both operands straight from L2 (wgrad_deep.hip) where the level is small enough; accumulates
+    _lib.check(lib.ursn_conv_plan(ctypes.byref(d), 2, buf, 32))
+    small = N * int(np.prod(S)) * (1 if nd == 3 else 4) <= 1024   # only the last level (wgrad_deep.hip: measured)
+    assert (buf.value == b"dwgrad") == small, buf.value
+    dwg = conv_backward_weight(d, xg, dyg, w.shape)
+    assert lib.ursn_last_kernel_name().startswith(b"dwgrad") == small
+    assert rel_err(dwg.cpu().numpy(), dw) < 5e-5
+    assert rel_err(conv_backward_weight(d, xg, dyg, w.shape, dw_init=dwg).cpu().numpy(), 2 * dw) < 5e-5
 
 
 @pytest.mark.parametrize("case", [(3, 2, (8, 12, 16), 16, 8, 1), (3, 2, (8, 12, 16), 8, 16, 2), (3, 1, (6, 10, 14), 32, 16, 1),

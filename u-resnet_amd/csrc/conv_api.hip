@@ -553,6 +553,7 @@ extern "C" int ursn_conv_plan(const ursn_conv_desc* d0, int32_t pass_, char* out
   if (pass == PASS_WGRAD) {
     if (d.in_mean || (d.in_split && !pointwise_wgrad_supported(d))) name = tiled_wgrad_supported(d) ? "twgrad" : "none";
     else if (pointwise_wgrad_supported(d)) name = "pwgrad";
+    else if (deep_wgrad_supported(d)) name = "dwgrad";
     else if (igemm_wgrad_supported(d)) name = "igemm_wgrad";
     else if (valu_wgrad_supported(d)) name = "vwgrad";
     else if (tiled_wgrad_supported(d)) name = "twgrad";
@@ -591,6 +592,7 @@ extern "C" size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d) {
   size_t e = pointwise_wgrad_scratch_bytes(*d);
   size_t f = stride2_wgrad_scratch_bytes(*d);
   size_t v = valu_wgrad_scratch_bytes(*d);
+  { const size_t dwb = deep_wgrad_scratch_bytes(*d); if (dwb > a) a = dwb; }
   if (v > a) a = v;
   if (f > a) a = f;
   if (b > a) a = b;
@@ -613,6 +615,8 @@ int wgrad_dispatch(const ursn_conv_desc& d, const float* x, const float* dy, flo
   if ((d.algo == 0 || d.algo == 5) && pointwise_wgrad_supported(d))
     return launch_pointwise_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
   URSN_REQUIRE(d.algo != 5, "pointwise wgrad kernel does not support this shape");
+  if (d.algo == 0 && deep_wgrad_supported(d))   // deepest levels: operands straight from L2 (wgrad_deep.hip)
+    return launch_deep_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
   if ((d.algo == 0 || d.algo == 4) && igemm_wgrad_supported(d))
     return launch_igemm_wgrad(d, x, dy, dw, scratch, scratch_bytes, s);
   URSN_REQUIRE(d.algo != 4, "igemm wgrad kernel does not support this shape");

@@ -173,6 +173,11 @@ size_t deep_conv_scratch_floats(const ursn_conv_desc& d, ConvPass pass);
 size_t deep_conv_stats_scratch_doubles(const ursn_conv_desc& d);
 int launch_deep_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out, int accumulate,
                      float* scratch, double* stats_partial, float eps, float* mean, float* rstd, hipStream_t s);
+// weight gradient of the same deep-level layers with both operands straight from L2 (wgrad_deep.hip)
+int deep_wgrad_supported(const ursn_conv_desc& d);
+size_t deep_wgrad_scratch_bytes(const ursn_conv_desc& d);
+int launch_deep_wgrad(const ursn_conv_desc& d, const float* x, const float* dy, float* dw, void* scratch, size_t scratch_bytes,
+                      hipStream_t s);
 // pointwise (1x1) shortcut convolutions (conv_pointwise.hip)
 int pointwise_conv_supported(const ursn_conv_desc& d, ConvPass pass, int accumulate);
 size_t pointwise_stats_scratch_doubles(const ursn_conv_desc& d);
