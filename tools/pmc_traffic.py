@@ -10,7 +10,7 @@ import re
 import os
 import sys
 
-ROUND = os.environ.get("URSN_ROUND", "r03")
+ROUND = os.environ.get("URSN_ROUND", "r04")
 BF16 = len(sys.argv) > 1 and sys.argv[1] == "bf16"   # python tools/pmc_traffic.py bf16 -> profiles/r02_pmc_traffic_cfg5_bf16.json
 
 LABEL = [  # rocprof kernel name (regex) -> bench.py kernel label
@@ -21,6 +21,8 @@ LABEL = [  # rocprof kernel name (regex) -> bench.py kernel label
     (r"igemm_at_kernel<3, 32, 8, false", "igemm_at<32>"), (r"igemm_at_kernel<3, 32, 8, true", "igemm_at_dgrad<32>"),
     (r"igemm_at_kernel<3, 16, 16, false", "igemm_at<16>"), (r"igemm_wgrad_kernel<3, 2>", "igemm_wgrad<32>"),
     (r"s2conv_kernel<3", "s2conv"), (r"s2wgrad_kernel<3>", "s2wgrad"), (r"s2scatter_kernel<3", "s2scatter"),
+    (r"dconv_kernel<27, true", "dconv"), (r"dconv_kernel<27, false, false", "dconv_dgrad"),
+    (r"tconv_kernel<8, 8, 3, true, false, 1, true", "tconv_dgrad<8,8>+dz"),
     (r"bn_bwd_apply_kernel", "bn_bwd_apply"), (r"bn_bwd_reduce_kernel", "bn_bwd_reduce"), (r"bn_act_kernel", "bn_act"),
 ]
 if BF16:
@@ -31,6 +33,7 @@ if BF16:
              (r"bdeconv_kernel<true>", "bdeconv_bf16<16,8>"), (r"bpw_kernel<16, 8", "bpw_bf16"),
              (r"bcbconv_kernel<32, true>", "bcbconv_bf16<32>"), (r"bcbconv_kernel<32, false>", "bcbconv_bf16<32>(dgrad)"),
              (r"bcbconv_kernel<16, false>", "bcbconv_bf16<16>(dgrad)"), (r"b3conv_kernel<16, 16, false, false, 0, false", "b3conv_bf16<16,16>(dgrad)"),
+             (r"bdconv_kernel<2, 8", "bdconv_bf16<2,8>"), (r"bdconv_kernel<4, 8", "bdconv_bf16<4,8>"), (r"bdconv_kernel<2, 4", "bdconv_bf16<2,4>+splitk"),
              (r"bbn_bwd_apply_kernel<true, 0, false, false", "bbn_bwd_apply(C8)"), (r"bbn_bwd_reduce_kernel<true, 0, false", "bbn_bwd_reduce(C8)"),
              (r"bbn_act_kernel<true, false, false, false", "bbn_act(C8)")]
 
