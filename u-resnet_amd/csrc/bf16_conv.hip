@@ -879,15 +879,28 @@ static int bwgrad_launch(const BWPlan& p, const BWgradArgs& a, hipStream_t s) {
   return 0;
 }
 
+// 256 zero bytes inside the code object: the source of the padding pieces of the weight gradient's LDS-DMA staging (the launcher
+// used to clear the head of the caller's scratch with a hipMemsetAsync per launch: 49 fill kernels of 4.8 us per cfg5 step)
+__device__ __attribute__((aligned(256))) unsigned char ursn_zero_piece_dev[256];
+static const bf16_t* zero_piece() {
+  static const bf16_t* p = nullptr;
+  if (!p) {
+    void* d = nullptr;
+    if (hipGetSymbolAddress(&d, HIP_SYMBOL(ursn_zero_piece_dev)) != hipSuccess) return nullptr;
+    p = (const bf16_t*)d;
+  }
+  return p;
+}
+
 int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,
                   size_t scratch_bytes, hipStream_t s) {
   if (b3wgrad_ok(g)) return launch_b3wgrad(g, S, C, dw, Kw, Nw, scratch, scratch_bytes, s);
   BWPlan p;
   URSN_REQUIRE(bwgrad_plan(g, p), "bf16 wgrad: unsupported geometry (channels %d x %d)", g.K, g.Nn);
   URSN_REQUIRE(scratch && scratch_bytes >= bwgrad_scratch_bytes(g), "bf16 wgrad: scratch too small");
-  URSN_HIP(hipMemsetAsync(scratch, 0, 256, s));
-  const bf16_t* zero = (const bf16_t*)scratch;
-  scratch = (char*)scratch + 256;
+  const bf16_t* zero = zero_piece();
+  URSN_REQUIRE(zero, "bf16 wgrad: no address for the zero piece");
+  scratch = (char*)scratch + 256;   // (the slabs keep their 256-byte offset)
   BWgradArgs a;
   a.S = S; a.C = C; a.slab = (float*)scratch; a.N = g.N;
   for (int j = 0; j < 3; ++j) {
