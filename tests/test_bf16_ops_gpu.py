@@ -60,6 +60,16 @@ CASES = [
     ("k1s2_8_16", 3, 2, (8, 12, 36), 8, 16, 1, 2, 0),
     ("deconv_16_8", 3, 2, (4, 6, 18), 16, 8, 3, 2, 1),
     ("deconv_64_32", 3, 1, (3, 4, 6), 64, 32, 3, 2, 1),
+    # single-launch stride-2 scatter passes of the deeper levels (bf16_scatter.hip): transposed convs forward, stride-2 convs'
+    # data gradient; every kernel form <produced-channel tiles, voxel tiles>, two blocks of produced channels, ragged boxes
+    ("deconv_32_16_sc", 3, 2, (6, 8, 12), 32, 16, 3, 2, 1),           # <1,4>
+    ("deconv_32_16_big_sc", 3, 2, (32, 32, 32), 32, 16, 3, 2, 1),     # <1,8>: 128-voxel boxes
+    ("deconv_64_32_big_sc", 3, 2, (32, 32, 32), 64, 32, 3, 2, 1),     # <2,8>
+    ("deconv_128_64_sc", 3, 1, (5, 8, 8), 128, 64, 3, 2, 1),          # <4,4>
+    ("deconv_256_128_sc", 3, 2, (4, 4, 4), 256, 128, 3, 2, 1),        # <4,4>, two blocks of produced channels, 64 KB image
+    ("k3s2_16_32_sc", 3, 2, (8, 12, 20), 16, 32, 3, 2, 0),
+    ("k3s2_32_64_sc", 3, 1, (10, 12, 24), 32, 64, 3, 2, 0),
+    ("k3s2_128_256_sc", 3, 1, (8, 8, 8), 128, 256, 3, 2, 0),
     ("2d_k3s1_16_16", 2, 2, (24, 70), 16, 16, 3, 1, 0),
     ("2d_k3s2_16_32", 2, 2, (24, 70), 16, 32, 3, 2, 0),
     ("2d_deconv_32_16", 2, 1, (12, 20), 32, 16, 3, 2, 1),
@@ -92,11 +102,17 @@ def test_bf16_conv_forward_data_and_weight_gradients(case):
     if tag.endswith("_dp"):   # ... the deep-level kernel
         lib.ursn_last_kernel_name.restype = ctypes.c_char_p
         assert lib.ursn_last_kernel_name().startswith(b"bdconv_bf16"), lib.ursn_last_kernel_name()
+    if tag.endswith("_sc") and tr:   # ... the single-launch scatter kernel
+        lib.ursn_last_kernel_name.restype = ctypes.c_char_p
+        assert lib.ursn_last_kernel_name().startswith(b"bsconv_bf16"), lib.ursn_last_kernel_name()
     dxg = torch.full(x.shape, float("nan"), dtype=torch.bfloat16, device="cuda")
     _lib.check(lib.ursn_conv_backward_data(ctypes.byref(d), P(dyg), P(wg), P(dxg), 0, stream()))
     torch.cuda.synchronize()
     e = np.abs(dxg.float().cpu().numpy() - dx).max() / np.abs(dx).max()
     assert e <= BF_TOL, ("dgrad", e)
+    if tag.endswith("_sc") and not tr:
+        lib.ursn_last_kernel_name.restype = ctypes.c_char_p
+        assert lib.ursn_last_kernel_name().startswith(b"bsconv_bf16"), lib.ursn_last_kernel_name()
     if tag.endswith("_dp") and co % 64 == 0:   # the contraction splits over 2 | 4 waves: an even number of 32-channel chunks
         assert lib.ursn_last_kernel_name().startswith(b"bdconv_bf16"), lib.ursn_last_kernel_name()
     base, baseg = bf(rng.standard_normal(x.shape))

@@ -124,6 +124,16 @@ int bdeconv_grid_blocks(const GatherGeom* g, int cnt);   // = rows of its statis
 size_t bdeconv_pack_elems();
 int launch_bdeconv(const GatherGeom* g, int cnt, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                    double* stats_partial, int accumulate, hipStream_t s);
+// ... and of the deeper levels (>= 32 contraction channels, >= 16 produced): weight-streaming, classes dealt to the waves
+// (bf16_scatter.hip).  Statistics partials: [block of produced channels][bsconv_grid_blocks][2][64] doubles.
+bool bsconv_ok(const GatherGeom* g, int cnt);
+int bsconv_grid_blocks(const GatherGeom* g, int cnt);
+size_t bsconv_pack_elems(const GatherGeom* g, int cnt);
+size_t bsconv_stats_scratch_doubles(const GatherGeom* g, int cnt);
+int launch_bsconv(const GatherGeom* g, int cnt, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
+                  double* stats_partial, int accumulate, hipStream_t s);
+int bsconv_stats_finalize(const GatherGeom* g, int cnt, const double* partial, int64_t V, float eps, float* mean, float* rstd,
+                          hipStream_t s);
 bool b3wgrad_ok(const GatherGeom& g);   // z-marching weight gradient of the same layers (bf16_wgrad3.hip)
 bool b3wgrad_scalar_ok(const GatherGeom& g);   // S may be one fp32 channel per voxel (S_f32)
 size_t b3wgrad_scratch_bytes(const GatherGeom& g);

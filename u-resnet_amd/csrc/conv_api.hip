@@ -425,6 +425,14 @@ static int bf16_conv_op(const ursn_conv_desc& d0, ConvPass pass, const void* in,
     URSN_REQUIRE(wp, "bf16 conv: no memory for the packed weights");
     return launch_bdeconv(g, n, (const bf16_t*)in, w, 0, 0, wp, (bf16_t*)out, nullptr, accumulate, s);
   }
+  if (bsconv_ok(g, n)) {   // ... of the deeper levels (forward with BatchNorm moments too)
+    bf16_t* wp = op_wpack(bsconv_pack_elems(g, n));
+    URSN_REQUIRE(wp, "bf16 conv: no memory for the packed weights");
+    URSN_REQUIRE(!stats_partial || bsconv_stats_scratch_doubles(g, n) * sizeof(double) <= stats_bytes, "bf16 conv: statistics scratch too small");
+    URSN_TRY(launch_bsconv(g, n, (const bf16_t*)in, w, 0, 0, wp, (bf16_t*)out, stats_partial, accumulate, s));
+    if (stats_partial) URSN_TRY(bsconv_stats_finalize(g, n, stats_partial, V, eps, mean, rstd, s));
+    return 0;
+  }
   for (int i = 0; i < n; ++i) {
     g[i].accumulate = accumulate;
     if (g[i].ntaps == 0) continue;
@@ -541,6 +549,7 @@ extern "C" int ursn_conv_plan(const ursn_conv_desc* d0, int32_t pass_, char* out
     while (first < n - 1 && g[first].ntaps == 0) ++first;
     if (pass == PASS_WGRAD) name = b3wgrad_ok(g[0]) ? "b3wgrad" : (bwgrad_scratch_bytes(g[0]) ? "bwgrad" : "none");
     else if (bdeconv_ok(g, n)) name = "bdeconv";
+    else if (bsconv_ok(g, n)) name = "bsconv";
     else if (bpw_ok(g[first])) name = "bpw";
     else if (b3conv_ok(g[first])) name = "b3conv";
     else if (bcbconv_ok(g[first])) name = "bcbconv";

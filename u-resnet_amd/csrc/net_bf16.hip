@@ -303,6 +303,10 @@ int plan(ursn_bnet* n, Arena& A) {
           if (bdeconv_pack_elems() > wp) wp = bdeconv_pack_elems();
           if (pass == PASS_FWD) stl = (size_t)bdeconv_grid_blocks(g, cnt) * 32;
         }
+        if (pass != PASS_WGRAD && bsconv_ok(g, cnt)) {
+          if (bsconv_pack_elems(g, cnt) > wp) wp = bsconv_pack_elems(g, cnt);
+          if (pass == PASS_FWD) stl = bsconv_stats_scratch_doubles(g, cnt);
+        }
         for (int i = 0; i < cnt; ++i) {
           if (g[i].ntaps == 0) continue;
           if (pass == PASS_WGRAD) {
@@ -394,6 +398,10 @@ int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
     total = bdeconv_grid_blocks(g, cnt);
     URSN_TRY(launch_bdeconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, n->wpack, L.z, n->stats, 0, s));
     return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
+  }
+  if (bsconv_ok(g, cnt)) {   // transposed convs of the deeper levels: the eight parity classes in one launch
+    URSN_TRY(launch_bsconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, n->wpack, L.z, n->stats, 0, s));
+    return bsconv_stats_finalize(g, cnt, n->stats, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
   if (in.in_f32) {   // conv0 on the raw fp32 input
     URSN_REQUIRE(cnt == 1 && b3conv_ok(g[0]) && g[0].K == 8, "bf16 forward: %s cannot read a scalar fp32 input", L.name.c_str());
@@ -602,6 +610,8 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
   }
   if (bdeconv_ok(g, cnt))   // stride-2 conv 8 -> 16: the eight parity classes of its data gradient in one launch
     return launch_bdeconv(g, cnt, L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, acc ? 1 : 0, s);
+  if (bsconv_ok(g, cnt))   // stride-2 convs of the deeper levels: likewise
+    return launch_bsconv(g, cnt, L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, acc ? 1 : 0, s);
   for (int i = 0; i < cnt; ++i) {
     if (g[i].ntaps == 0) continue;
     g[i].accumulate = acc ? 1 : 0;
