@@ -212,6 +212,54 @@ def test_bf16_optional_kernel_paths_agree(tmp_path):
     assert np.median(errs) <= 0.2 and max(errs) <= 0.35
 
 
+_TRAIN_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from _net import as_f32_exact, make_inputs, oracle_params
+from uresnet_amd import uresnet
+dims, base, ncls, ns = (32, 32, 64, 1), 8, 3, 3
+P = as_f32_exact(oracle_params(dims, base, ncls, num_strides=ns))
+net = uresnet(dims=list(dims), num_class=ncls, base_num_outputs=base, num_strides=ns)
+net.construct(trainable=True, use_weight=True, learning_rate=1e-2, precision='bf16')
+net.set_variables(P)
+losses = []
+for it, N in enumerate((2, 2, 2, 1, 2)):   # the batch size changes once and comes back: the remembered jobs are dropped and re-made
+    data, label, weight = make_inputs(dims, ncls, N, seed=40 + it)
+    net.zero_gradients(None)
+    res, _ = net.accum_gradients(None, data, label, weight)
+    losses.append(res[1])
+    net.apply_gradients(None)
+sm = net.inference(None, data)[0]
+g = net.get_gradients()
+v = net.get_variables()
+np.savez(sys.argv[2], losses=np.array(losses), sm=sm, **{"g|" + k.replace("/", "|"): x for k, x in g.items()},
+         **{"v|" + k.replace("/", "|"): x for k, x in v.items()})
+"""
+
+
+def test_bf16_step_packing_in_one_launch_is_bitwise_the_per_launch_packing(tmp_path):
+    """From the second step at a batch size the bf16 plan packs every layer's weights in ONE launch at the start of forward
+    (bf16_pack.h) instead of one small launch in front of every conv kernel.  Five training iterations (Adam between them, so a
+    stale packed buffer would show; the batch size changes and returns) with the switch on and off (URSN_BF16_PREPACK=0):
+    losses, final gradients, updated variables and the softmax of a last inference call are bit-identical."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("one_launch", {}), ("per_launch", {"URSN_BF16_PREPACK": "0"})):
+        f = str(tmp_path / (tag + ".npz"))
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, "-c", _TRAIN_CHILD, root, f], check=True, env=e, timeout=600)
+        outs[tag] = dict(np.load(f))
+    a, b = outs["one_launch"], outs["per_launch"]
+    assert sorted(a) == sorted(b) and len(a) > 100
+    assert a["losses"][-1] != a["losses"][0]
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 _FULL_CHILD = r"""
 import sys, json, hashlib
 sys.path.insert(0, sys.argv[1])

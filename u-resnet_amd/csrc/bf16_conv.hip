@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "bf16_common.h"
+#include "bf16_pack.h"
 
 #define BCONV_MAX_SLOTS 112
 
@@ -316,34 +317,7 @@ __global__ __launch_bounds__(256) void bconv_kernel(BConvArgs a) {
   }
 }
 
-// ---- weight packing: fp32 master W_t[k][n] -> bf16 A-operand order [co block][chunk][j][co tile][lane = 16 g + m][8] -------
-struct BPackArgs {
-  const float* w;
-  bf16_t* wp;
-  int ntaps, K, Nn, w_tap_stride, w_sk, w_sn;   // K, Nn: extents of the STORED weight tensor (rows / columns beyond are 0)
-  int tap_w[URSN_MAX_TAPS];
-  int cinc, nchunks, nj, cot, ncob;
-};
-__global__ __launch_bounds__(256) void bconv_pack_kernel(BPackArgs a) {
-  const int cpb = a.cinc >> 3;
-  const int64_t total = (int64_t)a.ncob * a.nchunks * a.nj * a.cot * 64 * 8;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int i = (int)(e & 7);
-    int64_t r = e >> 3;
-    const int lane = (int)(r & 63); r >>= 6;
-    const int c = (int)(r % a.cot); r /= a.cot;
-    const int j = (int)(r % a.nj); r /= a.nj;
-    const int ch = (int)(r % a.nchunks);
-    const int cb_ = (int)(r / a.nchunks);
-    const int m = lane & 15, g = lane >> 4;
-    const int s = 4 * j + g, t = s / cpb, cb = s - t * cpb;
-    const int k = ch * a.cinc + cb * 8 + i, nn = (cb_ * a.cot + c) * 16 + m;
-    float v = 0.f;
-    if (t < a.ntaps && k < a.K && nn < a.Nn) v = a.w[(int64_t)a.tap_w[t] * a.w_tap_stride + (int64_t)k * a.w_sk + (int64_t)nn * a.w_sn];
-    a.wp[e] = f2bf(v);
-  }
-  if (blockIdx.x == 0 && threadIdx.x < 8) a.wp[total + threadIdx.x] = 0;   // the zero piece the conv's LDS-DMA pads with
-}
+// (weight packing: BPK_GENERIC in bf16_pack.hip -- [co block][chunk][j][co tile][lane = 16 g + m][8] + the zero piece)
 
 // ---- host side: box / chunk choice ----------------------------------------------------------------------------------
 struct BPlan {
@@ -516,15 +490,14 @@ int launch_bconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, 
   BPlan p;
   URSN_REQUIRE(bconv_plan(g, p), "bf16 conv: unsupported geometry (channels %d -> %d, strides %d / %d)", g.K, g.Nn, g.in_cs, g.out_cs);
   {
-    BPackArgs k;
-    k.w = w; k.wp = wpack; k.ntaps = g.ntaps; k.K = Kw > 0 ? Kw : g.K; k.Nn = Nw > 0 ? Nw : g.Nn;
+    BPackJob k = bpack_job(BPK_GENERIC);
+    k.w = w; k.wp = wpack; k.Kw = Kw > 0 ? Kw : g.K; k.Nw = Nw > 0 ? Nw : g.Nn;
     k.w_tap_stride = g.w_tap_stride; k.w_sk = g.w_sk; k.w_sn = g.w_sn;
-    for (int t = 0; t < g.ntaps; ++t) k.tap_w[t] = g.tap_w[t];
-    k.cinc = p.cinc; k.nchunks = p.nchunks; k.nj = p.nj; k.cot = p.cot; k.ncob = p.ncob;
+    for (int t = 0; t < g.ntaps; ++t) k.tap[t] = g.tap_w[t];
+    k.p[0] = g.ntaps; k.p[1] = p.cinc; k.p[2] = p.nchunks; k.p[3] = p.nj; k.p[4] = p.cot; k.p[5] = p.ncob;
     const int64_t total = (int64_t)p.ncob * p.nchunks * p.nj * p.cot * 64 * 8;
-    int blocks = (int)(cdiv64(total, 256) < 2048 ? cdiv64(total, 256) : 2048);
-    hipLaunchKernelGGL(bconv_pack_kernel, dim3(blocks), dim3(256), 0, s, k);
-    URSN_HIP(hipGetLastError());
+    k.blocks = (int)(cdiv64(total, 256) < 2048 ? cdiv64(total, 256) : 2048);
+    URSN_TRY(bpack_submit(k, s));
   }
   BConvArgs a;
   a.in = in; a.wp = wpack; a.out = out; a.stats_partial = stats_partial;

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "bf16_common.h"
+#include "bf16_pack.h"
 #include "buffer_stage.h"
 
 namespace {
@@ -485,38 +486,7 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
   }
 }
 
-struct B3PackArgs {
-  const float* w;
-  bf16_t* wp;
-  int tapw[27];   // weight tap index by displacement (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1), -1 = no such tap
-  int Kw, Nw, w_tap_stride, w_sk, w_sn;
-  const float* pw_w;   // shortcut weights [produced channel of the data gradient][8] or null
-};
-
-// fp32 master weights -> A operands: lane (row = l & 31, k half h = l >> 5) of k step m, row tile mt holds 8 contraction
-// channels of in-plane tap t (CI = 8: t = 2 m + h, channels 0..7; CI = 16: t = m, channels 8 h ..) for row (tap plane rg,
-// produced channel co): CO = 8: rg = row >> 3 (rows 24..31 zero); CO = 16: tile 0 rg = row >> 4, tile 1 rows 0..15 rg = 2
-template <int CI, int CO>
-__global__ void b3conv_pack_kernel(B3PackArgs k) {
-  using G = B3<CI, CO>;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < 8) k.wp[G::WPACK + e] = 0;   // the zero piece the LDS-DMA staging pads with
-  if (e >= G::WPACK) return;
-  const int j = e & 7, lane = (e >> 3) & 63, mm = e >> 9, mt = mm % G::MT, m = mm / G::MT;
-  const int row = lane & 31, h = lane >> 5;
-  const int t = CI == 8 ? 2 * m + h : m, ci = CI == 8 ? j : 8 * h + j;
-  int rg, co;
-  if (CO == 8) { rg = row >> 3; co = row & 7; }
-  else { rg = mt == 0 ? (row >> 4) : (row < 16 ? 2 : 3); co = row & 15; }
-  float v = 0.f;
-  if (t < 9 && rg < 3 && ci < k.Kw && co < k.Nw) {
-    const int tw = k.tapw[rg * 9 + t];
-    if (tw >= 0) v = k.w[(size_t)tw * k.w_tap_stride + (size_t)ci * k.w_sk + (size_t)co * k.w_sn];
-  }
-  // the idle slot (tap "9") of the centre tap plane carries the shortcut: dx[co] += sum_j pw[j] * Wsc[co][j]
-  if (CI == 8 && k.pw_w && t == 9 && rg == 1 && co < k.Nw) v = k.pw_w[(size_t)co * 8 + j];
-  k.wp[e] = f2bf(v);
-}
+// (weight packing: BPK_B3 in bf16_pack.hip)
 
 struct B3Plan { int zseg, nzseg, nty, ntx, grid; };
 B3Plan b3_plan(const GatherGeom& g) {
@@ -585,12 +555,16 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
   URSN_REQUIRE((!pw || ursn_bf16_plane_ok(g, pw_cs)) && (!out2 || ursn_bf16_plane_ok(g, out2_cs)) &&
                (!bs || (ursn_bf16_plane_ok(g, bs->z_cs) && ursn_bf16_plane_ok(g, bs->y_cs) && ursn_bf16_plane_ok(g, bs->z2_cs))),
                "bf16 3x3x3 conv: a z plane of an auxiliary operand (strides %d / %d) reaches the buffer path's out-of-range marker", pw_cs, out2_cs);
-  B3PackArgs k;
+  BPackJob k = bpack_job(BPK_B3);
   k.pw_w = pw ? pw_w : nullptr;
   k.w = w; k.wp = wpack; k.Kw = Kw > 0 ? Kw : g.K; k.Nw = Nw > 0 ? Nw : g.Nn;
   k.w_tap_stride = g.w_tap_stride; k.w_sk = g.w_sk; k.w_sn = g.w_sn;
-  for (int i = 0; i < 27; ++i) k.tapw[i] = -1;
-  for (int t = 0; t < g.ntaps; ++t) k.tapw[(g.tap_d[t][0] + 1) * 9 + (g.tap_d[t][1] + 1) * 3 + (g.tap_d[t][2] + 1)] = g.tap_w[t];
+  for (int i = 0; i < 27; ++i) k.tap[i] = -1;
+  for (int t = 0; t < g.ntaps; ++t) k.tap[(g.tap_d[t][0] + 1) * 9 + (g.tap_d[t][1] + 1) * 3 + (g.tap_d[t][2] + 1)] = g.tap_w[t];
+  auto pack = [&](int ci, int co, int wpack_elems, int mt) {
+    k.p[0] = ci; k.p[1] = co; k.p[2] = wpack_elems; k.p[3] = mt; k.blocks = (wpack_elems + 255) / 256;
+    return bpack_submit(k, s);
+  };
   const B3Plan p = b3_plan(g);
   B3Args a;
   a.in = in; a.wp = wpack; a.out = out; a.stats_partial = stats_partial;
@@ -612,7 +586,7 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
     a.aff_mean = aff->mean; a.aff_rstd = aff->rstd; a.aff_beta = aff->beta; a.aff_relu = aff->relu;
 #define B3AFF(c_, label)                                                                                                  \
     if (g.K == c_) {                                                                                                      \
-      hipLaunchKernelGGL((b3conv_pack_kernel<c_, c_>), dim3((B3<c_, c_>::WPACK + 255) / 256), dim3(256), 0, s, k);        \
+      URSN_TRY(pack(c_, c_, B3<c_, c_>::WPACK, B3<c_, c_>::MT));        \
       ursn_note_kernel(label);                                                                                            \
       if (stats_partial) hipLaunchKernelGGL((b3conv_kernel<c_, c_, true, false, 0, true>), dim3(p.grid), dim3(256), 0, s, a);  \
       else hipLaunchKernelGGL((b3conv_kernel<c_, c_, false, false, 0, true>), dim3(p.grid), dim3(256), 0, s, a);          \
@@ -629,7 +603,7 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
     a.bs_z = bs->z; a.bs_y = bs->y; a.bs_z2 = bs->z2; a.bs_maskb = bs->maskb; a.bs_mean = bs->mean; a.bs_rstd = bs->rstd; a.bs_beta = bs->beta;
     a.bs_mean2 = bs->mean2; a.bs_rstd2 = bs->rstd2; a.bs_partial = bs->partial;
     a.bs_z_cs = bs->z_cs; a.bs_y_cs = bs->y_cs; a.bs_z2_cs = bs->z2_cs; a.bs_mode = bs->mode;
-    hipLaunchKernelGGL((b3conv_pack_kernel<8, 8>), dim3((B3<8, 8>::WPACK + 255) / 256), dim3(256), 0, s, k);
+    URSN_TRY(pack(8, 8, B3<8, 8>::WPACK, B3<8, 8>::MT));
     ursn_note_kernel("b3conv_bf16<8,8>+bnred");
     if (bs->z2) hipLaunchKernelGGL((b3conv_kernel<8, 8, false, false, 2>), dim3(p.grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((b3conv_kernel<8, 8, false, false, 1>), dim3(p.grid), dim3(256), 0, s, a);
@@ -637,7 +611,7 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
     return 0;
   }
   if (pw) {
-    hipLaunchKernelGGL((b3conv_pack_kernel<8, 16>), dim3((B3<8, 16>::WPACK + 255) / 256), dim3(256), 0, s, k);
+    URSN_TRY(pack(8, 16, B3<8, 16>::WPACK, B3<8, 16>::MT));
     ursn_note_kernel("b3conv_bf16<8,16>+pw");
     hipLaunchKernelGGL((b3conv_kernel<8, 16, false, true>), dim3(p.grid), dim3(256), 0, s, a);
     URSN_HIP(hipGetLastError());
@@ -652,7 +626,7 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
   const bool pf2 = !dma_off && !in_f32 && !(g.K == 8 && g.Nn == 8 && !stats_partial);
 #define B3GO(ci, co, label)                                                                                              \
   if (g.K == ci && g.Nn == co) {                                                                                          \
-    hipLaunchKernelGGL((b3conv_pack_kernel<ci, co>), dim3((B3<ci, co>::WPACK + 255) / 256), dim3(256), 0, s, k);          \
+    URSN_TRY(pack(ci, co, B3<ci, co>::WPACK, B3<ci, co>::MT));          \
     ursn_note_kernel(label);                                                                                              \
     if (pf2) {                                                                                                            \
       if (stats_partial) hipLaunchKernelGGL((b3conv_kernel<ci, co, true, false, 0, false, true>), dim3(p.grid), dim3(256), 0, s, a);  \

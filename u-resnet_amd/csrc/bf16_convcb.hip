@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "bf16_common.h"
+#include "bf16_pack.h"
 #include "buffer_stage.h"
 
 namespace {
@@ -347,44 +348,7 @@ __global__ __launch_bounds__(256, 1) void bcbconv_kernel(CBArgs a) {
   }
 }
 
-struct CBPackArgs {
-  const float* w;
-  bf16_t* wp;
-  int tapw[27];   // weight tap index by displacement (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)
-  int Kw, Nw, w_tap_stride, w_sk, w_sn, ncob;
-  const float* pw_w;   // shortcut weights [produced channel of the data gradient][contraction channel] or null
-};
-
-// fp32 master weights -> A operands [cout block][tap plane tz][in-plane tap][k step][lane][8]: lane (row = l & 31, k half
-// h = l >> 5) holds contraction channels 16 ks + 8 h + (0..7) of produced channel 32 cob + row.  Tap plane tz multiplies input
-// plane p into output plane p + 1 - tz, i.e. it is the tap with displacement dz = tz - 1 ... of the OUTPUT: out[z] =
-// sum_dz in[z + dz] W[dz]  =>  in[p] W[dz] lands in out[p - dz]: tz = dz + 1.
-template <int CI>
-__global__ void bcbconv_pack_kernel(CBPackArgs k) {
-  using G = CB<CI>;
-  const int nk = 27 * G::KS + (k.pw_w ? G::KS : 0);   // KB of A fragments per block of produced channels
-  const int total = k.ncob * nk * 512;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < 8) k.wp[total + e] = 0;   // the zero piece
-  if (e >= total) return;
-  const int j = e & 7, lane = (e >> 3) & 63;
-  int r = e >> 9;
-  const int slot = r % nk, cob = r / nk;
-  const int co = cob * 32 + (lane & 31);
-  float v = 0.f;
-  if (slot < 27 * G::KS) {
-    const int ks = slot % G::KS, tt = slot / G::KS, t = tt % 9, tz = tt / 9;
-    const int ci = 16 * ks + 8 * (lane >> 5) + j;
-    if (ci < k.Kw && co < k.Nw) {
-      const int tw = k.tapw[tz * 9 + t];
-      if (tw >= 0) v = k.w[(size_t)tw * k.w_tap_stride + (size_t)ci * k.w_sk + (size_t)co * k.w_sn];
-    }
-  } else {
-    const int ci = 16 * (slot - 27 * G::KS) + 8 * (lane >> 5) + j;
-    if (ci < k.Kw && co < k.Nw) v = k.pw_w[(size_t)co * k.Kw + ci];
-  }
-  k.wp[e] = f2bf(v);
-}
+// (weight packing: BPK_CB in bf16_pack.hip)
 
 struct CBPlan { int zseg, nzseg, nty, ntx, ncob, grid; };
 CBPlan cb_plan(const GatherGeom& g) {
@@ -457,17 +421,16 @@ int launch_bcbconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw
   URSN_REQUIRE(!pw || (pw_w && !stats_partial && (pw_cs & 7) == 0 && pw_cs >= g.K), "bf16 channel-block conv: bad fused shortcut arguments");
   URSN_REQUIRE(!pw || ursn_bf16_plane_ok(g, pw_cs), "bf16 channel-block conv: a z plane of the fused shortcut operand (stride %d) reaches the buffer path's out-of-range marker", pw_cs);
   const CBPlan p = cb_plan(g);
-  CBPackArgs k;
+  BPackJob k = bpack_job(BPK_CB);
   k.w = w; k.wp = wpack; k.Kw = Kw > 0 ? Kw : g.K; k.Nw = Nw > 0 ? Nw : g.Nn;
-  k.w_tap_stride = g.w_tap_stride; k.w_sk = g.w_sk; k.w_sn = g.w_sn; k.ncob = p.ncob;
+  k.w_tap_stride = g.w_tap_stride; k.w_sk = g.w_sk; k.w_sn = g.w_sn;
   k.pw_w = pw ? pw_w : nullptr;
-  for (int i = 0; i < 27; ++i) k.tapw[i] = -1;
+  for (int i = 0; i < 27; ++i) k.tap[i] = -1;
   // in[q + d_t] W_t lands in out[q]: the staged plane p = q + dz feeds output plane p - dz, tap plane tz = dz + 1
-  for (int t = 0; t < g.ntaps; ++t) k.tapw[(g.tap_d[t][0] + 1) * 9 + (g.tap_d[t][1] + 1) * 3 + (g.tap_d[t][2] + 1)] = g.tap_w[t];
+  for (int t = 0; t < g.ntaps; ++t) k.tap[(g.tap_d[t][0] + 1) * 9 + (g.tap_d[t][1] + 1) * 3 + (g.tap_d[t][2] + 1)] = g.tap_w[t];
   const int total = p.ncob * (27 + (pw ? 1 : 0)) * (g.K / 16) * 512;
-  if (g.K == 16) hipLaunchKernelGGL(bcbconv_pack_kernel<16>, dim3((total + 255) / 256), dim3(256), 0, s, k);
-  else hipLaunchKernelGGL(bcbconv_pack_kernel<32>, dim3((total + 255) / 256), dim3(256), 0, s, k);
-  URSN_HIP(hipGetLastError());
+  k.p[0] = g.K / 16; k.p[1] = p.ncob; k.blocks = (total + 255) / 256;
+  URSN_TRY(bpack_submit(k, s));
   CBArgs a;
   a.in = in; a.wp = wpack; a.zero = wpack + total; a.out = out; a.stats_partial = stats_partial;
   a.N = g.N; a.Z = g.in_d[0]; a.Y = g.in_d[1]; a.X = g.in_d[2];

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "bf16_common.h"
+#include "bf16_pack.h"
 #include "buffer_stage.h"
 
 namespace {
@@ -347,26 +348,7 @@ __global__ __launch_bounds__(256) void bdconv_reduce_kernel(BDRedArgs a) {
   }
 }
 
-// ---- weight packing: fp32 master W_t[k][n] -> [cout block][chunk][tap][co tile][lane = 16 g + m][8] bf16 -------------------
-struct BDPackArgs {
-  const float* w;
-  bf16_t* wp;
-  int Kw, Nw, w_tap_stride, w_sk, w_sn, nchunks, ncob;
-  int tap_w[27];
-};
-__global__ __launch_bounds__(256) void bdconv_pack_kernel(BDPackArgs k) {
-  const int64_t total = (int64_t)k.ncob * k.nchunks * 27 * 2048;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int i = (int)(e & 7), lane = (int)((e >> 3) & 63), mt = (int)((e >> 9) & 3);
-    int64_t r = e >> 11;
-    const int t = (int)(r % 27); r /= 27;
-    const int ch = (int)(r % k.nchunks), cob = (int)(r / k.nchunks);
-    const int ci = ch * 32 + 8 * (lane >> 4) + i, co = cob * 64 + mt * 16 + (lane & 15);
-    float v = 0.f;
-    if (ci < k.Kw && co < k.Nw) v = k.w[(int64_t)k.tap_w[t] * k.w_tap_stride + (int64_t)ci * k.w_sk + (int64_t)co * k.w_sn];
-    k.wp[e] = f2bf(v);
-  }
-}
+// (weight packing: BPK_DEEP in bf16_pack.hip -- [cout block][chunk][tap][co tile][lane = 16 g + m][8])
 
 struct BDPlan {
   int wk, nt;            // kernel form
@@ -527,13 +509,13 @@ int launch_bdconv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
   URSN_REQUIRE(bdconv_ok(g) && bd_plan(g, p), "bf16 deep conv: unsupported geometry");
   const size_t wtotal = (size_t)p.ncob * p.nchunks * 27 * 2048;
   {
-    BDPackArgs k;
+    BPackJob k = bpack_job(BPK_DEEP);
     k.w = w; k.wp = wpack; k.Kw = Kw > 0 ? Kw : g.K; k.Nw = Nw > 0 ? Nw : g.Nn;
-    k.w_tap_stride = g.w_tap_stride; k.w_sk = g.w_sk; k.w_sn = g.w_sn; k.nchunks = p.nchunks; k.ncob = p.ncob;
-    for (int t = 0; t < 27; ++t) k.tap_w[t] = g.tap_w[t];
-    const int blocks = (int)(cdiv64((int64_t)wtotal, 256) < 4096 ? cdiv64((int64_t)wtotal, 256) : 4096);
-    hipLaunchKernelGGL(bdconv_pack_kernel, dim3(blocks), dim3(256), 0, s, k);
-    URSN_HIP(hipGetLastError());
+    k.w_tap_stride = g.w_tap_stride; k.w_sk = g.w_sk; k.w_sn = g.w_sn;
+    for (int t = 0; t < 27; ++t) k.tap[t] = g.tap_w[t];
+    k.p[0] = p.nchunks; k.p[1] = p.ncob;
+    k.blocks = (int)(cdiv64((int64_t)wtotal, 256) < 4096 ? cdiv64((int64_t)wtotal, 256) : 4096);
+    URSN_TRY(bpack_submit(k, s));
   }
   BDArgs a;
   a.in = in; a.wp = wpack; a.out = out; a.stats_partial = stats_partial;

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "bf16_common.h"
+#include "bf16_pack.h"
 
 namespace {
 
@@ -180,24 +181,7 @@ __global__ __launch_bounds__(256, 2) void bdeconv_kernel(D3Args a) {
   }
 }
 
-struct D3PackArgs {
-  const float* w;
-  bf16_t* wp;
-  int tapw[8][8];   // [class][neighbour] -> stored tap index, -1 = the class does not read that neighbour
-  int Kw, Nw, w_tap_stride, w_sk, w_sn;
-};
-// A operand of neighbour e, row tile mt: lane (row = l & 31, channel half h = l >> 5): class 4 mt + (row >> 3), produced channel
-// row & 7, contraction channels 8 h ..
-__global__ void bdeconv_pack_kernel(D3PackArgs k) {
-  const int x = blockIdx.x * 256 + threadIdx.x;
-  if (x >= D3_WPACK) return;
-  const int j = x & 7, lane = (x >> 3) & 63, mt = (x >> 9) & 1, e = x >> 10;
-  const int row = lane & 31, h = lane >> 5, cl = 4 * mt + (row >> 3), co = row & 7, ci = 8 * h + j;
-  float v = 0.f;
-  const int tw = k.tapw[cl][e];
-  if (tw >= 0 && ci < k.Kw && co < k.Nw) v = k.w[(size_t)tw * k.w_tap_stride + (size_t)ci * k.w_sk + (size_t)co * k.w_sn];
-  k.wp[x] = f2bf(v);
-}
+// (weight packing: BPK_D3 in bf16_pack.hip)
 
 struct D3Plan { int zseg, nzseg, nty, ntx, grid, dmin[3]; };
 bool d3_plan(const GatherGeom* g, int cnt, D3Plan& p) {
@@ -245,20 +229,19 @@ int launch_bdeconv(const GatherGeom* g, int cnt, const bf16_t* in, const float* 
                    double* stats_partial, int accumulate, hipStream_t s) {
   D3Plan p;
   URSN_REQUIRE(d3_plan(g, cnt, p), "bf16 stride-2 scatter pass: unsupported geometry");
-  D3PackArgs k;
+  BPackJob k = bpack_job(BPK_D3);
   k.w = w; k.wp = wpack; k.Kw = Kw > 0 ? Kw : g[0].K; k.Nw = Nw > 0 ? Nw : g[0].Nn;
   k.w_tap_stride = g[0].w_tap_stride; k.w_sk = g[0].w_sk; k.w_sn = g[0].w_sn;
-  for (int cl = 0; cl < 8; ++cl)
-    for (int e = 0; e < 8; ++e) k.tapw[cl][e] = -1;
+  for (int i = 0; i < 64; ++i) k.tap[i] = -1;
   for (int i = 0; i < cnt; ++i) {
     const int cl = g[i].po[0] * 4 + g[i].po[1] * 2 + g[i].po[2];
     for (int t = 0; t < g[i].ntaps; ++t) {
       const int e = (g[i].tap_d[t][0] - p.dmin[0]) * 4 + (g[i].tap_d[t][1] - p.dmin[1]) * 2 + (g[i].tap_d[t][2] - p.dmin[2]);
-      k.tapw[cl][e] = g[i].tap_w[t];
+      k.tap[cl * 8 + e] = g[i].tap_w[t];
     }
   }
-  hipLaunchKernelGGL(bdeconv_pack_kernel, dim3((D3_WPACK + 255) / 256), dim3(256), 0, s, k);
-  URSN_HIP(hipGetLastError());
+  k.p[0] = D3_WPACK; k.blocks = (D3_WPACK + 255) / 256;
+  URSN_TRY(bpack_submit(k, s));
   D3Args a;
   a.in = in; a.wp = wpack; a.out = out; a.stats_partial = stats_partial;
   a.N = g[0].N; a.Zc = g[0].in_d[0]; a.Yc = g[0].in_d[1]; a.Xc = g[0].in_d[2];

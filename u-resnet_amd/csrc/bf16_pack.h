@@ -1,0 +1,55 @@
+// bf16 plan: weight packing jobs -- gfx950.
+//
+// Every bf16 conv kernel reads its weights as bf16 MFMA A fragments in its own order; the fp32 masters change once per step
+// (Adam).  The launchers used to pack right before their kernel: ~110 launches of 4-5 us per cfg5 step, each on the critical
+// path of its layer.  Now a launcher describes its packing as a BPackJob and hands it to bpack_submit():
+//   * no context (operator API): the job's kernel is launched on the spot, as before;
+//   * under a network's BPackCtx, first step at a batch size (RECORD): launched on the spot AND remembered, keyed by its
+//     destination (the network gives every (layer, pass, parity class) its own packed buffer);
+//   * later steps (REPLAY): ursn_bnet forward starts with ONE launch of bpack_multi_kernel that runs every remembered job;
+//     bpack_submit() then finds the job remembered with identical arguments and launches nothing.  A job it has not seen (or
+//     sees with other arguments) is launched on the spot, remembered, and the device table is refreshed before the next replay.
+#pragma once
+#include <string.h>
+
+#include <unordered_map>
+#include <vector>
+
+#include "bf16_common.h"
+
+enum BPackType { BPK_GENERIC = 0, BPK_B3 = 1, BPK_CB = 2, BPK_D3 = 3, BPK_DEEP = 4, BPK_SCATTER = 5, BPK_PAD8 = 6 };
+
+struct BPackJob {
+  int type, blocks;           // blocks of 256 threads
+  const float* w;             // fp32 master weights of the layer
+  bf16_t* wp;                 // destination
+  const float* pw_w;          // fused shortcut weights (BPK_B3, BPK_CB) or null
+  int Kw, Nw, w_tap_stride, w_sk, w_sn;
+  int p[8];                   // per type, see bf16_pack.hip
+  int tap[64];
+  int pad_;                   // (no padding bytes: jobs are compared with memcmp)
+};
+
+struct BPackCtx {
+  int mode = 0;               // 0 record, 1 replay
+  std::vector<BPackJob> jobs;
+  std::unordered_map<const void*, int> by_dest;
+  bool dirty = false;
+  BPackJob* d_jobs = nullptr; // device table (cap jobs) and first-block prefix (cap + 1 ints): carved from the network's workspace
+  int* d_first = nullptr;
+  int cap = 0, uploaded = 0, total_blocks = 0;
+  long launches_saved = 0;
+  void clear() { jobs.clear(); by_dest.clear(); dirty = false; uploaded = 0; total_blocks = 0; mode = 0; }
+};
+
+static inline BPackJob bpack_job(int type) {
+  BPackJob j;
+  memset(&j, 0, sizeof(j));
+  j.type = type;
+  static_assert(sizeof(BPackJob) == 2 * 4 + 3 * 8 + 5 * 4 + 8 * 4 + 64 * 4 + 4, "BPackJob has padding");
+  return j;
+}
+
+void bpack_set_ctx(BPackCtx* c);          // thread-local; null = launch on the spot
+int bpack_submit(const BPackJob& j, hipStream_t s);
+int bpack_replay(BPackCtx& c, hipStream_t s);   // uploads the table if it changed, runs every remembered job in one launch

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "bf16_common.h"
+#include "bf16_pack.h"
 #include "buffer_stage.h"
 
 namespace {
@@ -224,27 +225,7 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(BSArgs a) {
   }
 }
 
-// ---- weight packing: fp32 master -> [cout block][item][chunk][mt][lane = 16 g + m][8] bf16 -------------------------------
-struct BSPackArgs {
-  const float* w;
-  bf16_t* wp;
-  int Kw, Nw, w_tap_stride, w_sk, w_sn, nchunks, ncob, mt;
-  int item_w[27];
-};
-__global__ __launch_bounds__(256) void bsconv_pack_kernel(BSPackArgs k) {
-  const int64_t total = (int64_t)k.ncob * 27 * k.nchunks * k.mt * 512;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int i = (int)(e & 7), lane = (int)((e >> 3) & 63);
-    int64_t r = e >> 9;
-    const int mt = (int)(r % k.mt); r /= k.mt;
-    const int ch = (int)(r % k.nchunks); r /= k.nchunks;
-    const int it = (int)(r % 27), cob = (int)(r / 27);
-    const int ci = ch * 32 + 8 * (lane >> 4) + i, co = (cob * k.mt + mt) * 16 + (lane & 15);
-    float v = 0.f;
-    if (ci < k.Kw && co < k.Nw) v = k.w[(int64_t)k.item_w[it] * k.w_tap_stride + (int64_t)ci * k.w_sk + (int64_t)co * k.w_sn];
-    k.wp[e] = f2bf(v);
-  }
-}
+// (weight packing: BPK_SCATTER in bf16_pack.hip -- [cout block][item][chunk][mt][lane = 16 g + m][8])
 
 struct BSPlan {
   int mt, nt, ncob, nchunks;
@@ -365,14 +346,14 @@ int launch_bsconv(const GatherGeom* g, int cnt, const bf16_t* in, const float* w
   URSN_REQUIRE(bs_plan(g, cnt, p), "bf16 stride-2 scatter pass (deep levels): unsupported geometry");
   const GatherGeom& g0 = g[0];
   {
-    BSPackArgs k;
+    BPackJob k = bpack_job(BPK_SCATTER);
     k.w = w; k.wp = wpack; k.Kw = Kw > 0 ? Kw : g0.K; k.Nw = Nw > 0 ? Nw : g0.Nn;
-    k.w_tap_stride = g0.w_tap_stride; k.w_sk = g0.w_sk; k.w_sn = g0.w_sn; k.nchunks = p.nchunks; k.ncob = p.ncob; k.mt = p.mt;
-    for (int t = 0; t < 27; ++t) k.item_w[t] = p.item_w[t];
+    k.w_tap_stride = g0.w_tap_stride; k.w_sk = g0.w_sk; k.w_sn = g0.w_sn;
+    for (int t = 0; t < 27; ++t) k.tap[t] = p.item_w[t];
+    k.p[0] = p.nchunks; k.p[1] = p.ncob; k.p[2] = p.mt;
     const int64_t total = (int64_t)p.ncob * 27 * p.nchunks * p.mt * 512;
-    const int blocks = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
-    hipLaunchKernelGGL(bsconv_pack_kernel, dim3(blocks), dim3(256), 0, s, k);
-    URSN_HIP(hipGetLastError());
+    k.blocks = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+    URSN_TRY(bpack_submit(k, s));
   }
   BSArgs a;
   a.in = in; a.wp = wpack; a.out = out; a.stats_partial = stats_partial;

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "bf16_common.h"
+#include "bf16_pack.h"
 #include "net_bf16.h"
 
 namespace {
@@ -50,6 +51,10 @@ struct BLayer {
   ursn_conv_desc desc;                                                     // memory-view channels
   bf16_t *z = nullptr, *dz = nullptr;
   float *mean = nullptr, *rstd = nullptr;
+  // packed weights of the forward pass [0] and the data gradient [1]: the layer's OWN buffers (one per parity class where the
+  // pass still runs as several launches), so that one launch at the start of a step can fill them all (bf16_pack.h)
+  bf16_t* wp[2] = {nullptr, nullptr};
+  size_t wp_elems[2] = {0, 0}, wp_stride[2] = {0, 0};
 };
 
 struct BUnit {
@@ -95,7 +100,7 @@ struct ursn_bnet {
   bf16_t* dlog = nullptr;
   float* metrics = nullptr;
   float* beta_pad = nullptr;     // conv2's beta padded to 8 (the head and the BatchNorm kernels index 8 channels)
-  bf16_t* wpack = nullptr; size_t wpack_elems = 0;
+  BPackCtx pack; int pack_N = -1;   // the step's weight packing in one launch (bf16_pack.h)
   bf16_t* wpack2 = nullptr;      // packed weights of the launches on the second stream (none today: wgrad packs nothing)
   double* stats = nullptr; size_t stats_doubles = 0;
   void* bn_scratch = nullptr;
@@ -289,8 +294,8 @@ int plan(ursn_bnet* n, Arena& A) {
   n->metrics = (float*)A.take(8 * sizeof(float));
   n->beta_pad = (float*)A.take(8 * sizeof(float));
   n->head_scratch = A.take(head_scratch_bytes(c.max_batch, n->lvox[0]) + 64);
-  size_t wp = 0, st = 0, bn = 0, wg = 0;
-  for (const BLayer& L : n->layers) {
+  size_t st = 0, bn = 0, wg = 0;
+  for (BLayer& L : n->layers) {
     const size_t b = bbn_scratch_bytes((int64_t)c.max_batch * n->lvox[L.lout], L.kout);
     if (b > bn) bn = b;
     for (int nb = 1; nb <= c.max_batch; ++nb) {   // the launch geometry is chosen per call from the batch actually fed
@@ -298,13 +303,13 @@ int plan(ursn_bnet* n, Arena& A) {
       for (int pass = 0; pass < (tr ? 3 : 1); ++pass) {
         const int cnt = layer_geoms(n, L, (ConvPass)pass, nb, L.kin, L.kout, g);
         URSN_REQUIRE(cnt >= 1, "bf16 plan: bad geometry for %s", L.name.c_str());
-        size_t stl = 0;
+        size_t stl = 0, wpl = 0, wps = 0;   // this pass: statistics doubles, packed elements (all classes), class stride
         if (pass != PASS_WGRAD && bdeconv_ok(g, cnt)) {
-          if (bdeconv_pack_elems() > wp) wp = bdeconv_pack_elems();
+          wpl = bdeconv_pack_elems();
           if (pass == PASS_FWD) stl = (size_t)bdeconv_grid_blocks(g, cnt) * 32;
         }
         if (pass != PASS_WGRAD && bsconv_ok(g, cnt)) {
-          if (bsconv_pack_elems(g, cnt) > wp) wp = bsconv_pack_elems(g, cnt);
+          wpl = bsconv_pack_elems(g, cnt);
           if (pass == PASS_FWD) stl = bsconv_stats_scratch_doubles(g, cnt);
         }
         for (int i = 0; i < cnt; ++i) {
@@ -314,18 +319,35 @@ int plan(ursn_bnet* n, Arena& A) {
             URSN_REQUIRE(w > 0, "bf16 plan: no weight-gradient kernel for %s", L.name.c_str());
             if (w > wg) wg = w;
           } else {
-            const size_t e = bconv_pack_elems(g[i]);
-            URSN_REQUIRE(e > 0, "bf16 plan: no conv kernel for %s (pass %d)", L.name.c_str(), pass);
-            if (e > wp) wp = e;
+            const size_t e = (bconv_pack_elems(g[i]) + 16 + 127) & ~(size_t)127;   // (+ the zero piece; 256-byte aligned classes)
+            URSN_REQUIRE(e > 16, "bf16 plan: no conv kernel for %s (pass %d)", L.name.c_str(), pass);
+            if (e > wps) wps = e;
             if (pass == PASS_FWD) stl += bconv_stats_scratch_doubles(g[i]);
           }
         }
         if (stl > st) st = stl;
+        if (pass != PASS_WGRAD) {
+          if (wps * cnt > wpl) wpl = wps * cnt;
+          if (wpl > L.wp_elems[pass]) L.wp_elems[pass] = wpl;
+          if (wps > L.wp_stride[pass]) L.wp_stride[pass] = wps;
+        }
       }
     }
   }
-  n->wpack_elems = wp;
-  n->wpack = (bf16_t*)A.take(wp * sizeof(bf16_t) + 256);
+  for (BLayer& L : n->layers)
+    for (int pass = 0; pass < (tr ? 2 : 1); ++pass) {
+      // a class stride chosen at one batch size must leave room for every class at any other: stride * 8 classes at most
+      if (L.wp_stride[pass] * 8 > L.wp_elems[pass] && L.wp_stride[pass] > 0) {
+        GatherGeom g[8];
+        int cmax = 1;
+        for (int nb = 1; nb <= c.max_batch; ++nb) { const int cc = layer_geoms(n, L, (ConvPass)pass, nb, L.kin, L.kout, g); if (cc > cmax) cmax = cc; }
+        if (L.wp_stride[pass] * cmax > L.wp_elems[pass]) L.wp_elems[pass] = L.wp_stride[pass] * cmax;
+      }
+      L.wp[pass] = (bf16_t*)A.take(L.wp_elems[pass] * sizeof(bf16_t) + 256);
+    }
+  n->pack.cap = 1024;
+  n->pack.d_jobs = (BPackJob*)A.take((size_t)n->pack.cap * sizeof(BPackJob));
+  n->pack.d_first = (int*)A.take((size_t)(n->pack.cap + 1) * sizeof(int));
   n->stats_doubles = st;
   n->stats = (double*)A.take(st * sizeof(double) + 256);
   n->bn_scratch = A.take(bn + 256);
@@ -396,18 +418,18 @@ int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
   int total = 0, off = 0;
   if (bdeconv_ok(g, cnt)) {   // transposed conv 16 -> 8: the eight parity classes in one launch
     total = bdeconv_grid_blocks(g, cnt);
-    URSN_TRY(launch_bdeconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, n->wpack, L.z, n->stats, 0, s));
+    URSN_TRY(launch_bdeconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, n->stats, 0, s));
     return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
   if (bsconv_ok(g, cnt)) {   // transposed convs of the deeper levels: the eight parity classes in one launch
-    URSN_TRY(launch_bsconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, n->wpack, L.z, n->stats, 0, s));
+    URSN_TRY(launch_bsconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, n->stats, 0, s));
     return bsconv_stats_finalize(g, cnt, n->stats, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
   if (in.in_f32) {   // conv0 on the raw fp32 input
     URSN_REQUIRE(cnt == 1 && b3conv_ok(g[0]) && g[0].K == 8, "bf16 forward: %s cannot read a scalar fp32 input", L.name.c_str());
     total = bconv_grid_blocks(g[0]);
     g[0].accumulate = 0;
-    URSN_TRY(launch_b3conv(g[0], nullptr, n->params + L.w_off, Kw, Nw, n->wpack, L.z, n->stats, 0, total, s, nullptr, 0, nullptr, nullptr,
+    URSN_TRY(launch_b3conv(g[0], nullptr, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, n->stats, 0, total, s, nullptr, 0, nullptr, nullptr,
                            nullptr, nullptr, 0, in.in_f32));
     return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
@@ -418,14 +440,14 @@ int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
     B3Affine af = {P.mean, P.rstd, beta_of(n, P), in.aff_relu};
     total = bconv_grid_blocks(g[0]);
     g[0].accumulate = 0;
-    URSN_TRY(launch_b3conv(g[0], P.z, n->params + L.w_off, Kw, Nw, n->wpack, L.z, n->stats, 0, total, s, nullptr, 0, nullptr, nullptr, &af));
+    URSN_TRY(launch_b3conv(g[0], P.z, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, n->stats, 0, total, s, nullptr, 0, nullptr, nullptr, &af));
     return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
   for (int i = 0; i < cnt; ++i) total += bconv_grid_blocks(g[i]);
   URSN_REQUIRE(total > 0, "bf16 forward: no kernel for %s", L.name.c_str());
   for (int i = 0; i < cnt; ++i) {
     g[i].accumulate = 0;
-    URSN_TRY(launch_bconv(g[i], in.p, n->params + L.w_off, Kw, Nw, n->wpack, L.z, n->stats, off, total, s));
+    URSN_TRY(launch_bconv(g[i], in.p, n->params + L.w_off, Kw, Nw, L.wp[0] + (size_t)i * L.wp_stride[0], L.z, n->stats, off, total, s));
     off += bconv_grid_blocks(g[i]);
   }
   return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
@@ -461,10 +483,19 @@ int unit_fwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s) {
 
 int forward(ursn_bnet* n, const float* data, int N, hipStream_t s) {
   const int ns = n->cfg.num_strides;
-  {  // conv2's beta, padded to the 8-channel piece
+  // Weight packing: every (layer, pass) has its own packed buffer; from the second step at a batch size on, ONE launch here
+  // fills them all and the launchers find their job done (bf16_pack.h).  URSN_BF16_PREPACK=0: every launcher packs for itself.
+  static const bool prepack = !(getenv("URSN_BF16_PREPACK") && getenv("URSN_BF16_PREPACK")[0] == '0');
+  if (prepack && n->pack.d_jobs) {
+    if (n->pack_N != N) { n->pack.clear(); n->pack_N = N; }
+    bpack_set_ctx(&n->pack);
+    URSN_TRY(bpack_replay(n->pack, s));
+  }
+  {  // conv2's beta, padded to the 8-channel piece (a packing job of its own kind: rides in the same launch)
     const BLayer& L2 = n->layers[n->conv2];
-    URSN_HIP(hipMemsetAsync(n->beta_pad, 0, 8 * sizeof(float), s));
-    URSN_HIP(hipMemcpyAsync(n->beta_pad, n->params + L2.b_off, L2.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+    BPackJob k = bpack_job(BPK_PAD8);
+    k.w = n->params + L2.b_off; k.wp = (bf16_t*)n->beta_pad; k.p[0] = L2.cout; k.blocks = 1;
+    URSN_TRY(bpack_submit(k, s));
   }
   n->a_data.in_f32 = n->scalar_in ? data : nullptr;
   if (!n->scalar_in) URSN_TRY(launch_bf16_input(data, n->a_data.p, (int64_t)N * n->lvox[0], s));
@@ -584,7 +615,7 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
       }
       r.partial = n->bs_scratch;
       g[0].accumulate = acc ? 1 : 0;
-      URSN_TRY(launch_b3conv(g[0], L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, 0, 0, s, nullptr, 0, nullptr, &r));
+      URSN_TRY(launch_b3conv(g[0], L.dz, n->params + L.w_off, Kw, Nw, L.wp[1], in.g, nullptr, 0, 0, s, nullptr, 0, nullptr, &r));
       n->bs_layer = bs->li; n->bs_blocks = blocks;
       return 0;
     }
@@ -594,7 +625,7 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
     URSN_REQUIRE(S.k == 1 && S.stride == 1 && S.kout == g[0].K && S.cout == S.kout && S.kin == g[0].Nn && S.cin == S.kin,
                  "bf16 backward: shortcut of %s does not match its data gradient", L.name.c_str());
     g[0].accumulate = acc ? 1 : 0;
-    return launch_bcbconv(g[0], L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, s, S.dz, S.kout, n->params + S.w_off);
+    return launch_bcbconv(g[0], L.dz, n->params + L.w_off, Kw, Nw, L.wp[1], in.g, nullptr, s, S.dz, S.kout, n->params + S.w_off);
   }
   if (fused_sc >= 0) {
     const BLayer& S = n->layers[fused_sc];
@@ -603,19 +634,19 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
     if (n->dec0_g && in.g == n->cat[n->cfg.num_strides - 1].g && !acc) {   // level-0 concat gradient: two 8-channel tensors
       g[0].out_cs = 8;
       n->split0_done = true;
-      return launch_b3conv(g[0], L.dz, n->params + L.w_off, Kw, Nw, n->wpack, n->dec0_g, nullptr, 0, 0, s, S.dz, S.kout, n->params + S.w_off,
+      return launch_b3conv(g[0], L.dz, n->params + L.w_off, Kw, Nw, L.wp[1], n->dec0_g, nullptr, 0, 0, s, S.dz, S.kout, n->params + S.w_off,
                            nullptr, nullptr, n->skip0_g, 8);
     }
-    return launch_b3conv(g[0], L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, 0, 0, s, S.dz, S.kout, n->params + S.w_off);
+    return launch_b3conv(g[0], L.dz, n->params + L.w_off, Kw, Nw, L.wp[1], in.g, nullptr, 0, 0, s, S.dz, S.kout, n->params + S.w_off);
   }
   if (bdeconv_ok(g, cnt))   // stride-2 conv 8 -> 16: the eight parity classes of its data gradient in one launch
-    return launch_bdeconv(g, cnt, L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, acc ? 1 : 0, s);
+    return launch_bdeconv(g, cnt, L.dz, n->params + L.w_off, Kw, Nw, L.wp[1], in.g, nullptr, acc ? 1 : 0, s);
   if (bsconv_ok(g, cnt))   // stride-2 convs of the deeper levels: likewise
-    return launch_bsconv(g, cnt, L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, acc ? 1 : 0, s);
+    return launch_bsconv(g, cnt, L.dz, n->params + L.w_off, Kw, Nw, L.wp[1], in.g, nullptr, acc ? 1 : 0, s);
   for (int i = 0; i < cnt; ++i) {
     if (g[i].ntaps == 0) continue;
     g[i].accumulate = acc ? 1 : 0;
-    URSN_TRY(launch_bconv(g[i], L.dz, n->params + L.w_off, Kw, Nw, n->wpack, in.g, nullptr, 0, 0, s));
+    URSN_TRY(launch_bconv(g[i], L.dz, n->params + L.w_off, Kw, Nw, L.wp[1] + (size_t)i * L.wp_stride[1], in.g, nullptr, 0, 0, s));
   }
   return 0;
 }
@@ -838,6 +869,7 @@ int bnet_param(const ursn_bnet* n, int64_t index, ursn_param_info* out) {
 int bnet_step(ursn_bnet* n, const float* data, const float* label, const float* weight, int N, int mode, float* softmax_out,
               float* labels_out, hipStream_t s) {
   // mode 0: accumulate gradients (forward + loss + backward); 1: evaluate (forward + loss); 2: inference
+  struct PackScope { ~PackScope() { bpack_set_ctx(nullptr); } } pack_scope;   // forward() installs the network's packing context
   URSN_TRY(forward(n, data, N, s));
   const float* w = n->cfg.use_weight ? weight : nullptr;
   if (mode == 0) {
