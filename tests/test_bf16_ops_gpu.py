@@ -262,7 +262,7 @@ def test_bf16_data_gradient_with_fused_shortcut_term_and_split_output(shape, spl
     assert np.abs(baseg.float().cpu().numpy() - (dx + base)).max() <= BF_TOL * np.abs(dx + base).max()
 
 
-@pytest.mark.parametrize("shape", [(2, (9, 21, 37)), (1, (40, 18, 34)), (2, (8, 16, 64))], ids=["odd", "zseg", "even"])
+@pytest.mark.parametrize("shape", [(2, (9, 21, 37)), (1, (40, 18, 34)), (2, (8, 16, 64)), (1, (5, 9, 130))], ids=["odd", "zseg", "even", "three_tiles"])
 def test_bf16_conv0_reads_the_fp32_scalar_input(shape):
     """conv0 (lib/uresnet.py:37-45) on the raw fp32 data, one channel per voxel: forward (+ fused moments) and weight gradient."""
     N, S = shape
@@ -285,9 +285,13 @@ def test_bf16_conv0_reads_the_fp32_scalar_input(shape):
     ys = yg.float().cpu().numpy().astype(np.float64)
     ax = tuple(range(ys.ndim - 1))
     assert rel_err(orr.cpu().numpy(), 1 / np.sqrt(ys.var(axis=ax) + 1e-3)) < 1e-5
+    assert rel_err(om.cpu().numpy(), ys.mean(axis=ax)) < 1e-5
+    lib.ursn_last_kernel_name.restype = ctypes.c_char_p
+    assert lib.ursn_last_kernel_name().startswith(b"b0conv_bf16"), lib.ursn_last_kernel_name()   # the taps-as-contraction kernel
     dy, dyg = bf(rng.standard_normal(y.shape))
     dw = O.conv_bwd(x, w, 1, dy)[1]
     assert rel_err(_wgrad(lib, d, xg, dyg, (3, 3, 3, 1, 8)), dw) < 2e-5
+    assert lib.ursn_last_kernel_name().startswith(b"b0wgrad_bf16"), lib.ursn_last_kernel_name()
 
 
 @pytest.mark.parametrize("shape", [(2, (8, 12, 36)), (1, (16, 20, 68))], ids=["small", "ragged_tiles"])

@@ -134,6 +134,17 @@ int launch_bsconv(const GatherGeom* g, int cnt, const bf16_t* in, const float* w
                   double* stats_partial, int accumulate, hipStream_t s);
 int bsconv_stats_finalize(const GatherGeom* g, int cnt, const double* partial, int64_t V, float eps, float* mean, float* rstd,
                           hipStream_t s);
+// conv0: one fp32 input channel per voxel -> 8 channels, 3x3x3 stride 1 (bf16_conv0.hip): the taps are the contraction.  g = the
+// layer's geometry in its 8-channel kernel view (K = 8).  Statistics partials: [b0conv_grid_blocks][2][16] doubles.
+bool b0conv_ok(const GatherGeom& g);
+int b0conv_grid_blocks(const GatherGeom& g);
+size_t b0conv_pack_elems();
+int launch_b0conv(const GatherGeom& g, const float* x, const float* w, int Nw, bf16_t* wpack, bf16_t* out, double* stats_partial,
+                  hipStream_t s);
+bool b0wgrad_ok(const GatherGeom& g);
+size_t b0wgrad_scratch_bytes(const GatherGeom& g);
+int launch_b0wgrad(const GatherGeom& g, const float* x, const bf16_t* dz, float* dw, int Nw, void* scratch, size_t scratch_bytes,
+                   hipStream_t s);
 bool b3wgrad_ok(const GatherGeom& g);   // z-marching weight gradient of the same layers (bf16_wgrad3.hip)
 bool b3wgrad_scalar_ok(const GatherGeom& g);   // S may be one fp32 channel per voxel (S_f32)
 size_t b3wgrad_scratch_bytes(const GatherGeom& g);

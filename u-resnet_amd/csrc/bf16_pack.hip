@@ -136,6 +136,18 @@ __device__ void pk_pad8(const BPackJob& k, int vb, int tid) {
   if (vb == 0 && tid < 8) ((float*)k.wp)[tid] = tid < k.p[0] ? k.w[tid] : 0.f;
 }
 
+// BPK_C0 (bf16_conv0.hip: one input channel): [tap plane dz][lane = 16 g + m][4]: k = 4 g + j is the tap (dy = g - 1, dx = j - 1)
+// of plane dz for produced channel m; k group 3 and j = 3 are zero.  tap[(dz+1)*9 + (dy+1)*3 + (dx+1)] = stored tap index
+__device__ void pk_c0(const BPackJob& k, int vb, int tid) {
+  const int e = vb * 256 + tid;
+  if (e >= 768) return;
+  const int j = e & 3, lane = (e >> 2) & 63, d = e >> 8;
+  const int m = lane & 15, g = lane >> 4;
+  float v = 0.f;
+  if (g < 3 && j < 3 && m < k.Nw) v = pk_w(k, k.tap[d * 9 + g * 3 + j], 0, m);
+  k.wp[e] = f2bf(v);
+}
+
 __device__ __forceinline__ void pk_run(const BPackJob& j, int vb, int tid) {
   switch (j.type) {
     case BPK_GENERIC: pk_generic(j, vb, tid); break;
@@ -144,6 +156,7 @@ __device__ __forceinline__ void pk_run(const BPackJob& j, int vb, int tid) {
     case BPK_D3: pk_d3(j, vb, tid); break;
     case BPK_DEEP: pk_deep(j, vb, tid); break;
     case BPK_PAD8: pk_pad8(j, vb, tid); break;
+    case BPK_C0: pk_c0(j, vb, tid); break;
     default: pk_scatter(j, vb, tid); break;
   }
 }

@@ -391,6 +391,15 @@ static int bf16_conv_op(const ursn_conv_desc& d0, ConvPass pass, const void* in,
     g[0].accumulate = accumulate;
     const int blocks = bconv_grid_blocks(g[0]);
     URSN_REQUIRE(!stats_partial || bconv_stats_scratch_doubles(g[0]) * sizeof(double) <= stats_bytes, "bf16 conv: statistics scratch too small");
+    if (scalar_in && (stored_weight_strides(g[0], 1, d.cout), b0conv_ok(g[0])) && !accumulate) {   // the taps are the contraction (bf16_conv0.hip)
+      bf16_t* wp0 = op_wpack(b0conv_pack_elems());
+      URSN_REQUIRE(wp0, "bf16 conv: no memory for the packed weights");
+      const int blocks0 = b0conv_grid_blocks(g[0]);
+      URSN_REQUIRE(!stats_partial || (size_t)blocks0 * 32 * sizeof(double) <= stats_bytes, "bf16 conv: statistics scratch too small");
+      URSN_TRY(launch_b0conv(g[0], (const float*)in, w, d.cout, wp0, (bf16_t*)out, stats_partial, s));
+      if (stats_partial) URSN_TRY(launch_bn_stats_final(stats_partial, blocks0, g[0].Nn, 16, V, eps, mean, rstd, s));
+      return 0;
+    }
     if (scalar_in) {
       URSN_REQUIRE(g[0].K == 8, "bf16 conv: the scalar input form needs the 8-channel kernel view");
       stored_weight_strides(g[0], 1, d.cout);
@@ -592,6 +601,7 @@ extern "C" size_t ursn_conv_wgrad_scratch_bytes(const ursn_conv_desc* d) {
     ursn_conv_desc dd = *d;
     if (dd.cin == 1) { dd.cin = 8; dd.in_cstride = 8; }
     if (build_geoms(dd, PASS_WGRAD, g) != 1) return 0;
+    if (d->cin == 1 && b0wgrad_ok(g[0]) && b0wgrad_scratch_bytes(g[0]) > bwgrad_scratch_bytes(g[0])) return b0wgrad_scratch_bytes(g[0]) + 256;
     return bwgrad_scratch_bytes(g[0]) + 256;
   }
   if (build_geoms(*d, PASS_WGRAD, g) != 1) return 0;
@@ -657,6 +667,10 @@ extern "C" int ursn_conv_backward_weight(const ursn_conv_desc* d, const float* x
     if (scalar_in || dd.in_mean) {   // the fused forms of the z-marching kernel (bf16_wgrad3.hip)
       URSN_REQUIRE(!dd.transposed && b3wgrad_ok(g[0]) && (!scalar_in || (b3wgrad_scalar_ok(g[0]) && !dd.in_mean)),
                    "conv_backward_weight: bf16 fused forms (cin = 1 / in_mean) need a 3-D k3 s1 layer with 8 / 16 channels");
+      if (scalar_in && b0wgrad_ok(g[0])) {
+        stored_weight_strides(g[0], 1, dd.cout);
+        return launch_b0wgrad(g[0], x, (const bf16_t*)dy, dw, dd.cout, scratch, scratch_bytes, (hipStream_t)stream);
+      }
       if (scalar_in)
         return launch_b3wgrad(g[0], nullptr, (const bf16_t*)dy, dw, 1, dd.cout, scratch, scratch_bytes, (hipStream_t)stream, nullptr, x);
       URSN_REQUIRE(dd.in_rstd && dd.in_beta, "conv_backward_weight: incomplete normalise-on-load arguments");

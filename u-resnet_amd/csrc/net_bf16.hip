@@ -315,7 +315,8 @@ int plan(ursn_bnet* n, Arena& A) {
         for (int i = 0; i < cnt; ++i) {
           if (g[i].ntaps == 0) continue;
           if (pass == PASS_WGRAD) {
-            const size_t w = bwgrad_scratch_bytes(g[i]);
+            size_t w = bwgrad_scratch_bytes(g[i]);
+            if (&L == &n->layers[n->conv0] && b0wgrad_ok(g[i]) && b0wgrad_scratch_bytes(g[i]) > w) w = b0wgrad_scratch_bytes(g[i]);
             URSN_REQUIRE(w > 0, "bf16 plan: no weight-gradient kernel for %s", L.name.c_str());
             if (w > wg) wg = w;
           } else {
@@ -323,6 +324,10 @@ int plan(ursn_bnet* n, Arena& A) {
             URSN_REQUIRE(e > 16, "bf16 plan: no conv kernel for %s (pass %d)", L.name.c_str(), pass);
             if (e > wps) wps = e;
             if (pass == PASS_FWD) stl += bconv_stats_scratch_doubles(g[i]);
+            if (pass == PASS_FWD && &L == &n->layers[n->conv0] && b0conv_ok(g[i])) {
+              if ((size_t)b0conv_grid_blocks(g[i]) * 32 > stl) stl = (size_t)b0conv_grid_blocks(g[i]) * 32;
+              if (b0conv_pack_elems() > wps) wps = (b0conv_pack_elems() + 127) & ~(size_t)127;
+            }
           }
         }
         if (stl > st) st = stl;
@@ -425,7 +430,12 @@ int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
     URSN_TRY(launch_bsconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, n->stats, 0, s));
     return bsconv_stats_finalize(g, cnt, n->stats, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
-  if (in.in_f32) {   // conv0 on the raw fp32 input
+  if (in.in_f32 && cnt == 1 && b0conv_ok(g[0])) {   // conv0 on the raw fp32 input: the taps are the contraction (bf16_conv0.hip)
+    total = b0conv_grid_blocks(g[0]);
+    URSN_TRY(launch_b0conv(g[0], in.in_f32, n->params + L.w_off, Nw, L.wp[0], L.z, n->stats, s));
+    return launch_bn_stats_final(n->stats, total, g[0].Nn, 16, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
+  }
+  if (in.in_f32) {   // ... or as an 8-channel layer with seven absent channels
     URSN_REQUIRE(cnt == 1 && b3conv_ok(g[0]) && g[0].K == 8, "bf16 forward: %s cannot read a scalar fp32 input", L.name.c_str());
     total = bconv_grid_blocks(g[0]);
     g[0].accumulate = 0;
@@ -578,7 +588,9 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
       ws = n->s2;
     }
     BProf pw(n, ws, li, 2, blayer_flops(n, L, N), blayer_bytes(n, L, N));
-    if (in.in_f32) {
+    if (in.in_f32 && !L.kind && b0wgrad_ok(g[0])) {
+      URSN_TRY(launch_b0wgrad(g[0], in.in_f32, L.dz, n->grads + L.w_off, Nw, n->wg_scratch, n->wg_bytes, ws));
+    } else if (in.in_f32) {
       URSN_REQUIRE(!L.kind && b3wgrad_scalar_ok(g[0]), "bf16 backward: %s cannot read a scalar fp32 input", L.name.c_str());
       URSN_TRY(launch_b3wgrad(g[0], nullptr, L.dz, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, ws, nullptr, in.in_f32));
     } else if (in.aff_layer >= 0) {
