@@ -623,7 +623,10 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
   // measured (256^3 x 4 / 128^3 x 4, tools/bf16_op_bench.py): forward 8 -> 8 0.81 -> 0.70 ms, 16 -> 8 1.12 -> 1.04, 16 -> 16 0.254 ->
   // 0.235; data gradients 16 -> 8 1.00 -> 0.96, 16 -> 16 0.244 -> 0.232, 8 -> 8 0.553 -> 0.572 (no statistics epilogue to hide
   // behind: stays on the register path)
-  const bool pf2 = !dma_off && !in_f32 && !(g.K == 8 && g.Nn == 8 && !stats_partial);
+  // ... unless it accumulates: on the register path the old values are read inside the epilogue (0.85 ms); the DMA path requests
+  // them a whole iteration ahead
+  static const bool acc_dma = !(getenv("URSN_B3CONV_ACC_DMA") && getenv("URSN_B3CONV_ACC_DMA")[0] == '0');
+  const bool pf2 = !dma_off && !in_f32 && (!(g.K == 8 && g.Nn == 8 && !stats_partial) || (acc_dma && g.accumulate));
 #define B3GO(ci, co, label)                                                                                              \
   if (g.K == ci && g.Nn == co) {                                                                                          \
     URSN_TRY(pack(ci, co, B3<ci, co>::WPACK, B3<ci, co>::MT));          \
