@@ -59,7 +59,8 @@ assert set(T.worst) >= {"z", "rstd", "act", "join", "dlogits", "dz", "dw", "dx"}
 print("INSITU_OK")
 """
 SWITCHES = [
-    ("bf16", {"URSN_B3CONV_DMA": "0"}),                    # register-staged planes instead of the LDS-DMA ring
+    ("bf16", {"URSN_B3CONV_DMA": "0", "URSN_BF16_SKIP0_MERGE": "0", "URSN_BF16_PREPACK": "0", "URSN_BF16_FWD_OVERLAP": "0"}),   # register-staged planes instead of the LDS-DMA ring; the skip's gradient share in its own tensor; per-launch weight packing; shortcut convs in line
+    ("bf16", {"URSN_BSCONV": "0", "URSN_B0CONV": "0", "URSN_B3CONV_ACC_DMA": "0"}),   # round-4 kernels off: stride-2 scatter passes by parity class, conv0 as an 8-channel layer
     ("bf16", {"URSN_BCB": "0", "URSN_SLAB_FOLD": "0"}),    # generic box kernel at levels 1-2, one-stage slab reduce
     ("bf16", {"URSN_BF16_FUSE_BN_BWD_REDUCE": "1"}),       # BatchNorm-backward reductions in the data-gradient epilogue
     ("bf16", {"URSN_B3CONV_PW": "0", "URSN_BF16_NORM_ON_LOAD": "0", "URSN_BF16_SKIP0_OWN": "0"}),   # no fused shortcut term, materialised activations, skip inside the concat buffer
@@ -148,8 +149,16 @@ def _full_size_checks(net, P, bf16, ns=5):
     F = xd.shape[-1]
     terms = lambda s: [(c1, "conv", s), (sc, "conv", s)]
     fs.check_data_gradient(dec + ":grad", fs.t(dec + ":grad"), terms(slice(0, F)), n_terms=2)
-    if bf16 and F == 8:   # the skip's share of the concat gradient is its own tensor
-        fs.check_data_gradient(U + "conv0:grad2", net.debug_tensor(U + "conv0:grad2"), terms(slice(F, 2 * F)), n_terms=2)
+    if bf16 and F == 8:   # the skip's share of the concat gradient is its own tensor ...
+        try:
+            g2 = net.debug_tensor(U + "conv0:grad2")
+        except Exception as e:   # ... until the encoder's data gradients accumulate into it (default): by the end of the backward
+            # pass it holds the whole d(conv0 activation); the sum over ALL consumers is checked on the small nets
+            # (_insitu.InSitu.total_grad) and the switch case URSN_BF16_SKIP0_MERGE=0 keeps the separate tensor
+            assert "no second gradient tensor" in str(e), e
+            g2 = None
+        if g2 is not None:
+            fs.check_data_gradient(U + "conv0:grad2", g2, terms(slice(F, 2 * F)), n_terms=2)
     gd = fs.t(dec + ":grad")
     fs.check_bn_backward(dec, lambda n, a, b: gd[n, a:b].astype(np.float64) * (xd[n, a:b] > 0))
     fs.drop(c1 + ":z", c1 + ":dz", sc + ":dz", U + "conv0", dec, dec + ":grad")

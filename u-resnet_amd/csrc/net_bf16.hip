@@ -94,6 +94,7 @@ struct ursn_bnet {
   // ... and the gradient of that concat voxel is produced as two 8-channel tensors (the transposed conv's half and the skip's
   // half have different consumers; read as 16-byte halves of a 32-byte voxel each cost a full pass of the other half)
   bf16_t* dec0_g = nullptr; bf16_t* skip0_g = nullptr;
+  bool skip0_merge = false;
   bool split0_done = false;   // this backward pass produced the two tensors (the fused 8 -> 16 data gradient ran)
   std::vector<int> ginit;
   float *params = nullptr, *grads = nullptr;
@@ -106,6 +107,7 @@ struct ursn_bnet {
   void* bn_scratch = nullptr;
   void* head_scratch = nullptr;
   void* wg_scratch = nullptr; size_t wg_bytes = 0;
+  double* stats2 = nullptr;
   hipStream_t s2 = nullptr;
   hipEvent_t s2_done = nullptr;
   std::vector<hipEvent_t> evs;
@@ -223,11 +225,16 @@ int plan(ursn_bnet* n, Arena& A) {
                    (!tr || (layer_geoms(n, L0, PASS_WGRAD, c.max_batch, L0.kin, L0.kout, g) == 1 && b3wgrad_scalar_ok(g[0])));
   }
   n->skip0_own = F == 8 && !(getenv("URSN_BF16_SKIP0_OWN") && getenv("URSN_BF16_SKIP0_OWN")[0] == '0');
-  n->a_conv0 = n->skip0_own ? make_act(n, A, 0, F, tr) : fmap_view(0);
+  // ... and the skip's half IS the gradient tensor of conv0's activation: the encoder's data gradients (module0, run later in
+  // the backward pass) accumulate into it, so conv0's BatchNorm backward reads one gradient tensor in each of its two passes
+  // instead of two (URSN_BF16_SKIP0_MERGE=0: a tensor of its own for the encoder's share)
+  n->skip0_merge = n->skip0_own && tr && !(getenv("URSN_BF16_SKIP0_MERGE") && getenv("URSN_BF16_SKIP0_MERGE")[0] == '0');
+  n->a_conv0 = n->skip0_own ? make_act(n, A, 0, F, tr && !n->skip0_merge) : fmap_view(0);
   if (n->skip0_own && tr) {
     const size_t bytes = (size_t)c.max_batch * n->lvox[0] * 8 * sizeof(bf16_t);
     n->dec0_g = (bf16_t*)A.take(bytes);
     n->skip0_g = (bf16_t*)A.take(bytes);
+    if (n->skip0_merge) n->a_conv0.g = n->skip0_g;
   }
   // can the consumer layer L (k3 s1, C -> C) apply its producer's BatchNorm while staging (forward and weight gradient)?
   auto virtual_ok = [&](const BLayer& L) {
@@ -355,6 +362,7 @@ int plan(ursn_bnet* n, Arena& A) {
   n->pack.d_first = (int*)A.take((size_t)(n->pack.cap + 1) * sizeof(int));
   n->stats_doubles = st;
   n->stats = (double*)A.take(st * sizeof(double) + 256);
+  n->stats2 = (double*)A.take(st * sizeof(double) + 256);   // the shortcut convs' partials: they run beside conv1 / conv2 on the second stream
   n->bn_scratch = A.take(bn + 256);
   n->wg_bytes = wg;
   n->wg_scratch = tr ? A.take(wg + 256) : nullptr;
@@ -413,7 +421,8 @@ double blayer_bytes(const ursn_bnet* n, const BLayer& L, int N) {
 }
 
 const float* beta_of(ursn_bnet* n, const BLayer& L);
-int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
+int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s, double* stats = nullptr) {
+  if (!stats) stats = n->stats;
   BLayer& L = n->layers[li];
   GatherGeom g[8];
   const int cnt = layer_geoms(n, L, PASS_FWD, N, in.cs, L.kout, g);
@@ -423,25 +432,25 @@ int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
   int total = 0, off = 0;
   if (bdeconv_ok(g, cnt)) {   // transposed conv 16 -> 8: the eight parity classes in one launch
     total = bdeconv_grid_blocks(g, cnt);
-    URSN_TRY(launch_bdeconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, n->stats, 0, s));
-    return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
+    URSN_TRY(launch_bdeconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, stats, 0, s));
+    return bconv_stats_finalize(g[0], stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
   if (bsconv_ok(g, cnt)) {   // transposed convs of the deeper levels: the eight parity classes in one launch
-    URSN_TRY(launch_bsconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, n->stats, 0, s));
-    return bsconv_stats_finalize(g, cnt, n->stats, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
+    URSN_TRY(launch_bsconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, stats, 0, s));
+    return bsconv_stats_finalize(g, cnt, stats, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
   if (in.in_f32 && cnt == 1 && b0conv_ok(g[0])) {   // conv0 on the raw fp32 input: the taps are the contraction (bf16_conv0.hip)
     total = b0conv_grid_blocks(g[0]);
-    URSN_TRY(launch_b0conv(g[0], in.in_f32, n->params + L.w_off, Nw, L.wp[0], L.z, n->stats, s));
-    return launch_bn_stats_final(n->stats, total, g[0].Nn, 16, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
+    URSN_TRY(launch_b0conv(g[0], in.in_f32, n->params + L.w_off, Nw, L.wp[0], L.z, stats, s));
+    return launch_bn_stats_final(stats, total, g[0].Nn, 16, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
   if (in.in_f32) {   // ... or as an 8-channel layer with seven absent channels
     URSN_REQUIRE(cnt == 1 && b3conv_ok(g[0]) && g[0].K == 8, "bf16 forward: %s cannot read a scalar fp32 input", L.name.c_str());
     total = bconv_grid_blocks(g[0]);
     g[0].accumulate = 0;
-    URSN_TRY(launch_b3conv(g[0], nullptr, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, n->stats, 0, total, s, nullptr, 0, nullptr, nullptr,
+    URSN_TRY(launch_b3conv(g[0], nullptr, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, stats, 0, total, s, nullptr, 0, nullptr, nullptr,
                            nullptr, nullptr, 0, in.in_f32));
-    return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
+    return bconv_stats_finalize(g[0], stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
   if (in.aff_layer >= 0) {   // virtual input: BatchNorm of the producer applied while staging
     const BLayer& P = n->layers[in.aff_layer];
@@ -450,17 +459,17 @@ int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s) {
     B3Affine af = {P.mean, P.rstd, beta_of(n, P), in.aff_relu};
     total = bconv_grid_blocks(g[0]);
     g[0].accumulate = 0;
-    URSN_TRY(launch_b3conv(g[0], P.z, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, n->stats, 0, total, s, nullptr, 0, nullptr, nullptr, &af));
-    return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
+    URSN_TRY(launch_b3conv(g[0], P.z, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, stats, 0, total, s, nullptr, 0, nullptr, nullptr, &af));
+    return bconv_stats_finalize(g[0], stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
   for (int i = 0; i < cnt; ++i) total += bconv_grid_blocks(g[i]);
   URSN_REQUIRE(total > 0, "bf16 forward: no kernel for %s", L.name.c_str());
   for (int i = 0; i < cnt; ++i) {
     g[i].accumulate = 0;
-    URSN_TRY(launch_bconv(g[i], in.p, n->params + L.w_off, Kw, Nw, L.wp[0] + (size_t)i * L.wp_stride[0], L.z, n->stats, off, total, s));
+    URSN_TRY(launch_bconv(g[i], in.p, n->params + L.w_off, Kw, Nw, L.wp[0] + (size_t)i * L.wp_stride[0], L.z, stats, off, total, s));
     off += bconv_grid_blocks(g[i]);
   }
-  return bconv_stats_finalize(g[0], n->stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
+  return bconv_stats_finalize(g[0], stats, total, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
 }
 
 const float* beta_of(ursn_bnet* n, const BLayer& L) { return L.cout == L.kout ? n->params + L.b_off : n->beta_pad; }
@@ -482,11 +491,36 @@ int bn_out(ursn_bnet* n, int li, const BAct& out, int relu, int N, int li2, cons
   return launch_bbn_act(a, s);
 }
 
+hipEvent_t next_event(ursn_bnet* n) {
+  if (n->ev_used == n->evs.size()) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    n->evs.push_back(e);
+  }
+  return n->evs[n->ev_used++];
+}
+
 int unit_fwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s) {
-  if (u.sc >= 0) URSN_TRY(conv_stats(n, u.sc, u.in, N, s));
+  // The 1x1 shortcut conv reads the unit's input like conv1 and is needed at the join only: it runs on the second stream beside
+  // conv1 -> BatchNorm -> conv2 (these passes sit at 4-5 TB/s each, latency-bound; together they use more of the HBM).
+  // URSN_BF16_FWD_OVERLAP=0: in line.
+  static const bool overlap = !(getenv("URSN_BF16_FWD_OVERLAP") && getenv("URSN_BF16_FWD_OVERLAP")[0] == '0');
+  hipEvent_t joined = nullptr;
+  if (u.sc >= 0 && overlap && n->s2 && n->s2_on) {
+    hipEvent_t e0 = next_event(n);
+    joined = next_event(n);
+    URSN_REQUIRE(e0 && joined, "bf16 forward: no event for the shortcut stream");
+    URSN_HIP(hipEventRecord(e0, s));
+    URSN_HIP(hipStreamWaitEvent(n->s2, e0, 0));
+    URSN_TRY(conv_stats(n, u.sc, u.in, N, n->s2, n->stats2));
+    URSN_HIP(hipEventRecord(joined, n->s2));
+  } else if (u.sc >= 0) {
+    URSN_TRY(conv_stats(n, u.sc, u.in, N, s));
+  }
   URSN_TRY(conv_stats(n, u.c1, u.in, N, s));
   if (u.a1.aff_layer < 0) URSN_TRY(bn_out(n, u.c1, u.a1, 0, N, -1, nullptr, s));
   URSN_TRY(conv_stats(n, u.c2, u.a1, N, s));
+  if (joined) URSN_HIP(hipStreamWaitEvent(s, joined, 0));
   if (u.sc >= 0) return bn_out(n, u.c2, u.out, 1, N, u.sc, nullptr, s, u.jmask);
   return bn_out(n, u.c2, u.out, 1, N, -1, &u.in, s, u.jmask);
 }
@@ -495,6 +529,7 @@ int forward(ursn_bnet* n, const float* data, int N, hipStream_t s) {
   const int ns = n->cfg.num_strides;
   // Weight packing: every (layer, pass) has its own packed buffer; from the second step at a batch size on, ONE launch here
   // fills them all and the launchers find their job done (bf16_pack.h).  URSN_BF16_PREPACK=0: every launcher packs for itself.
+  n->ev_used = 0;
   static const bool prepack = !(getenv("URSN_BF16_PREPACK") && getenv("URSN_BF16_PREPACK")[0] == '0');
   if (prepack && n->pack.d_jobs) {
     if (n->pack_N != N) { n->pack.clear(); n->pack_N = N; }
@@ -646,6 +681,7 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
     if (n->dec0_g && in.g == n->cat[n->cfg.num_strides - 1].g && !acc) {   // level-0 concat gradient: two 8-channel tensors
       g[0].out_cs = 8;
       n->split0_done = true;
+      if (n->skip0_merge) n->ginit[n->a_conv0.flag] = 1;   // the skip's share is in place: the encoder's data gradients accumulate
       return launch_b3conv(g[0], L.dz, n->params + L.w_off, Kw, Nw, L.wp[1], n->dec0_g, nullptr, 0, 0, s, S.dz, S.kout, n->params + S.w_off,
                            nullptr, nullptr, n->skip0_g, 8);
     }
@@ -747,7 +783,8 @@ int backward(ursn_bnet* n, int N, hipStream_t s) {
   const BAct& a0 = n->a_conv0;
   if (n->skip0_own) {   // d(conv0 activation) = the encoder's share (own tensor) + the skip's share (second half of the concat gradient)
     const BAct& cg = n->cat[ns - 1];
-    if (n->split0_done) URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s, n->skip0_g, 8));
+    if (n->split0_done && n->skip0_merge) URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
+    else if (n->split0_done) URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s, n->skip0_g, 8));
     else URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s, cg.g + cg.C / 2, cg.cs));
   } else {
     URSN_TRY(bn_back(n, n->conv0, a0.g, a0.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
@@ -927,7 +964,8 @@ int bnet_tensor(const ursn_bnet* n, const char* name, void** ptr, int64_t* voxel
     return 2;
   }
   if (want_g2) {
-    URSN_REQUIRE(s == "UResNet/conv0" && n->skip0_own && n->cfg.trainable, "tensor: %s has no second gradient tensor", s.c_str());
+    URSN_REQUIRE(s == "UResNet/conv0" && n->skip0_own && n->cfg.trainable && !(n->skip0_merge && n->split0_done),
+                 "tensor: %s has no second gradient tensor", s.c_str());
     const BAct& cg = n->cat[ns - 1];
     if (n->split0_done) { *ptr = n->skip0_g; *cstride = 8; }
     else { *ptr = cg.g + cg.C / 2; *cstride = cg.cs; }
