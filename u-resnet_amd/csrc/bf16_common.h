@@ -188,7 +188,11 @@ struct BHeadArgs {    // logits = bn(z); z, dlogits bf16 with channel stride 8
   float* softmax_out; bf16_t* dlogits; int dl_cs;
   float* ana_out;
   float* metrics; void* scratch;
+  // want dlogits: the BatchNorm-backward reductions of the logits layer, taken from the STORED (rounded) dlogits while they are
+  // in registers: [head blocks][3][8] doubles = sum g, sum g * xhat(z) (the layout launch_bbn_bwd's pre_partial reads), or null
+  double* bs_partial;
 };
+int bhead_blocks(int n, int64_t pix);   // rows of bs_partial
 int launch_bhead(const BHeadArgs& a, hipStream_t s);
 // data [V] fp32 (one input channel) -> [V][8] bf16, channels 1..7 zero
 int launch_bf16_input(const float* data, bf16_t* out, int64_t V, hipStream_t s);

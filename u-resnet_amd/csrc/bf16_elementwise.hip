@@ -318,6 +318,9 @@ __global__ __launch_bounds__(256) void bhead_kernel(BHeadArgs a, double* __restr
     sh[k] = k < a.ncls ? a.beta[k] - a.mean[k] * sc[k] : 0.f;
   }
   const float invn = 1.0f / (float)a.n;
+  float bg[8], bgx[8];   // per-thread sums of at most ~100 terms: fp32
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bg[k] = bgx[k] = 0.f;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
     float raw[8], z[8], e[8];
     unpack8(ld16(a.z + p * a.z_cs), raw);
@@ -360,7 +363,15 @@ __global__ __launch_bounds__(256) void bhead_kernel(BHeadArgs a, double* __restr
         float d[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) d[k] = k < a.ncls ? w * invn * (e[k] * inv - (k == labc ? 1.f : 0.f)) : 0.f;
-        *(u32x4*)(a.dlogits + p * a.dl_cs) = pack8(d);
+        const u32x4 pk = pack8(d);
+        *(u32x4*)(a.dlogits + p * a.dl_cs) = pk;
+        if (a.bs_partial) {
+          float dr[8];
+          unpack8(pk, dr);
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (k < a.ncls) { bg[k] += dr[k]; bgx[k] = fmaf(dr[k], (raw[k] - a.mean[k]) * sc[k], bgx[k]); }
+        }
       }
     }
   }
@@ -373,6 +384,29 @@ __global__ __launch_bounds__(256) void bhead_kernel(BHeadArgs a, double* __restr
     __syncthreads();
   }
   if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] = sm[threadIdx.x][0];
+  if (a.bs_partial) {   // uniform
+    __syncthreads();
+    double (*bm)[256] = sm;   // 16 columns in four rounds of four
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int col = 4 * r + k;
+        sm[k][threadIdx.x] = col < 8 ? (double)bg[col & 7] : (double)bgx[col & 7];
+      }
+      __syncthreads();
+      for (int st = 128; st >= 1; st >>= 1) {
+        if (threadIdx.x < st)
+          for (int k = 0; k < 4; ++k) bm[k][threadIdx.x] += bm[k][threadIdx.x + st];
+        __syncthreads();
+      }
+      if (threadIdx.x < 4) {
+        const int col = 4 * r + threadIdx.x;
+        a.bs_partial[(size_t)blockIdx.x * 24 + (col < 8 ? col : 8 + (col - 8))] = sm[threadIdx.x][0];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x < 8) a.bs_partial[(size_t)blockIdx.x * 24 + 16 + threadIdx.x] = 0.0;
+  }
 }
 
 __global__ void bf16_input_kernel(const float* __restrict__ data, bf16_t* __restrict__ out, int64_t V) {
@@ -469,6 +503,7 @@ int launch_bbn_bwd(const BBnBwdArgs& a, hipStream_t s) {
   return 0;
 }
 
+int bhead_blocks(int n, int64_t pix) { return head_blocks(n, pix); }
 int launch_bhead(const BHeadArgs& a, hipStream_t s) {
   URSN_REQUIRE(a.ncls >= 1 && a.ncls <= 8 && a.z_cs == 8 && (!a.dlogits || a.dl_cs == 8), "bf16 head: needs <= 8 classes in 8-channel pieces");
   const int nb = head_blocks(a.n, a.pix);

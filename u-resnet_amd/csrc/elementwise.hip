@@ -517,6 +517,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a, double* __restric
     }
   }
   const float invn = 1.0f / (float)a.n;
+  float bg[4] = {0.f, 0.f, 0.f, 0.f}, bgx[4] = {0.f, 0.f, 0.f, 0.f};   // per-thread sums of a few hundred terms at most
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
     float z[URSN_MAX_CLASS];
     float m = -INFINITY;
@@ -572,6 +573,11 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a, double* __restric
           for (int k = 0; k < 4; ++k)
             if (k < a.ncls) dv[k] = w * invn * (e[k] * inv - (k == labc ? 1.f : 0.f));
           *(f32x4*)(a.dlogits + p * 4) = dv;
+          if (a.bs_partial) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (k < a.ncls) { bg[k] += dv[k]; bgx[k] = fmaf(dv[k], (zv[k] - a.mean[k]) * sc[k], bgx[k]); }
+          }
         } else {
 #pragma unroll
           for (int k = 0; k < URSN_MAX_CLASS; ++k)
@@ -592,6 +598,21 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a, double* __restric
     __syncthreads();
   }
   if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] = sm[threadIdx.x][0];
+  if (a.bs_partial) {   // uniform: two more rounds of the same tree for sum g, sum g xhat
+    for (int r = 0; r < 2; ++r) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sm[k][threadIdx.x] = (double)(r == 0 ? bg[k] : bgx[k]);
+      __syncthreads();
+      for (int st = 128; st >= 1; st >>= 1) {
+        if (threadIdx.x < st)
+          for (int k = 0; k < 4; ++k) sm[k][threadIdx.x] += sm[k][threadIdx.x + st];
+        __syncthreads();
+      }
+      if (threadIdx.x < 4) a.bs_partial[(size_t)blockIdx.x * 12 + 4 * r + threadIdx.x] = sm[threadIdx.x][0];
+    }
+    if (threadIdx.x < 4) a.bs_partial[(size_t)blockIdx.x * 12 + 8 + threadIdx.x] = 0.0;
+  }
 }
 
 __global__ __launch_bounds__(256) void head_final_kernel(const double* __restrict__ partial, int nblocks, int n, int64_t pix,

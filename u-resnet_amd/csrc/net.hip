@@ -90,6 +90,7 @@ struct ursn_net {
   // BatchNorm-backward reductions taken in the epilogue of the data-gradient kernel that finished a layer's output gradient
   double* bs_scratch = nullptr;
   int bs_layer = -1, bs_blocks = 0;   // layer whose (first) reductions are waiting in bs_scratch
+  int bs_C = 8;                       // ... and their channel count (8; the logits layer's, from the head: 4)
   // BatchNorm-backward apply on load: bn_back left this layer's dz to its data-gradient kernel (coefficients in Layer::coef)
   int vdz_layer = -1, vdz_relu = 0, vdz_cs = 0;
   const float* vdz_g = nullptr;
@@ -602,6 +603,13 @@ int head(ursn_net* n, const float* data, const float* label, const float* weight
   a.dl_cs = L.zcs;
   a.ana_out = ana_out;
   a.scratch = n->head_scratch; a.metrics = n->metrics;
+  // the logits layer's BatchNorm-backward sums ride in the head (dlogits and z are in its registers): one pass of two tensors less
+  static const bool fuse = !(getenv("URSN_HEAD_BN_BWD") && getenv("URSN_HEAD_BN_BWD")[0] == '0');
+  n->bs_layer = -1;
+  if (want_grad && fuse && n->bs_scratch && L.zcs == 4 && a.ncls <= 4 && head_blocks(N, n->lvox[0]) <= 16384) {
+    a.bs_partial = n->bs_scratch;
+    n->bs_layer = n->conv2; n->bs_blocks = head_blocks(N, n->lvox[0]); n->bs_C = 4;
+  }
   ProfScope ps(n, s, n->conv2, 6, 0.0, 4.0 * N * n->lvox[0] * (2.0 * a.ncls + 3));
   URSN_TRY(launch_head(a, s));
   ps.done("head");
@@ -767,8 +775,9 @@ int bn_back(ursn_net* n, int li, const float* dy, int dycs, const float* y, int 
   a.dres = dres; a.drescs = drescs; a.dres_accumulate = dres_acc;
   a.V = (int64_t)N * n->lvox[L.lout]; a.C = L.cout; a.relu = relu; a.scratch = n->red_scratch;
   if (L.zcs != L.cout && li2 < 0 && !relu && dycs == L.zcs && !dres) { a.C = L.zcs; a.Cw = L.cout; }   // logits layer: float4 path
-  if (n->bs_layer == li && a.C == 8) { a.pre_partial = n->bs_scratch; a.pre_nblocks = n->bs_blocks; }
+  if (n->bs_layer == li && a.C == n->bs_C) { a.pre_partial = n->bs_scratch; a.pre_nblocks = n->bs_blocks; }
   n->bs_layer = -1;
+  n->bs_C = 8;
   n->vdz_layer = -1;
   if (fuse_in && li2 < 0 && !dres && !mask && !y && dycs == L.zcs && vdz_ok(n, li, *fuse_in, N, fuse_two_z)) {
     a.coef_out = L.coef;

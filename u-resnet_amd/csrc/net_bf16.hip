@@ -583,6 +583,13 @@ int head(ursn_bnet* n, const float* data, const float* label, const float* weigh
   a.data = data; a.data_cs = 1; a.label = label; a.weight = weight; a.n = N; a.pix = n->lvox[0]; a.ncls = n->cfg.num_class;
   a.softmax_out = softmax_out; a.dlogits = want_grad ? n->dlog : nullptr; a.dl_cs = 8; a.ana_out = ana_out;
   a.metrics = n->metrics; a.scratch = n->head_scratch;
+  // the logits layer's BatchNorm-backward sums ride in the head (dlogits and z are in its registers): one pass of two tensors less
+  static const bool fuse = !(getenv("URSN_BF16_HEAD_BN_BWD") && getenv("URSN_BF16_HEAD_BN_BWD")[0] == '0');
+  n->bs_layer = -1;
+  if (want_grad && fuse && n->bs_scratch && L.kout == 8 && bhead_blocks(N, n->lvox[0]) <= 16384) {
+    a.bs_partial = n->bs_scratch;
+    n->bs_layer = n->conv2; n->bs_blocks = bhead_blocks(N, n->lvox[0]);
+  }
   BProf ps(n, s, n->conv2, 6, 0.0, (double)N * n->lvox[0] * (16.0 + 12.0 + (want_grad ? 16.0 : 0.0)), "bhead");
   return launch_bhead(a, s);
 }

@@ -267,6 +267,9 @@ struct HeadArgs {
   double* partial;                     // [nblocks][4]
   float* metrics;                      // device [3 + 1]
   void* scratch;
+  // with dlogits in the 4-padded layout (dl_cs = z_cs = 4, <= 4 classes): the BatchNorm-backward reductions of the logits layer,
+  // [head_blocks][3][4] doubles = sum g, sum g * xhat(z) (BnBwdArgs.pre_partial), or null
+  double* bs_partial;
 };
 size_t head_scratch_bytes(int n, int64_t pix);
 int head_blocks(int n, int64_t pix);
