@@ -84,13 +84,17 @@ struct B3BnRed {
 // normalise-on-load (forward C -> C and the weight gradient): `in` / `S` is the raw z of the preceding conv, its BatchNorm
 // (+ ReLU) is applied while planes are staged
 struct B3Affine { const float* mean; const float* rstd; const float* beta; int relu; };
+// data gradient of resnet_conv1 behind an identity shortcut: + g (gradient of the unit's output, channel stride cs) where the join's
+// relu mask byte says so -- the residual branch's share of d(input)
+struct B3Residual { const bf16_t* g; int cs; const unsigned char* mask; };
 bool b3conv_aff_ok(const GatherGeom& g);
 bool b3conv_bs_ok(const GatherGeom& g);
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                   double* stats_partial, int stats_off, int stats_total, hipStream_t s, const bf16_t* pw = nullptr,
                   int pw_cs = 0, const float* pw_w = nullptr, const B3BnRed* bs = nullptr, const B3Affine* aff = nullptr,
                   bf16_t* out2 = nullptr, int out2_cs = 0,    // out2: produced channels 8..15 of a 16-channel result
-                  const float* in_f32 = nullptr);             // in_f32 (K = 8): the input is one fp32 channel per voxel (`in` unused)
+                  const float* in_f32 = nullptr,              // in_f32 (K = 8): the input is one fp32 channel per voxel (`in` unused)
+                  const B3Residual* res = nullptr);           // out = conv + res->g * relu mask (plain C -> C data gradients)
 // 3x3x3 stride-1 layers with 16 / 32 contraction channels (levels 1 / 2 of an F = 8 network): z-marching channel-block kernel,
 // weights resident in LDS (bf16_convcb.hip); launch_bconv and the bconv_* helpers dispatch
 bool bcbconv_ok(const GatherGeom& g);

@@ -67,6 +67,11 @@ struct B3Args {
   // CI = 8 only: the input is ONE fp32 channel per voxel (the network's data tensor, lib/uresnet.py:31-36); staged as
   // (bf16(value), 0 x 7) -- no 8-channel bf16 copy of the input exists
   const float* in_f32;
+  // accumulate with res != null (data gradient of a unit's resnet_conv1 behind an IDENTITY shortcut, lib/resnet_module.py:52-66):
+  // out = conv + res * mask instead of out += conv -- res = the gradient of the unit's output, mask = the join's relu mask bytes
+  // (bit j of byte [voxel * CO / 8 + cb] = channel 8 cb + j), i.e. the residual branch's share of d(input), which the join's
+  // BatchNorm backward then does not have to write
+  const bf16_t* res; int res_cs; const unsigned char* res_mask;
 };
 
 // DMA: the planes travel global -> LDS by LDS-DMA (global_load_lds, no staging registers) into a ring of FOUR slots, three
@@ -247,15 +252,27 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
   auto out_rsrc = [&](int q) { return ursn_rsrc(a.out + ((size_t)n * a.Z + q) * plane_vox * a.out_cs, out_plane_bytes); };
   auto out2_rsrc = [&](int q) { return ursn_rsrc(a.out2 + ((size_t)n * a.Z + q) * plane_vox * a.out2_cs, out2_plane_bytes); };
   u32x2 oldv[RPW][NCH];
+  unsigned oldm[RPW][NCH];
+  const unsigned res_plane_bytes = a.res ? (unsigned)plane_vox * a.res_cs * 2u : 0u;
+  auto res_rsrc = [&](int q) { return ursn_rsrc(a.res + ((size_t)n * a.Z + q) * plane_vox * a.res_cs, res_plane_bytes); };
+  auto resm_rsrc = [&](int q) { return ursn_rsrc(a.res_mask + ((size_t)n * a.Z + q) * plane_vox * NCH, (unsigned)plane_vox * NCH); };
+  // the value a lane adds to its four produced channels: the tensor's old value, or the masked residual gradient
+  auto old_fetch = [&](const __amdgpu_buffer_rsrc_t& ro, const __amdgpu_buffer_rsrc_t& rres, const __amdgpu_buffer_rsrc_t& rmask, int q,
+                       int nt, int cb, u32x2& v, unsigned& m) {
+    m = 0xffu;
+    if (a.res) {
+      v = ursn_bload_b64(rres, vrow[nt] * (unsigned)(a.res_cs * 2) + h * 8 + 16 * cb);
+      m = ursn_bload_u8(rmask, vrow[nt] * (unsigned)NCH + cb);
+    } else if (CO == 16 && cb == 1 && a.out2) v = ursn_bload_b64(out2_rsrc(q), vrow[nt] * (unsigned)(a.out2_cs * 2) + h * 8);
+    else v = ursn_bload_b64(ro, vrow[nt] * (unsigned)(a.out_cs * 2) + h * 8 + 16 * cb);
+  };
   auto old_load = [&](int q) {
     const __amdgpu_buffer_rsrc_t ro = out_rsrc(q);
+    const __amdgpu_buffer_rsrc_t rres = a.res ? res_rsrc(q) : ro, rmask = a.res ? resm_rsrc(q) : ro;
 #pragma unroll
     for (int nt = 0; nt < RPW; ++nt) {
 #pragma unroll
-      for (int cb = 0; cb < NCH; ++cb) {
-        if (CO == 16 && cb == 1 && a.out2) oldv[nt][cb] = ursn_bload_b64(out2_rsrc(q), vrow[nt] * (unsigned)(a.out2_cs * 2) + h * 8);
-        else oldv[nt][cb] = ursn_bload_b64(ro, vrow[nt] * (unsigned)(a.out_cs * 2) + h * 8 + 16 * cb);
-      }
+      for (int cb = 0; cb < NCH; ++cb) old_fetch(ro, rres, rmask, q, nt, cb, oldv[nt][cb], oldm[nt][cb]);
     }
   };
   auto plane_step = [&](int p, int slot) {
@@ -330,9 +347,12 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
             const unsigned oo = second ? vrow[nt] * (unsigned)(a.out2_cs * 2) + h * 8 : vrow[nt] * (unsigned)(a.out_cs * 2) + h * 8 + 16 * cb;
             if (a.accumulate) {
               u32x2 e;
-              if constexpr (DMA) e = oldv[nt][cb]; else e = ursn_bload_b64(rr, oo);
-              v[0] += __uint_as_float(e[0] << 16); v[1] += __uint_as_float(e[0] & 0xffff0000u);
-              v[2] += __uint_as_float(e[1] << 16); v[3] += __uint_as_float(e[1] & 0xffff0000u);
+              unsigned mk;
+              if constexpr (DMA) { e = oldv[nt][cb]; mk = oldm[nt][cb]; }
+              else old_fetch(ro, a.res ? res_rsrc(q) : ro, a.res ? resm_rsrc(q) : ro, q, nt, cb, e, mk);
+              mk >>= 4 * h;   // this lane's four channels
+              v[0] += (mk & 1u) ? __uint_as_float(e[0] << 16) : 0.f; v[1] += (mk & 2u) ? __uint_as_float(e[0] & 0xffff0000u) : 0.f;
+              v[2] += (mk & 4u) ? __uint_as_float(e[1] << 16) : 0.f; v[3] += (mk & 8u) ? __uint_as_float(e[1] & 0xffff0000u) : 0.f;
             }
             u32x2 pk;
             pk[0] = pack_bf2(v[0], v[1]);
@@ -549,7 +569,8 @@ bool b3conv_bs_ok(const GatherGeom& g) {
 
 int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out,
                   double* stats_partial, int stats_off, int stats_total, hipStream_t s, const bf16_t* pw, int pw_cs,
-                  const float* pw_w, const B3BnRed* bs, const B3Affine* aff, bf16_t* out2, int out2_cs, const float* in_f32) {
+                  const float* pw_w, const B3BnRed* bs, const B3Affine* aff, bf16_t* out2, int out2_cs, const float* in_f32,
+                  const B3Residual* res) {
   URSN_REQUIRE(b3conv_ok(g), "bf16 3x3x3 conv: unsupported geometry");
   URSN_REQUIRE(!pw || (b3conv_pw_ok(g) && pw_w && !stats_partial && (pw_cs & 7) == 0), "bf16 3x3x3 conv: the fused shortcut term needs the 8 -> 16 data gradient");
   URSN_REQUIRE((!pw || ursn_bf16_plane_ok(g, pw_cs)) && (!out2 || ursn_bf16_plane_ok(g, out2_cs)) &&
@@ -581,6 +602,13 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
   URSN_REQUIRE(!in_f32 || (g.K == 8 && !pw && !bs && !aff), "bf16 3x3x3 conv: the scalar fp32 input form needs the 8-channel forward kernel");
   a.in_f32 = in_f32;
   if (in_f32) a.in_cs = 1;
+  a.res = nullptr; a.res_cs = 0; a.res_mask = nullptr;
+  if (res) {
+    URSN_REQUIRE(g.K == g.Nn && !pw && !bs && !aff && !stats_partial && !out2 && !in_f32 && res->g && res->mask && (res->cs & 3) == 0 &&
+                 ursn_bf16_plane_ok(g, res->cs), "bf16 3x3x3 conv: the residual term belongs to a plain C -> C data gradient");
+    a.res = res->g; a.res_cs = res->cs; a.res_mask = res->mask;
+    a.accumulate = 1;
+  }
   if (aff) {
     URSN_REQUIRE(b3conv_aff_ok(g) && !pw && !bs && aff->mean && aff->rstd && aff->beta, "bf16 3x3x3 conv: normalise-on-load needs a C -> C forward shape");
     a.aff_mean = aff->mean; a.aff_rstd = aff->rstd; a.aff_beta = aff->beta; a.aff_relu = aff->relu;
@@ -626,7 +654,7 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
   // ... unless it accumulates: on the register path the old values are read inside the epilogue (0.85 ms); the DMA path requests
   // them a whole iteration ahead
   static const bool acc_dma = !(getenv("URSN_B3CONV_ACC_DMA") && getenv("URSN_B3CONV_ACC_DMA")[0] == '0');
-  const bool pf2 = !dma_off && !in_f32 && (!(g.K == 8 && g.Nn == 8 && !stats_partial) || (acc_dma && g.accumulate));
+  const bool pf2 = !dma_off && !in_f32 && (!(g.K == 8 && g.Nn == 8 && !stats_partial) || (acc_dma && (g.accumulate || res)));
 #define B3GO(ci, co, label)                                                                                              \
   if (g.K == ci && g.Nn == co) {                                                                                          \
     URSN_TRY(pack(ci, co, B3<ci, co>::WPACK, B3<ci, co>::MT));          \

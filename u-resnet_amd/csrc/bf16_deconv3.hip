@@ -108,12 +108,33 @@ __global__ __launch_bounds__(256, 2) void bdeconv_kernel(D3Args a) {
   stage_load(pz0 + 1);
   stage_store((pz0 + 4) % 3);
   __syncthreads();
+  // accumulate: the old values of a row are requested one row ahead of their use (read inside the epilogue -- a load behind every
+  // store of the previous class -- the data gradient of the stride-2 conv took 0.58 ms instead of 0.26 + the 0.18 of the extra read)
+  u32x2 exn[8];
+  auto old_addr = [&](int qz_, int rr_, int cl) {
+    const int pz = cl >> 2, py = (cl >> 1) & 1, px = cl & 1;
+    const int gy = y0 + D3_RPW * wave + rr_, gx = x0 + c;
+    return (u32x2*)(a.out + ((((size_t)n * (2 * a.Zc) + 2 * qz_ + pz) * (2 * a.Yc) + 2 * gy + py) * (size_t)(2 * a.Xc) + 2 * gx + px) * a.out_cs + h * 4);
+  };
+  auto old_load = [&](int qz_, int rr_) {
+    const int gy = y0 + D3_RPW * wave + rr_, gx = x0 + c;
+#pragma unroll
+    for (int cl = 0; cl < 8; ++cl) exn[cl] = (gy < a.Yc && gx < a.Xc) ? *old_addr(qz_, rr_, cl) : (u32x2){0u, 0u};
+  };
+  if (a.accumulate) old_load(z0, 0);
   for (int qz = z0; qz < z1; ++qz) {
     const int pl = qz + a.dmin[0];
     if (qz + 1 < z1) stage_load(pl + 2);
     const unsigned sb0 = (unsigned)(((pl + 3) % 3) * D3_PLANE), sb1 = (unsigned)(((pl + 4) % 3) * D3_PLANE);
 #pragma unroll
     for (int rr = 0; rr < D3_RPW; ++rr) {
+      u32x2 exo[8];
+#pragma unroll
+      for (int cl = 0; cl < 8; ++cl) exo[cl] = exn[cl];
+      if (a.accumulate) {
+        if (rr + 1 < D3_RPW) old_load(qz, rr + 1);
+        else if (qz + 1 < z1) old_load(qz + 1, 0);
+      }
       d3_f32x16 cc[2];
 #pragma unroll
       for (int i = 0; i < 16; ++i) cc[0][i] = cc[1][i] = 0.f;
@@ -133,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void bdeconv_kernel(D3Args a) {
           for (int i = 0; i < 4; ++i) v[i] = cc[cl >> 2][(cl & 3) * 4 + i];
           u32x2* o = (u32x2*)(a.out + ((((size_t)n * (2 * a.Zc) + 2 * qz + pz) * (2 * a.Yc) + 2 * gy + py) * (size_t)(2 * a.Xc) + 2 * gx + px) * a.out_cs + h * 4);
           if (a.accumulate) {
-            const u32x2 ex = *o;
+            const u32x2 ex = exo[cl];
             v[0] += __uint_as_float(ex[0] << 16); v[1] += __uint_as_float(ex[0] & 0xffff0000u);
             v[2] += __uint_as_float(ex[1] << 16); v[3] += __uint_as_float(ex[1] & 0xffff0000u);
           }

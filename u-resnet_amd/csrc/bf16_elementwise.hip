@@ -318,9 +318,9 @@ __global__ __launch_bounds__(256) void bhead_kernel(BHeadArgs a, double* __restr
     sh[k] = k < a.ncls ? a.beta[k] - a.mean[k] * sc[k] : 0.f;
   }
   const float invn = 1.0f / (float)a.n;
-  float bg[8], bgx[8];   // per-thread sums of at most ~100 terms: fp32
+  float bg[8], bgx[8], mu[8];   // per-thread sums of at most ~100 terms: fp32
 #pragma unroll
-  for (int k = 0; k < 8; ++k) bg[k] = bgx[k] = 0.f;
+  for (int k = 0; k < 8; ++k) { bg[k] = bgx[k] = 0.f; mu[k] = k < a.ncls ? a.mean[k] : 0.f; }
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
     float raw[8], z[8], e[8];
     unpack8(ld16(a.z + p * a.z_cs), raw);
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void bhead_kernel(BHeadArgs a, double* __restr
           unpack8(pk, dr);
 #pragma unroll
           for (int k = 0; k < 8; ++k)
-            if (k < a.ncls) { bg[k] += dr[k]; bgx[k] = fmaf(dr[k], (raw[k] - a.mean[k]) * sc[k], bgx[k]); }
+            if (k < a.ncls) { bg[k] += dr[k]; bgx[k] = fmaf(dr[k], (raw[k] - mu[k]) * sc[k], bgx[k]); }
         }
       }
     }

@@ -518,6 +518,9 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a, double* __restric
   }
   const float invn = 1.0f / (float)a.n;
   float bg[4] = {0.f, 0.f, 0.f, 0.f}, bgx[4] = {0.f, 0.f, 0.f, 0.f};   // per-thread sums of a few hundred terms at most
+  float mu[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) mu[k] = (k < a.ncls && a.mean) ? a.mean[k] : 0.f;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
     float z[URSN_MAX_CLASS];
     float m = -INFINITY;
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs a, double* __restric
           if (a.bs_partial) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              if (k < a.ncls) { bg[k] += dv[k]; bgx[k] = fmaf(dv[k], (zv[k] - a.mean[k]) * sc[k], bgx[k]); }
+              if (k < a.ncls) { bg[k] += dv[k]; bgx[k] = fmaf(dv[k], (zv[k] - mu[k]) * sc[k], bgx[k]); }
           }
         } else {
 #pragma unroll

@@ -610,7 +610,7 @@ struct BBsTarget {
 
 // fused_sc >= 0: the data gradient also carries the term of that (1x1, stride-1) shortcut layer
 int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipStream_t s, int fused_sc = -1,
-             const BBsTarget* bs = nullptr) {
+             const BBsTarget* bs = nullptr, const B3Residual* res = nullptr) {
   BLayer& L = n->layers[li];
   GatherGeom g[8];
   int Kw, Nw;
@@ -655,6 +655,12 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
   for (int i = 0; i < cnt; ++i) empty = empty || g[i].ntaps == 0;
   URSN_REQUIRE(!empty || acc, "bf16 backward: %s would leave voxels of its input gradient unwritten", L.name.c_str());
   n->bs_layer = -1;
+  if (res) {   // identity unit: the residual branch's share rides in this launch (unit_bwd checked the shape)
+    URSN_REQUIRE(cnt == 1 && !acc && fused_sc < 0 && b3conv_ok(g[0]) && g[0].K == g[0].Nn, "bf16 backward: %s cannot carry the residual term", L.name.c_str());
+    g[0].accumulate = 0;
+    return launch_b3conv(g[0], L.dz, n->params + L.w_off, Kw, Nw, L.wp[1], in.g, nullptr, 0, 0, s, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                         nullptr, res);
+  }
   if (bs && bs->li >= 0 && bs->mode != 1 && fused_sc < 0 && cnt == 1 && b3conv_bs_ok(g[0]) && in.C == 8 && in.cs == 8) {
     const BLayer& T = n->layers[bs->li];
     const int blocks = bconv_grid_blocks(g[0]);
@@ -730,11 +736,26 @@ int bn_back(ursn_bnet* n, int li, const bf16_t* dy, int dycs, const bf16_t* y, i
 }
 
 int unit_bwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s, const BBsTarget* in_target = nullptr) {
+  bool res_in_dgrad = false;
   if (u.sc >= 0) {
     URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, u.sc, nullptr, 0, 0, N, s, nullptr, 0, u.jmask));
   } else {
-    const bool acc = take_flag(n, u.in);
-    URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, -1, u.in.g, u.in.cs, acc ? 1 : 0, N, s, nullptr, 0, u.jmask));
+    // identity shortcut: d(in) = conv1's data gradient + g(out) * relu mask.  Where conv1's data gradient runs on the
+    // input-stationary kernel and nothing has been written to d(in) yet, that kernel adds the second term itself (it reads g(out)
+    // and the mask bytes instead of old values) and the join's BatchNorm backward writes one tensor less
+    // (URSN_BF16_RESIDUAL_IN_DGRAD=0: written here, accumulated there)
+    static const bool fuse_res = !(getenv("URSN_BF16_RESIDUAL_IN_DGRAD") && getenv("URSN_BF16_RESIDUAL_IN_DGRAD")[0] == '0');
+    GatherGeom gg[8];
+    const BLayer& C1 = n->layers[u.c1];
+    const int gc = layer_geoms(n, C1, PASS_DGRAD, N, u.in.cs, C1.kout, gg);
+    res_in_dgrad = fuse_res && u.jmask && !n->ginit[u.in.flag] && gc == 1 && b3conv_ok(gg[0]) && gg[0].K == gg[0].Nn &&
+                   (in_target == nullptr || !b3conv_bs_ok(gg[0])) && ursn_bf16_plane_ok(gg[0], u.out.cs);
+    if (res_in_dgrad) {
+      URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, -1, nullptr, 0, 0, N, s, nullptr, 0, u.jmask));
+    } else {
+      const bool acc = take_flag(n, u.in);
+      URSN_TRY(bn_back(n, u.c2, u.out.g, u.out.cs, u.out.p, u.out.cs, 1, -1, u.in.g, u.in.cs, acc ? 1 : 0, N, s, nullptr, 0, u.jmask));
+    }
   }
   BBsTarget t1;   // conv2's data gradient IS d(a1): resnet_conv1's BatchNorm (no activation) consumes it
   t1.li = u.c1;
@@ -750,6 +771,11 @@ int unit_bwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s, const BBsTarget* in_t
     fuse = fuse || (one && !b3conv_ok(g[0]) && bcbconv_pw_ok(g[0]) && S.kout == g[0].K && S.cout == S.kout && S.kin == g[0].Nn && S.cin == S.kin);
   }
   // with an identity shortcut conv1's data gradient is the last contribution to d(in): its consumer's reductions ride along
+  if (res_in_dgrad) {
+    const B3Residual rs = {u.out.g, u.out.cs, u.jmask};
+    URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, -1, nullptr, &rs));
+    return 0;
+  }
   URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, fuse ? u.sc : -1, u.sc < 0 ? in_target : nullptr));   // k3 (s1 | s2): writes every voxel of d(in)
   if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, !fuse, N, s));      // 1x1 (s1 | s2): weight gradient (+ accumulated data gradient)
   return 0;
