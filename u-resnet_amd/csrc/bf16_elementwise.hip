@@ -170,6 +170,46 @@ __global__ __launch_bounds__(256) void bbn_act_kernel(BBnActArgs a, int shift) {
   }
 }
 
+// concat form (the level-0 skip, lib/uresnet.py:80-83): y[v] = [act(bn(z[v])) | act(bn2(z2[v]))], 16 channels per voxel.  Lane pairs
+// own a voxel -- the even lane the first piece from z, the odd lane the second from z2 -- so that one store instruction writes
+// whole 32-byte voxels back to back (with one thread per voxel each of its two 16-byte stores left 16-byte holes: 4.8 TB/s)
+__global__ __launch_bounds__(256) void bbn_cat_kernel(BBnActArgs a) {
+  const int pc = threadIdx.x & 1, vr = threadIdx.x >> 1;
+  constexpr int U = URSN_BEW_U, VPB = 128;
+  const int64_t chunkv = (int64_t)VPB * U, nchunks = (a.V + chunkv - 1) / chunkv;
+  const bf16_t* src = pc ? a.z2 : a.z;
+  const int scs = pc ? a.z2cs : a.zcs;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = pc ? a.rstd2[j] : a.rstd[j];
+    sh[j] = pc ? a.beta2[j] - a.mean2[j] * sc[j] : a.beta[j] - a.mean[j] * sc[j];
+  }
+  const bool relu = a.relu != 0;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t vb = ch * chunkv + vr;
+    u32x4 x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = vb + (int64_t)u * VPB;
+      if (v < a.V) x[u] = ld16(src + v * scs);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = vb + (int64_t)u * VPB;
+      if (v >= a.V) continue;
+      float f[8], y[8];
+      unpack8(x[u], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = fmaf(f[j], sc[j], sh[j]);
+        y[j] = relu ? fmaxf(t, 0.f) : t;
+      }
+      st16(a.y + v * a.ycs + 8 * pc, pack8(y));
+    }
+  }
+}
+
 // ---- BN backward ----------------------------------------------------------------------------------------------------
 // MASK: 0 no activation, 1 mask = y > 0 (y given), 2 mask = bn(z) > 0 (beta given), 3 mask bytes of the forward pass.
 // Per-thread sums in fp32: a thread adds <= ~1e3 terms of bf16-rounded data (relative error ~1e-6 of its own partial sum);
@@ -321,9 +361,11 @@ __global__ __launch_bounds__(256) void bhead_kernel(BHeadArgs a, double* __restr
   float bg[8], bgx[8], mu[8];   // per-thread sums of at most ~100 terms: fp32
 #pragma unroll
   for (int k = 0; k < 8; ++k) { bg[k] = bgx[k] = 0.f; mu[k] = k < a.ncls ? a.mean[k] : 0.f; }
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+  // two voxels per iteration, every load of both issued before the first use (one voxel in flight per thread left the kernel at
+  // 4.3 TB/s: 28 bytes per lane against the ~60 KB per CU that bandwidth x latency asks for)
+  auto voxel = [&](int64_t p, const u32x4 zq, const float labf, const float wf, const float df) {
     float raw[8], z[8], e[8];
-    unpack8(ld16(a.z + p * a.z_cs), raw);
+    unpack8(zq, raw);
     float m = -INFINITY;
     int arg = 0;
 #pragma unroll
@@ -344,20 +386,20 @@ __global__ __launch_bounds__(256) void bhead_kernel(BHeadArgs a, double* __restr
     if (a.ana_out) {   // lib/ssnet_trainval.py:285-287
       const float shower = e[1] * inv, track = e[2] * inv;
       const float lab = (shower > track ? 1.f : 0.f) + (track >= shower ? 2.f : 0.f);
-      a.ana_out[p] = (a.data && a.data[p * a.data_cs] > 1.0f) ? lab : 0.f;
+      a.ana_out[p] = (a.data && df > 1.0f) ? lab : 0.f;
     }
     if (a.label) {
-      const int lab = (int)a.label[p];
+      const int lab = (int)labf;
       const bool lab_ok = lab >= 0 && lab < a.ncls;
       const int labc = lab_ok ? lab : 0;
-      const float w = a.weight ? a.weight[p] : 1.0f;
+      const float w = wf;
       float zl = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         if (k == labc) zl = z[k];
       const float ce = (m + logf(ssum)) - zl;
       loss += lab_ok ? (double)(w * ce) : (double)NAN;
-      const bool okp = (arg == lab), nz = a.data ? (a.data[p * a.data_cs] > 0.f) : false;
+      const bool okp = (arg == lab), nz = a.data ? (df > 0.f) : false;
       n_ok += okp; n_nz += nz; n_ok_nz += (okp && nz);
       if (a.dlogits) {
         float d[8];
@@ -374,6 +416,20 @@ __global__ __launch_bounds__(256) void bhead_kernel(BHeadArgs a, double* __restr
         }
       }
     }
+  };
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += 2 * stride) {
+    const int64_t p1 = p + stride;
+    const bool two = p1 < P;
+    const u32x4 z0 = ld16(a.z + p * a.z_cs);
+    u32x4 z1 = z0;
+    if (two) z1 = ld16(a.z + p1 * a.z_cs);
+    float l0 = 0.f, l1 = 0.f, w0 = 1.f, w1 = 1.f, d0 = 0.f, d1 = 0.f;
+    if (a.label) { l0 = a.label[p]; if (two) l1 = a.label[p1]; }
+    if (a.weight) { w0 = a.weight[p]; if (two) w1 = a.weight[p1]; }
+    if (a.data) { d0 = a.data[p * a.data_cs]; if (two) d1 = a.data[p1 * a.data_cs]; }
+    voxel(p, z0, l0, w0, d0);
+    if (two) voxel(p1, z1, l1, w1, d1);
   }
   __shared__ double sm[4][256];
   sm[0][threadIdx.x] = loss; sm[1][threadIdx.x] = (double)n_ok; sm[2][threadIdx.x] = (double)n_nz; sm[3][threadIdx.x] = (double)n_ok_nz;
@@ -455,7 +511,9 @@ int launch_bbn_act(const BBnActArgs& a, hipStream_t s) {
                        else if (a.res) BACT(c8, false, true); else BACT(c8, false, false); } while (0)
   if (a.cat) {
     URSN_REQUIRE(a.C == 8 && a.z2 && !a.res && a.ycs >= 16, "bf16 bn_act: the concat form needs two 8-channel inputs and a 16-channel output voxel");
-    hipLaunchKernelGGL((bbn_act_kernel<true, true, false, true>), dim3(grid), dim3(256), 0, s, a, m.shift);
+    static const bool pairs = !(getenv("URSN_BBN_CAT_PAIRS") && getenv("URSN_BBN_CAT_PAIRS")[0] == '0');
+    if (pairs) hipLaunchKernelGGL(bbn_cat_kernel, dim3(bew_grid(a.V, 1, acap)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((bbn_act_kernel<true, true, false, true>), dim3(grid), dim3(256), 0, s, a, m.shift);
   } else if (a.C == 8) BACT2(true); else BACT2(false);
 #undef BACT2
 #undef BACT
