@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void bhead_kernel(BHeadArgs a, double* __restr
     float ssum = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (k < a.ncls) { e[k] = expf(z[k] - m); ssum += e[k]; }
+      if (k < a.ncls) { e[k] = __expf(z[k] - m); ssum += e[k]; }
     const float inv = 1.0f / ssum;
     if (a.softmax_out)
 #pragma unroll
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void bhead_kernel(BHeadArgs a, double* __restr
 #pragma unroll
       for (int k = 0; k < 8; ++k)
         if (k == labc) zl = z[k];
-      const float ce = (m + logf(ssum)) - zl;
+      const float ce = (m + __logf(ssum)) - zl;
       loss += lab_ok ? (double)(w * ce) : (double)NAN;
       const bool okp = (arg == lab), nz = a.data ? (df > 0.f) : false;
       n_ok += okp; n_nz += nz; n_ok_nz += (okp && nz);
