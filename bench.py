@@ -399,7 +399,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the per-launch figure
     # comes from the committed rocprofv3 --pmc passes of this same command (profiles/pmc_traffic.json), else null
     pmc = {}
-    pmc_file = {"cfg3_3d192_f8_b4": "pmc_traffic.json", "cfg5_3d256_f8_b4_bf16": "r03_pmc_traffic_cfg5_bf16.json"}.get(args.workload)
+    pmc_file = {"cfg3_3d192_f8_b4": "pmc_traffic.json", "cfg5_3d256_f8_b4_bf16": "r04_pmc_traffic_cfg5_bf16.json"}.get(args.workload)
     try:
         if pmc_file:
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:

@@ -35,7 +35,10 @@ if BF16:
              (r"bcbconv_kernel<16, false>", "bcbconv_bf16<16>(dgrad)"), (r"b3conv_kernel<16, 16, false, false, 0, false", "b3conv_bf16<16,16>(dgrad)"),
              (r"bdconv_kernel<2, 8", "bdconv_bf16<2,8>"), (r"bdconv_kernel<4, 8", "bdconv_bf16<4,8>"), (r"bdconv_kernel<2, 4", "bdconv_bf16<2,4>+splitk"),
              (r"bbn_bwd_apply_kernel<true, 0, false, false", "bbn_bwd_apply(C8)"), (r"bbn_bwd_reduce_kernel<true, 0, false", "bbn_bwd_reduce(C8)"),
-             (r"bbn_act_kernel<true, false, false, false", "bbn_act(C8)")]
+             (r"bbn_act_kernel<true, false, false, false", "bbn_act(C8)"),
+             (r"bsconv_kernel<1, 8", "bsconv_bf16<1,8>"), (r"bsconv_kernel<2, 8", "bsconv_bf16<2,8>"), (r"bsconv_kernel<4, 4", "bsconv_bf16<4,4>"),
+             (r"b0conv_kernel", "b0conv_bf16<1,8>"), (r"b0wgrad_kernel", "b0wgrad_bf16<1,8>"), (r"bbn_cat_kernel", "bbn_act(concat)"),
+             (r"bhead_kernel", "bhead"), (r"bpack_multi_kernel", "bpack_multi")]
 
 vals = {c: collections.defaultdict(list) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 for c in vals:

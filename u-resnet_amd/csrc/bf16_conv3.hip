@@ -520,6 +520,8 @@ B3Plan b3_plan(const GatherGeom& g) {
   const int64_t tiles = (int64_t)g.N * p.nty * p.ntx;
   static const int64_t minwg = getenv("URSN_B3_MINWG") ? atoi(getenv("URSN_B3_MINWG")) : 2048;   // A/B
   while (zseg > 16 && tiles * ((Z + zseg - 1) / zseg) < minwg) zseg = (zseg + 1) / 2;
+  static const int force_nz = getenv("URSN_B3_NZSEG") ? atoi(getenv("URSN_B3_NZSEG")) : 0;   // A/B
+  if (force_nz > 0) zseg = (Z + force_nz - 1) / force_nz;
   p.zseg = zseg;
   p.nzseg = (Z + zseg - 1) / zseg;
   p.grid = (int)(tiles * p.nzseg);
