@@ -127,6 +127,8 @@ def test_bf16_conv_forward_data_and_weight_gradients(case):
         _lib.check(lib.ursn_conv_backward_weight(ctypes.byref(d), P(xg), P(dyg), P(dwg), P(scratch), nb, stream()))
         torch.cuda.synchronize()
         assert rel_err(dwg.cpu().numpy(), rep * dw) < 2e-5, ("wgrad", rep)
+    if tag.endswith("_dp") and co % 64 == 0:   # the deep-level weight-gradient kernel (bf16_wgraddeep.hip)
+        assert lib.ursn_last_kernel_name().startswith(b"bdwgrad_bf16"), lib.ursn_last_kernel_name()
 
 
 @pytest.mark.parametrize("case", [c for c in CASES if not c[8]][:29], ids=[c[0] for c in CASES if not c[8]][:29])

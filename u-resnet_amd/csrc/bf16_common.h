@@ -155,6 +155,12 @@ size_t b3wgrad_scratch_bytes(const GatherGeom& g);
 int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,
                    size_t scratch_bytes, hipStream_t s, const B3Affine* aff = nullptr, const float* S_f32 = nullptr);
 // dW[t][m][n] += sum_q S[q*si+d_t][m] * C[q][n]   (fp32 accumulation, fp32 dW [t][Kw][Nw])
+// ... of the deep levels (3x3x3 stride 1, contraction channels a multiple of 32, produced channels a multiple of 64):
+// 32 x 32 x 16 tiles, taps split over seven waves, double-buffered boxes (bf16_wgraddeep.hip); launch_bwgrad dispatches
+bool bdwgrad_ok(const GatherGeom& g);
+size_t bdwgrad_scratch_bytes(const GatherGeom& g);
+int launch_bdwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch, size_t scratch_bytes,
+                   hipStream_t s);
 size_t bwgrad_scratch_bytes(const GatherGeom& g);
 int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,
                   size_t scratch_bytes, hipStream_t s);

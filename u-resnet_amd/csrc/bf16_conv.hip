@@ -834,6 +834,7 @@ static bool bwgrad_plan(const GatherGeom& g, BWPlan& p) {
 
 size_t bwgrad_scratch_bytes(const GatherGeom& g) {   // 256 bytes (the zero piece) + the slabs
   if (b3wgrad_ok(g)) return b3wgrad_scratch_bytes(g);
+  if (bdwgrad_ok(g)) return bdwgrad_scratch_bytes(g);
   BWPlan p;
   if (!bwgrad_plan(g, p)) return 0;
   return (size_t)p.nchunks * p.ncob * p.gridx * p.U * 16 * 16 * p.cot * sizeof(float) + 512;
@@ -868,6 +869,7 @@ static const bf16_t* zero_piece() {
 int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch,
                   size_t scratch_bytes, hipStream_t s) {
   if (b3wgrad_ok(g)) return launch_b3wgrad(g, S, C, dw, Kw, Nw, scratch, scratch_bytes, s);
+  if (bdwgrad_ok(g)) return launch_bdwgrad(g, S, C, dw, Kw, Nw, scratch, scratch_bytes, s);   // deep levels (bf16_wgraddeep.hip)
   BWPlan p;
   URSN_REQUIRE(bwgrad_plan(g, p), "bf16 wgrad: unsupported geometry (channels %d x %d)", g.K, g.Nn);
   URSN_REQUIRE(scratch && scratch_bytes >= bwgrad_scratch_bytes(g), "bf16 wgrad: scratch too small");
