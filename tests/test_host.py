@@ -158,6 +158,37 @@ def test_buffer_path_kernels_refuse_planes_beyond_their_offset_range():
     assert lib.ursn_conv_bs_blocks(ctypes.byref(d)) == 0
 
 
+def test_bf16_dispatch_plan_of_the_round4_kernels():
+    """Which bf16 kernel family a layer pass is handed to (ursn_conv_plan: plan query only, nothing runs): the single-launch
+    stride-2 scatter kernel for the transposed convs / stride-2 data gradients of levels 1-5 (even extents, >= 32 contraction
+    channels), the conv0 kernels for one input channel, the deep-level weight gradient for >= 64 produced channels at <= 2^18
+    voxels -- and the generic kernels where a guard fails (odd extents, 32 produced channels, a million voxels)."""
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(32)
+
+    def plan(ndim, n, sp, ci, co, k, stride, tr, ps):
+        d = _lib.ursn_conv_desc()
+        d.ndim, d.n, d.cin, d.cout, d.k, d.stride, d.transposed, d.dtype = ndim, n, ci, co, k, stride, tr, 1
+        for i, v in enumerate(sp):
+            d.in_sp[i] = v
+        _lib.check(lib.ursn_conv_plan(ctypes.byref(d), ps, buf, 32))
+        return buf.value.decode()
+
+    assert plan(3, 4, (8, 8, 8), 256, 128, 3, 2, 1, 0) == "bsconv"        # deconv0 forward
+    assert plan(3, 4, (64, 64, 64), 32, 16, 3, 2, 1, 0) == "bsconv"       # deconv3 forward
+    assert plan(3, 4, (128, 128, 128), 16, 8, 3, 2, 1, 0) == "bdeconv"    # deconv4: the 16 -> 8 kernel of round 3
+    assert plan(3, 4, (128, 128, 128), 16, 32, 3, 2, 0, 1) == "bsconv"    # stride-2 conv 16 -> 32: its data gradient
+    assert plan(3, 1, (7, 9, 21), 16, 32, 3, 2, 0, 1) == "bconv"          # odd extents: by parity class on the box kernel
+    assert plan(3, 4, (256, 256, 256), 1, 8, 3, 1, 0, 0) == "b0conv"
+    assert plan(3, 4, (256, 256, 256), 1, 8, 3, 1, 0, 2) == "b0wgrad"
+    assert plan(3, 4, (32, 32, 32), 64, 64, 3, 1, 0, 2) == "bdwgrad"
+    assert plan(3, 4, (8, 8, 8), 256, 256, 3, 1, 0, 2) == "bdwgrad"
+    assert plan(3, 4, (32, 32, 32), 128, 64, 3, 1, 0, 2) == "bdwgrad"     # decoder conv1: 2C -> C
+    assert plan(3, 4, (64, 64, 64), 32, 32, 3, 1, 0, 2) == "bwgrad"       # 32 produced channels / a million voxels: generic
+    assert plan(3, 4, (32, 32, 32), 64, 64, 3, 1, 0, 0) == "bdconv"
+    assert plan(3, 4, (256, 256, 256), 8, 8, 3, 1, 0, 0) == "b3conv"
+
+
 # ---- synthetic IO (larcv_threadio protocol) ------------------------------------------------------------------------
 def test_synthetic_threadio_protocol():
     io_ = sio.synthetic_threadio()
