@@ -83,7 +83,7 @@ struct B3Args {
 template <int CI, int CO, bool STATS, bool PW = false, int BS = 0, bool AFF = false, bool DMA = false>
 __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ? 3 : 2) void b3conv_kernel(B3Args a) {
   static_assert(!AFF || (!PW && BS == 0), "normalise-on-load: plain forward instantiations");
-  static_assert(!DMA || (!AFF && !PW && BS == 0), "LDS-DMA staging: plain instantiations (no transform on the way in)");
+  static_assert(!DMA || (!AFF && !PW), "LDS-DMA staging: no transform on the way in (the BS operands belong to the epilogue)");
   using G = B3<CI, CO>;
   static_assert(!PW || (CI == 8 && CO == 16 && !STATS), "fused shortcut term: the 8 -> 16 data gradient");
   static_assert(BS == 0 || (CO == 8 && !STATS && !PW), "fused BatchNorm-backward reductions: data gradients producing 8 channels");
@@ -450,12 +450,20 @@ __global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ?
           constexpr int STEADY = AHEAD * krow + G::NST * (AHEAD - 1);
           constexpr int STEADY_ACC = STEADY + (AHEAD - 1) * krow < 63 ? STEADY + (AHEAD - 1) * krow : 63;   // a smaller count only waits for more
           static_assert(STEADY <= 63, "vmcnt immediate");
-          if (a.accumulate) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY_ACC) : "memory");
+          if constexpr (BS != 0) {   // + the epilogue operand loads of iterations p + 1 - AHEAD .. p (issued behind that iteration's DMA)
+            const int bsl = RPW * (1 + (BS == 2 ? 1 : 0)) + (a.bs_mode == 3 ? RPW : 0);
+            wait_vm(STEADY + AHEAD * bsl + (a.accumulate ? (AHEAD - 1) * krow : 0));
+          } else if (a.accumulate) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY_ACC) : "memory");
           else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY) : "memory");
         } else {
           int kst = 0, nd = 0;
 #pragma unroll
           for (int k = 1; k <= AHEAD; ++k) kst += (p - k >= z0 && p - k < z1) ? krow : 0;
+          if constexpr (BS != 0) {
+            const int bsl = RPW * (1 + (BS == 2 ? 1 : 0)) + (a.bs_mode == 3 ? RPW : 0);
+#pragma unroll
+            for (int k = 1; k <= AHEAD; ++k) kst += (p - k >= z0 && p - k < z1) ? bsl : 0;
+          }
 #pragma unroll
           for (int k = 2; k <= AHEAD; ++k) nd += (p + k <= z1) ? 1 : 0;
           if (a.accumulate) {
@@ -635,7 +643,15 @@ int launch_b3conv(const GatherGeom& g, const bf16_t* in, const float* w, int Kw,
     a.bs_z_cs = bs->z_cs; a.bs_y_cs = bs->y_cs; a.bs_z2_cs = bs->z2_cs; a.bs_mode = bs->mode;
     URSN_TRY(pack(8, 8, B3<8, 8>::WPACK, B3<8, 8>::MT));
     ursn_note_kernel("b3conv_bf16<8,8>+bnred");
-    if (bs->z2) hipLaunchKernelGGL((b3conv_kernel<8, 8, false, false, 2>), dim3(p.grid), dim3(256), 0, s, a);
+    // URSN_B3CONV_BS_DMA=1: planes through the LDS-DMA ring.  Measured at cfg5 with the fusion on: 0.91-1.53 ms per launch against
+    // 0.73-1.30 on the register path (and 0.45 + 0.38 for the plain data gradient + the separate reduce pass): the epilogue's
+    // arithmetic, not the latency of its operands, is what the fusion costs -- off
+    static const bool bs_dma = getenv("URSN_B3CONV_BS_DMA") && getenv("URSN_B3CONV_BS_DMA")[0] == '1' &&
+                               !(getenv("URSN_B3CONV_DMA") && getenv("URSN_B3CONV_DMA")[0] == '0');
+    if (bs_dma) {
+      if (bs->z2) hipLaunchKernelGGL((b3conv_kernel<8, 8, false, false, 2, false, true>), dim3(p.grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((b3conv_kernel<8, 8, false, false, 1, false, true>), dim3(p.grid), dim3(256), 0, s, a);
+    } else if (bs->z2) hipLaunchKernelGGL((b3conv_kernel<8, 8, false, false, 2>), dim3(p.grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((b3conv_kernel<8, 8, false, false, 1>), dim3(p.grid), dim3(256), 0, s, a);
     URSN_HIP(hipGetLastError());
     return 0;
