@@ -265,6 +265,209 @@ __global__ __launch_bounds__(512, 4) void s2conv_kernel(S2Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// s2conv2_kernel (round 4): the same boxes, but the operands are read as 16-byte pieces.  s2conv_kernel issues two
+// ds_read_b32 per v_mfma_f32_16x16x4_f32 (one weight, one input value per lane) and is bound by instruction issue
+// (MFMA-busy 0.35-0.46, 54 % of its wave cycles waiting to issue: profiles/r04_pmc_mfma_busy_cfg3.json).  Here a
+// lane's float4 holds FOUR k values and element j feeds MFMA j of a group of four (any bijection between a lane
+// quad's 16 k values and the four MFMAs' k indices is a valid contraction as long as A and B use the same one):
+//   C16  k = 16 channels of one tap:  lane (il, kl) holds channels 4 kl .. 4 kl + 3
+//   C8   k = 8 channels of two taps:  lanes kl = 0, 1 hold tap 2 p, lanes kl = 2, 3 tap 2 p + 1 (K = 8 layers)
+// -> one b128 weight read and one b128 input read per FOUR MFMAs (NR + 1 per 4 NR).  Halo layout [piece][position]
+// with the x parity split as before, so the 16 lanes of a k group read 256 contiguous bytes; weights are staged in
+// A-operand order [tap][piece][co].
+template <int MODE, bool C16, int NTHR = 512>
+struct Halo2 {
+  using B = SBox<MODE>;
+  static constexpr int NPC = C16 ? 4 : 2;                      // 16-byte pieces per staged voxel
+  static constexpr int HZ = (B::KZ == 3) ? 2 * B::BZ + 1 : 1, HY = 2 * B::BY + 1, HX = 2 * B::BX + 1, HXH = B::BX + 1;
+  static constexpr int PS = HZ * HY * 2 * HXH;
+  static constexpr int PSP = PS + ((4 - PS % 16) + 16) % 16;   // piece-plane stride == 4 (mod 16) float4: planes 64 B apart mod 256
+  static constexpr int NLD = HZ * HY * HX * NPC;
+  static constexpr int NH = (NLD + NTHR - 1) / NTHR;
+  static constexpr int WST = 20;                               // float4 per (tap, piece) row of the staged weights (16 + pad)
+};
+
+template <int MODE, bool C16, bool STATS>
+__global__ __launch_bounds__(512) void s2conv2_kernel(S2Args a) {
+  constexpr int NTHR = 512, NWAVE = 8;
+  using B = SBox<MODE>;
+  using H = Halo2<MODE, C16, NTHR>;
+  constexpr int BZ = B::BZ, BY = B::BY, BX = B::BX, NT = B::NT, KZ = B::KZ;
+  constexpr int HY = H::HY, HX = H::HX, HXH = H::HXH, PSP = H::PSP, NLD = H::NLD, NH = H::NH, NPC = H::NPC, WST = H::WST;
+  constexpr int CC = C16 ? 16 : 8;                            // channels per chunk
+  constexpr int NR = (BZ * BY) / NWAVE;                       // 16-voxel rows per wave
+  constexpr int NG = C16 ? NT : (NT + 1) / 2;                 // groups of four MFMAs: taps | tap pairs
+  extern __shared__ __attribute__((aligned(16))) float s2l[];
+  s2_f32x4* hal = (s2_f32x4*)s2l;                             // [NPC][PSP]
+  s2_f32x4* wl = hal + NPC * PSP;                             // [NT][NPC][WST]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int il = lane & 15, kl = lane >> 4;
+  const S2Geom& g = a.g;
+  const int co0 = blockIdx.y * 16;
+
+  int goff[NH], loff[NH];
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int idx = tid + i * NTHR;
+    const int sv = idx / NPC, q = idx - sv * NPC;
+    const int hx = sv % HX, r = sv / HX;
+    const int hy = r % HY, hz = r / HY;
+    goff[i] = ((hz * g.IY + hy) * g.IX + hx) * a.in_cs + 4 * q;
+    loff[i] = q * PSP + ((hz * HY + hy) * 2 + (hx & 1)) * HXH + (hx >> 1);
+  }
+  // B operand: lane (il, kl) reads piece plane (C16: kl | C8: kl & 1) at the lane's voxel + the tap's offset
+  int hb[NR];
+#pragma unroll
+  for (int v = 0; v < NR; ++v) {
+    const int row = NR * wave + v;
+    const int lz = (MODE == 3) ? row / BY : 0, ly = (MODE == 3) ? row % BY : row;
+    hb[v] = (C16 ? kl : (kl & 1)) * PSP + ((2 * lz) * HY + 2 * ly) * 2 * HXH + il;
+  }
+  const int wb = (C16 ? kl : (kl & 1)) * WST + il;
+  const bool second = !C16 && kl >= 2;   // C8: this lane's k values belong to the pair's second tap
+
+  auto load_halo = [&](const BoxPos& bp, int c0, s2_f32x4 (&hv)[NH]) {
+    const int oz0 = (KZ == 3) ? 2 * bp.z0 - g.pz : 0, oy0 = 2 * bp.y0 - g.py, ox0 = 2 * bp.x0 - g.px;
+    const int64_t base = ((((int64_t)bp.n * g.IZ + oz0) * g.IY + oy0) * g.IX + ox0) * a.in_cs + c0;
+    const bool interior = oz0 >= 0 && oz0 + H::HZ <= g.IZ && oy0 >= 0 && oy0 + HY <= g.IY && ox0 >= 0 && ox0 + HX <= g.IX;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int idx = tid + i * NTHR;
+      bool ok = (i + 1) * NTHR <= NLD || idx < NLD;
+      if (!interior) {
+        const int sv = idx / NPC;
+        const int hx = sv % HX, r = sv / HX;
+        const int hy = r % HY, hz = r / HY;
+        const int pz = oz0 + hz, py = oy0 + hy, px = ox0 + hx;
+        ok = ok && pz >= 0 && pz < g.IZ && py >= 0 && py < g.IY && px >= 0 && px < g.IX;
+      }
+      s2_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *(const s2_f32x4*)(a.in + base + goff[i]);
+      hv[i] = v;
+    }
+  };
+  auto store_halo = [&](const s2_f32x4 (&hv)[NH]) {
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+      if ((i + 1) * NTHR <= NLD || tid + i * NTHR < NLD) hal[loff[i]] = hv[i];
+  };
+  // weights of a chunk in A-operand order: element (t, piece q, co) = W[t][c0 + 4 q + (0..3)][co0 + co]
+  constexpr int NWE = NT * NPC * 16, NWL = (NWE + NTHR - 1) / NTHR;
+  auto load_w = [&](int c0, s2_f32x4 (&wv)[NWL]) {
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int idx = tid + i * NTHR;
+      s2_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < NWE) {
+        const int co = idx & 15, q = (idx >> 4) % NPC, t = idx / (16 * NPC);
+        const float* wp = a.w + ((size_t)t * a.cin + c0 + 4 * q) * a.cout + co0 + co;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = wp[(size_t)j * a.cout];
+      }
+      wv[i] = v;
+    }
+  };
+  auto store_w = [&](const s2_f32x4 (&wv)[NWL]) {
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int idx = tid + i * NTHR;
+      if (idx < NWE) wl[(idx >> 4) * WST + (idx & 15)] = wv[i];
+    }
+  };
+
+  const int nchunks = a.cin / CC;
+  const int box_begin = ursn_xcd_block(blockIdx.x, gridDim.x) * a.bpw;
+  int box_end = box_begin + a.bpw;
+  if (box_end > a.nboxes) box_end = a.nboxes;
+  const int nitems = (box_end - box_begin) * nchunks;
+
+  s2_f32x4 acc[NR];
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, piv[4] = {0.f, 0.f, 0.f, 0.f}, nacc = 0.f;
+  s2_f32x4 hv[NH], wv[NWL];
+  BoxPos cur = s2_box(g, box_begin, BZ, BY, BX);
+  load_halo(cur, 0, hv);
+  load_w(0, wv);
+  int box = box_begin, ch = 0;
+  for (int it = 0; it < nitems; ++it) {
+    if (it) __syncthreads();
+    store_halo(hv);
+    if (it == 0 || nchunks > 1) store_w(wv);
+    __syncthreads();
+    int nbox = box, nch = ch + 1;
+    if (nch == nchunks) { nch = 0; ++nbox; }
+    BoxPos nxt = cur;
+    if (it + 1 < nitems) {
+      if (nbox != box) nxt = s2_box(g, nbox, BZ, BY, BX);
+      load_halo(nxt, CC * nch, hv);
+      if (nchunks > 1) load_w(CC * nch, wv);
+    }
+    if (ch == 0) {
+#pragma unroll
+      for (int v = 0; v < NR; ++v) acc[v] = (s2_f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    s2_static_for<NG>([&](auto Gi) {
+      constexpr int gi = decltype(Gi)::value;
+      constexpr int t0 = C16 ? gi : 2 * gi, t1 = C16 ? gi : (2 * gi + 1 < NT ? 2 * gi + 1 : NT - 1);   // (phantom tap of the last pair: zero weights below)
+      constexpr int tz0 = (KZ == 3) ? t0 / 9 : 0, ty0 = (t0 / 3) % 3, tx0 = t0 % 3;
+      constexpr int tz1 = (KZ == 3) ? t1 / 9 : 0, ty1 = (t1 / 3) % 3, tx1 = t1 % 3;
+      constexpr int toff0 = ((tz0 * HY + ty0) * 2 + (tx0 & 1)) * HXH + (tx0 >> 1);
+      constexpr int toff1 = ((tz1 * HY + ty1) * 2 + (tx1 & 1)) * HXH + (tx1 >> 1);
+      const int toff = second ? toff1 : toff0;
+      s2_f32x4 av = wl[wb + (second ? t1 : t0) * (NPC * WST)];
+      if (!C16 && 2 * gi + 1 >= NT && second) av = (s2_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < NR; ++v) {
+        const s2_f32x4 bv = hal[hb[v] + toff];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[v] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[v], 0, 0, 0);
+      }
+    });
+    if (ch == nchunks - 1) {
+      const int gx = cur.x0 + il;
+#pragma unroll
+      for (int v = 0; v < NR; ++v) {
+        const int row = NR * wave + v;
+        const int gz = (MODE == 3) ? cur.z0 + row / BY : 0, gy = (MODE == 3) ? cur.y0 + row % BY : cur.y0 + row;
+        if (!(gz < g.OZ && gy < g.OY && gx < g.OX)) continue;
+        float* op = a.out + ((((size_t)cur.n * g.OZ + gz) * g.OY + gy) * g.OX + gx) * a.out_cs + co0 + 4 * kl;
+        s2_f32x4 val = acc[v];
+        if (a.accumulate) val += *(s2_f32x4*)op;
+        *(s2_f32x4*)op = val;
+        if constexpr (STATS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (nacc == 0.f) piv[r] = val[r];
+            ursn_sacc(piv[r], s1[r], s2[r], val[r]);
+          }
+          nacc += 1.f;
+        }
+      }
+    }
+    box = nbox; ch = nch; cur = nxt;
+  }
+  if constexpr (STATS) {
+    __shared__ double red[NWAVE][32];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double u, w2;
+      ursn_sacc_final(piv[r], s1[r], s2[r], nacc, u, w2);
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) { u += __shfl_xor(u, o); w2 += __shfl_xor(w2, o); }
+      if (il == 0) {
+        red[wave][4 * kl + r] = u;
+        red[wave][16 + 4 * kl + r] = w2;
+      }
+    }
+    __syncthreads();
+    if (tid < 32)
+      a.stats_partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + tid] =
+          ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) +
+          ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 struct S2WArgs {
   const float* S;   // hi-res tensor (x for a conv, dy for a transposed conv)
   const float* C;   // lo-res tensor
@@ -533,6 +736,22 @@ static int launch_s2c(const S2Plan& p, const S2Args& a, hipStream_t s) {
   return 0;
 }
 
+template <int MODE, bool C16, bool STATS>
+static int launch_s2c2(const S2Plan& p, const S2Args& a, hipStream_t s) {
+  using H = Halo2<MODE, C16, 512>;
+  constexpr int NT = SBox<MODE>::NT;
+  const size_t lds = ((size_t)H::NPC * H::PSP + (size_t)NT * H::NPC * H::WST) * 16;
+  auto kern = s2conv2_kernel<MODE, C16, STATS>;
+  static size_t attr_lds = 48 * 1024;
+  if (lds > attr_lds) {
+    URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.gridx, p.Nn / 16), dim3(512), lds, s, a);
+  URSN_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_stride2_conv(const ursn_conv_desc& d, ConvPass pass, const float* in, const float* w, float* out,
                         int accumulate, double* stats_partial, float eps, float* mean, float* rstd, hipStream_t s) {
   S2Plan p;
@@ -545,7 +764,21 @@ int launch_stride2_conv(const ursn_conv_desc& d, ConvPass pass, const float* in,
   a.nboxes = p.nboxes; a.bpw = p.bpw;
   ursn_note_kernel(d.transposed ? "s2conv(deconv dgrad)" : "s2conv");
   int rc;
-  if (p.mode == 3) rc = stats_partial ? launch_s2c<3, true>(p, a, s) : launch_s2c<3, false>(p, a, s);
+  // 16-byte operand reads (s2conv2_kernel): one weight and one input read per four MFMAs instead of one each per MFMA.  Measured
+  // (tools/s2_v2_sweep.sh, forward of the stride-2 conv / data gradient of the transposed conv, ms): the issue diet alone buys
+  // nothing -- 3-D 192^3 8 -> 16: 0.376 vs 0.336, 96^3 16 -> 32: 0.198 vs 0.180, 24^3 64 -> 128: 0.088 vs 0.078; 2-D 512^2 x 16
+  // 16 -> 32: 0.182 vs 0.175, 64^2 x 16 128 -> 256: 0.156 vs 0.131 -- except where the old kernel's four / eight 8-channel chunk
+  // items per box stall it: 2-D 256^2 x 16 32 -> 64: 0.173 vs 0.321, 128^2 x 16 64 -> 128: 0.173 vs 0.231 (and their transposed
+  // twins).  Default: those shapes only.  URSN_S2CONV_V2=0 never, =2 wherever the channel count allows
+  static const int v2mode = getenv("URSN_S2CONV_V2") ? atoi(getenv("URSN_S2CONV_V2")) : 1;
+  const bool v2 = v2mode == 2 || (v2mode == 1 && p.mode == 2 && (p.K == 32 || p.K == 64));
+  if (v2) {
+    const bool c16 = (p.K % 16) == 0;
+#define S2V2(m_, c_) (stats_partial ? launch_s2c2<m_, c_, true>(p, a, s) : launch_s2c2<m_, c_, false>(p, a, s))
+    if (p.mode == 3) rc = c16 ? S2V2(3, true) : S2V2(3, false);
+    else rc = c16 ? S2V2(2, true) : S2V2(2, false);
+#undef S2V2
+  } else if (p.mode == 3) rc = stats_partial ? launch_s2c<3, true>(p, a, s) : launch_s2c<3, false>(p, a, s);
   else rc = stats_partial ? launch_s2c<2, true>(p, a, s) : launch_s2c<2, false>(p, a, s);
   if (rc) return rc;
   if (stats_partial) {
