@@ -62,8 +62,10 @@ __device__ __forceinline__ double bs_row_sum(double v) {   // over the 16 lanes 
 }
 
 // MT: 16-channel tiles of produced channels per block (1 | 2 | 4); NT: 16-voxel tiles of the coarse box (4 | 8)
-template <int MT, int NT, bool STATS>
+// FAST (MT = 1, one chunk): the wave's whole weight stream in registers (below)
+template <int MT, int NT, bool STATS, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void bsconv_kernel(BSArgs a) {
+  static_assert(!FAST || MT == 1, "register-resident weights: one tile of produced channels");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, g = lane >> 4;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(BSArgs a) {
   // this wave's weight stream: iteration i (item-major, chunk-minor) is MT KB at wsrc + i * MT * 1024
   const unsigned char* wsrc = (const unsigned char*)a.wp + ((size_t)(cob * 27 + it0) * a.nchunks) * (MT * 1024) + lane * 16;
 
-  bfx8 A[3][MT], B[3][NT];
+  bfx8 A[FAST ? 1 : 3][MT], B[FAST ? 1 : 3][NT];
   // prefetch cursor (item, chunk) of iteration i + 2 and compute cursor of iteration i
   int pit = it0, pch = 0, cit = it0, cch = 0;
   auto fetch_a = [&](bfx8 (&Ad)[MT], int i) {
@@ -143,6 +145,17 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(BSArgs a) {
   auto finish = [&](int cls) {   // round and store the class's fine voxels; moments of the stored values
     const int rz = (cls >> 2) & 1, ry = (cls >> 1) & 1, rx = cls & 1;
     const unsigned coff = (unsigned)(((rz * Yf + ry) * Xf + rx) * a.out_cs) * 2u;
+    // accumulate (data gradients: never together with the forward's moments): every old value of the class is requested before
+    // the first is used
+    bst_u32x2 oldv[STATS ? 1 : NT][STATS ? 1 : MT];
+    if constexpr (!STATS) {
+      if (a.accumulate) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) oldv[nt][mt] = ursn_bload_b64(rout, obase[nt] + coff + 32u * mt);
+      }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -151,8 +164,8 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(BSArgs a) {
         acc[mt][nt] = (bf_f32x4){0.f, 0.f, 0.f, 0.f};
         if (cob * (16 * MT) + 16 * mt >= a.Cout) continue;
         const unsigned off = obase[nt] + coff + 32u * mt;
-        if (a.accumulate) {
-          const bst_u32x2 e = ursn_bload_b64(rout, off);
+        if (!STATS && a.accumulate) {
+          const bst_u32x2 e = oldv[STATS ? 0 : nt][STATS ? 0 : mt];
           v[0] += __uint_as_float(e[0] << 16); v[1] += __uint_as_float(e[0] & 0xffff0000u);
           v[2] += __uint_as_float(e[1] << 16); v[3] += __uint_as_float(e[1] & 0xffff0000u);
         }
@@ -176,6 +189,34 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(BSArgs a) {
     }
   };
 
+  if constexpr (FAST) {
+    // one tile of produced channels and one chunk (32 -> 16: the 64^3 level, HBM-sized passes): an item is 8 MFMAs of 16 cycles --
+    // nothing to hide an L2 round trip behind, two items ahead or not.  The wave's whole weight stream (<= 8 KB: 8 items) is
+    // requested before the images are waited for and stays in registers
+    {
+      bfx8 Aall[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) Aall[i] = *(const bfx8*)(wsrc + (size_t)(i < I ? i : 0) * 1024);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      bfx8 Bc[NT], Bn[NT];
+      fetch_b(Bc);
+#pragma unroll 1
+      for (int i = 0; i < I; ++i) {   // (one copy of the epilogue: eight unrolled ones sent the accumulators to scratch)
+        if (i + 1 < I) fetch_b(Bn);
+        bfx8 Ai = Aall[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) if (i == k) Ai = Aall[k];   // wave-uniform selects instead of indexed registers
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ai, Bc[nt], acc[0][nt], 0, 0, 0);
+        const int cls = __builtin_amdgcn_readfirstlane(a.item_cls[cit]);
+        ++cit;
+        if (cls & 8) finish(cls & 7);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) Bc[nt] = Bn[nt];
+      }
+    }
+  } else {
   if (I > 0) fetch_a(A[0], 0);
   if (I > 1) fetch_a(A[1], 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the image has landed
@@ -200,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void bsconv_kernel(BSArgs a) {
     body(A[0], B[0], A[2], B[2], i);
     if (i + 1 < I) body(A[1], B[1], A[0], B[0], i + 1);
     if (i + 2 < I) body(A[2], B[2], A[1], B[1], i + 2);
+  }
   }
 
   if constexpr (STATS) {
@@ -314,9 +356,9 @@ bool bs_plan(const GatherGeom* g, int cnt, BSPlan& p) {
   return it == 27;
 }
 
-template <int MT, int NT, bool STATS>
+template <int MT, int NT, bool STATS, bool FAST = false>
 int bs_launch(const BSPlan& p, const BSArgs& a, hipStream_t s) {
-  auto kern = bsconv_kernel<MT, NT, STATS>;
+  auto kern = bsconv_kernel<MT, NT, STATS, FAST>;
   static size_t attr = 48 * 1024;
   if (p.lds > attr) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
@@ -344,6 +386,7 @@ int launch_bsconv(const GatherGeom* g, int cnt, const bf16_t* in, const float* w
                   double* stats_partial, int accumulate, hipStream_t s) {
   BSPlan p;
   URSN_REQUIRE(bs_plan(g, cnt, p), "bf16 stride-2 scatter pass (deep levels): unsupported geometry");
+  URSN_REQUIRE(!(stats_partial && accumulate), "bf16 stride-2 scatter pass: moments belong to a forward pass, which overwrites");
   const GatherGeom& g0 = g[0];
   {
     BPackJob k = bpack_job(BPK_SCATTER);
@@ -372,8 +415,18 @@ int launch_bsconv(const GatherGeom* g, int cnt, const bf16_t* in, const float* w
     ursn_note_kernel(label);                                                                      \
     rc = st ? bs_launch<mt_, nt_, true>(p, a, s) : bs_launch<mt_, nt_, false>(p, a, s);           \
   }
-  BS(4, 4, "bsconv_bf16<4,4>") BS(2, 8, "bsconv_bf16<2,8>") BS(2, 4, "bsconv_bf16<2,4>") BS(1, 8, "bsconv_bf16<1,8>")
-  BS(1, 4, "bsconv_bf16<1,4>")
+  BS(4, 4, "bsconv_bf16<4,4>") BS(2, 8, "bsconv_bf16<2,8>") BS(2, 4, "bsconv_bf16<2,4>")
+  // (forward with moments: measured 1.23 ms against 0.14 on the streamed path -- not understood, not used)
+  if (p.mt == 1 && p.nchunks == 1 && !st) {   // 32 contraction channels: every wave's weights (<= 8 items) stay in registers
+    int most = 0;
+    for (int w2 = 0; w2 < 4; ++w2) if (p.wave_first[w2 + 1] - p.wave_first[w2] > most) most = p.wave_first[w2 + 1] - p.wave_first[w2];
+    URSN_REQUIRE(most <= 8, "bf16 stride-2 scatter pass: a wave owns more than 8 items");
+    ursn_note_kernel(p.nt == 8 ? "bsconv_bf16<1,8>" : "bsconv_bf16<1,4>");
+    if (p.nt == 8) rc = bs_launch<1, 8, false, true>(p, a, s);
+    else rc = bs_launch<1, 4, false, true>(p, a, s);
+  } else {
+    BS(1, 8, "bsconv_bf16<1,8>") BS(1, 4, "bsconv_bf16<1,4>")
+  }
 #undef BS
   URSN_TRY(rc);
   return 0;
