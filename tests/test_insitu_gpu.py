@@ -60,7 +60,7 @@ print("INSITU_OK")
 """
 SWITCHES = [
     ("bf16", {"URSN_B3CONV_DMA": "0", "URSN_BF16_SKIP0_MERGE": "0", "URSN_BF16_PREPACK": "0", "URSN_BF16_FWD_OVERLAP": "0"}),   # register-staged planes instead of the LDS-DMA ring; the skip's gradient share in its own tensor; per-launch weight packing; shortcut convs in line
-    ("bf16", {"URSN_BSCONV": "0", "URSN_B0CONV": "0", "URSN_B3CONV_ACC_DMA": "0", "URSN_BDWGRAD": "0", "URSN_BF16_RESIDUAL_IN_DGRAD": "0", "URSN_BF16_HEAD_BN_BWD": "0", "URSN_BBN_CAT_PAIRS": "0"}),   # round-4 kernels off: stride-2 scatter passes by parity class, conv0 as an 8-channel layer
+    ("bf16", {"URSN_BSCONV": "0", "URSN_B0CONV": "0", "URSN_BS2K8": "0", "URSN_B3CONV_ACC_DMA": "0", "URSN_BDWGRAD": "0", "URSN_BF16_RESIDUAL_IN_DGRAD": "0", "URSN_BF16_HEAD_BN_BWD": "0", "URSN_BBN_CAT_PAIRS": "0"}),   # round-4 kernels off: stride-2 scatter passes by parity class, conv0 as an 8-channel layer
     ("bf16", {"URSN_BCB": "0", "URSN_SLAB_FOLD": "0"}),    # generic box kernel at levels 1-2, one-stage slab reduce
     ("bf16", {"URSN_BF16_FUSE_BN_BWD_REDUCE": "1"}),       # BatchNorm-backward reductions in the data-gradient epilogue
     ("bf16", {"URSN_B3CONV_PW": "0", "URSN_BF16_NORM_ON_LOAD": "0", "URSN_BF16_SKIP0_OWN": "0"}),   # no fused shortcut term, materialised activations, skip inside the concat buffer

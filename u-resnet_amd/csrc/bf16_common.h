@@ -149,6 +149,13 @@ bool b0wgrad_ok(const GatherGeom& g);
 size_t b0wgrad_scratch_bytes(const GatherGeom& g);
 int launch_b0wgrad(const GatherGeom& g, const float* x, const bf16_t* dz, float* dw, int Nw, void* scratch, size_t scratch_bytes,
                    hipStream_t s);
+// stride-2 gather 8 -> 16 channels, z-marching (bf16_s2k8.hip): forward of the first stride-2 conv (+ its unit's 1x1 stride-2
+// shortcut conv in the same pass: sc_w [8][16], second output, second set of moments) and data gradient of the last transposed conv
+bool bs2k8_ok(const GatherGeom& g);
+int bs2k8_grid_blocks(const GatherGeom& g);   // statistics partials: [blocks][2][16] doubles, the shortcut's behind the conv's
+size_t bs2k8_pack_elems();
+int launch_bs2k8(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out, double* stats_partial,
+                 int accumulate, const float* sc_w, bf16_t* out2, int out2_cs, hipStream_t s);
 bool b3wgrad_ok(const GatherGeom& g);   // z-marching weight gradient of the same layers (bf16_wgrad3.hip)
 bool b3wgrad_scalar_ok(const GatherGeom& g);   // S may be one fp32 channel per voxel (S_f32)
 size_t b3wgrad_scratch_bytes(const GatherGeom& g);

@@ -17,7 +17,7 @@
 
 #include "bf16_common.h"
 
-enum BPackType { BPK_GENERIC = 0, BPK_B3 = 1, BPK_CB = 2, BPK_D3 = 3, BPK_DEEP = 4, BPK_SCATTER = 5, BPK_PAD8 = 6, BPK_C0 = 7 };
+enum BPackType { BPK_GENERIC = 0, BPK_B3 = 1, BPK_CB = 2, BPK_D3 = 3, BPK_DEEP = 4, BPK_SCATTER = 5, BPK_PAD8 = 6, BPK_C0 = 7, BPK_S2K8 = 8 };
 
 struct BPackJob {
   int type, blocks;           // blocks of 256 threads

@@ -148,6 +148,23 @@ __device__ void pk_c0(const BPackJob& k, int vb, int tid) {
   k.wp[e] = f2bf(v);
 }
 
+// BPK_S2K8 (bf16_s2k8.hip: stride-2 gather 8 -> 16): [fragment 0..7][lane = 16 g + m][8]: fragments 0..6: k slot 4 j + g = tap (slot 27
+// zero), 8 channels, produced channel m; fragment 7: the 1x1 shortcut's weights pw_w[ci][16] in k slot 27 only (or zeros)
+__device__ void pk_s2k8(const BPackJob& k, int vb, int tid) {
+  const int e = vb * 256 + tid;
+  if (e >= 4096) return;
+  const int i = e & 7, lane = (e >> 3) & 63, j = e >> 9;
+  const int m = lane & 15, g = lane >> 4;
+  float v = 0.f;
+  if (j < 7) {
+    const int t = 4 * j + g;
+    if (t < 27 && i < k.Kw && m < k.Nw) v = pk_w(k, k.tap[t], i, m);
+  } else if (g == 3 && k.pw_w && i < k.Kw && m < k.Nw) {
+    v = k.pw_w[i * 16 + m];
+  }
+  k.wp[e] = f2bf(v);
+}
+
 __device__ __forceinline__ void pk_run(const BPackJob& j, int vb, int tid) {
   switch (j.type) {
     case BPK_GENERIC: pk_generic(j, vb, tid); break;
@@ -157,6 +174,7 @@ __device__ __forceinline__ void pk_run(const BPackJob& j, int vb, int tid) {
     case BPK_DEEP: pk_deep(j, vb, tid); break;
     case BPK_PAD8: pk_pad8(j, vb, tid); break;
     case BPK_C0: pk_c0(j, vb, tid); break;
+    case BPK_S2K8: pk_s2k8(j, vb, tid); break;
     default: pk_scatter(j, vb, tid); break;
   }
 }

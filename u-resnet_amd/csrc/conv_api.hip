@@ -434,6 +434,15 @@ static int bf16_conv_op(const ursn_conv_desc& d0, ConvPass pass, const void* in,
     URSN_REQUIRE(wp, "bf16 conv: no memory for the packed weights");
     return launch_bdeconv(g, n, (const bf16_t*)in, w, 0, 0, wp, (bf16_t*)out, nullptr, accumulate, s);
   }
+  if (n == 1 && bs2k8_ok(g[0])) {   // stride-2 gather 8 -> 16 (forward of the stride-2 conv, data gradient of the transposed conv)
+    bf16_t* wp = op_wpack(bs2k8_pack_elems());
+    URSN_REQUIRE(wp, "bf16 conv: no memory for the packed weights");
+    const int blocks = bs2k8_grid_blocks(g[0]);
+    URSN_REQUIRE(!stats_partial || (size_t)blocks * 32 * sizeof(double) <= stats_bytes, "bf16 conv: statistics scratch too small");
+    URSN_TRY(launch_bs2k8(g[0], (const bf16_t*)in, w, 0, 0, wp, (bf16_t*)out, stats_partial, accumulate, nullptr, nullptr, 0, s));
+    if (stats_partial) URSN_TRY(launch_bn_stats_final(stats_partial, blocks, g[0].Nn, 16, V, eps, mean, rstd, s));
+    return 0;
+  }
   if (bsconv_ok(g, n)) {   // ... of the deeper levels (forward with BatchNorm moments too)
     bf16_t* wp = op_wpack(bsconv_pack_elems(g, n));
     URSN_REQUIRE(wp, "bf16 conv: no memory for the packed weights");
@@ -558,6 +567,7 @@ extern "C" int ursn_conv_plan(const ursn_conv_desc* d0, int32_t pass_, char* out
     while (first < n - 1 && g[first].ntaps == 0) ++first;
     if (pass == PASS_WGRAD) name = (d0->cin == 1 && b0wgrad_ok(g[0])) ? "b0wgrad" : b3wgrad_ok(g[0]) ? "b3wgrad" : bdwgrad_ok(g[0]) ? "bdwgrad" : (bwgrad_scratch_bytes(g[0]) ? "bwgrad" : "none");
     else if (d0->cin == 1 && pass == PASS_FWD && n == 1 && b0conv_ok(g[0])) name = "b0conv";
+    else if (n == 1 && bs2k8_ok(g[0])) name = "bs2k8";
     else if (bdeconv_ok(g, n)) name = "bdeconv";
     else if (bsconv_ok(g, n)) name = "bsconv";
     else if (bpw_ok(g[first])) name = "bpw";

@@ -331,6 +331,10 @@ int plan(ursn_bnet* n, Arena& A) {
             URSN_REQUIRE(e > 16, "bf16 plan: no conv kernel for %s (pass %d)", L.name.c_str(), pass);
             if (e > wps) wps = e;
             if (pass == PASS_FWD) stl += bconv_stats_scratch_doubles(g[i]);
+            if (cnt == 1 && bs2k8_ok(g[i])) {
+              if (pass == PASS_FWD && (size_t)bs2k8_grid_blocks(g[i]) * 64 > stl) stl = (size_t)bs2k8_grid_blocks(g[i]) * 64;
+              if (((bs2k8_pack_elems() + 127) & ~(size_t)127) > wps) wps = (bs2k8_pack_elems() + 127) & ~(size_t)127;
+            }
             if (pass == PASS_FWD && &L == &n->layers[n->conv0] && b0conv_ok(g[i])) {
               if ((size_t)b0conv_grid_blocks(g[i]) * 32 > stl) stl = (size_t)b0conv_grid_blocks(g[i]) * 32;
               if (b0conv_pack_elems() > wps) wps = (b0conv_pack_elems() + 127) & ~(size_t)127;
@@ -439,6 +443,11 @@ int conv_stats(ursn_bnet* n, int li, const BAct& in, int N, hipStream_t s, doubl
     URSN_TRY(launch_bsconv(g, cnt, in.p, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, stats, 0, s));
     return bsconv_stats_finalize(g, cnt, stats, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
   }
+  if (cnt == 1 && !in.in_f32 && in.aff_layer < 0 && bs2k8_ok(g[0])) {   // stride-2 gather 8 -> 16 (without a shortcut beside it)
+    total = bs2k8_grid_blocks(g[0]);
+    URSN_TRY(launch_bs2k8(g[0], in.p, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, stats, 0, nullptr, nullptr, 0, s));
+    return launch_bn_stats_final(stats, total, g[0].Nn, 16, (int64_t)N * n->lvox[L.lout], n->cfg.bn_eps, L.mean, L.rstd, s);
+  }
   if (in.in_f32 && cnt == 1 && b0conv_ok(g[0])) {   // conv0 on the raw fp32 input: the taps are the contraction (bf16_conv0.hip)
     total = b0conv_grid_blocks(g[0]);
     URSN_TRY(launch_b0conv(g[0], in.in_f32, n->params + L.w_off, Nw, L.wp[0], L.z, stats, s));
@@ -506,7 +515,26 @@ int unit_fwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s) {
   // URSN_BF16_FWD_OVERLAP=0: in line.
   static const bool overlap = !(getenv("URSN_BF16_FWD_OVERLAP") && getenv("URSN_BF16_FWD_OVERLAP")[0] == '0');
   hipEvent_t joined = nullptr;
-  if (u.sc >= 0 && overlap && n->s2 && n->s2_on) {
+  bool fused_sc = false;
+  if (u.sc >= 0) {   // stride-2 conv 8 -> 16 with its 1x1 stride-2 shortcut: ONE pass over the fine tensor (bf16_s2k8.hip)
+    BLayer& L = n->layers[u.c1];
+    BLayer& S = n->layers[u.sc];
+    GatherGeom g[8];
+    if (u.in.aff_layer < 0 && !u.in.in_f32 && L.stride == 2 && S.stride == 2 && S.k == 1 && S.kin == 8 && S.cin == 8 && S.kout == 16 && S.cout == 16 &&
+        layer_geoms(n, L, PASS_FWD, N, u.in.cs, L.kout, g) == 1 && bs2k8_ok(g[0])) {
+      int Kw, Nw;
+      real_extents(L, PASS_FWD, Kw, Nw);
+      BProf ps(n, s, u.c1, 0, blayer_flops(n, L, N) + blayer_flops(n, S, N), blayer_bytes(n, L, N) + 2.0 * N * n->lvox[S.lout] * S.cout);
+      const int blocks = bs2k8_grid_blocks(g[0]);
+      URSN_TRY(launch_bs2k8(g[0], u.in.p, n->params + L.w_off, Kw, Nw, L.wp[0], L.z, n->stats, 0, n->params + S.w_off, S.z, S.kout, s));
+      const int64_t V = (int64_t)N * n->lvox[L.lout];
+      URSN_TRY(launch_bn_stats_final(n->stats, blocks, 16, 16, V, n->cfg.bn_eps, L.mean, L.rstd, s));
+      URSN_TRY(launch_bn_stats_final(n->stats + (size_t)blocks * 32, blocks, 16, 16, V, n->cfg.bn_eps, S.mean, S.rstd, s));
+      fused_sc = true;
+    }
+  }
+  if (fused_sc) {
+  } else if (u.sc >= 0 && overlap && n->s2 && n->s2_on) {
     hipEvent_t e0 = next_event(n);
     joined = next_event(n);
     URSN_REQUIRE(e0 && joined, "bf16 forward: no event for the shortcut stream");
@@ -517,7 +545,7 @@ int unit_fwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s) {
   } else if (u.sc >= 0) {
     URSN_TRY(conv_stats(n, u.sc, u.in, N, s));
   }
-  URSN_TRY(conv_stats(n, u.c1, u.in, N, s));
+  if (!fused_sc) URSN_TRY(conv_stats(n, u.c1, u.in, N, s));
   if (u.a1.aff_layer < 0) URSN_TRY(bn_out(n, u.c1, u.a1, 0, N, -1, nullptr, s));
   URSN_TRY(conv_stats(n, u.c2, u.a1, N, s));
   if (joined) URSN_HIP(hipStreamWaitEvent(s, joined, 0));
@@ -702,6 +730,8 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
   }
   if (bdeconv_ok(g, cnt))   // stride-2 conv 8 -> 16: the eight parity classes of its data gradient in one launch
     return launch_bdeconv(g, cnt, L.dz, n->params + L.w_off, Kw, Nw, L.wp[1], in.g, nullptr, acc ? 1 : 0, s);
+  if (cnt == 1 && fused_sc < 0 && bs2k8_ok(g[0]))   // transposed conv 16 -> 8: its data gradient is a stride-2 gather 8 -> 16
+    return launch_bs2k8(g[0], L.dz, n->params + L.w_off, Kw, Nw, L.wp[1], in.g, nullptr, acc ? 1 : 0, nullptr, nullptr, 0, s);
   if (bsconv_ok(g, cnt))   // stride-2 convs of the deeper levels: likewise
     return launch_bsconv(g, cnt, L.dz, n->params + L.w_off, Kw, Nw, L.wp[1], in.g, nullptr, acc ? 1 : 0, s);
   for (int i = 0; i < cnt; ++i) {
