@@ -181,6 +181,7 @@ def test_bf16_dispatch_plan_of_the_round4_kernels():
     assert plan(3, 1, (7, 9, 21), 16, 32, 3, 2, 0, 1) == "bconv"          # odd extents: by parity class on the box kernel
     assert plan(3, 4, (256, 256, 256), 8, 16, 3, 2, 0, 0) == "bs2k8"     # first stride-2 conv: z-marching gather 8 -> 16
     assert plan(3, 4, (128, 128, 128), 16, 8, 3, 2, 1, 1) == "bs2k8"     # last transposed conv: its data gradient is the same gather
+    assert plan(3, 4, (256, 256, 256), 8, 16, 3, 2, 0, 2) == "bs2k8w"    # ... and its weight gradient
     assert plan(3, 4, (256, 256, 256), 1, 8, 3, 1, 0, 0) == "b0conv"
     assert plan(3, 4, (256, 256, 256), 1, 8, 3, 1, 0, 2) == "b0wgrad"
     assert plan(3, 4, (32, 32, 32), 64, 64, 3, 1, 0, 2) == "bdwgrad"

@@ -7,7 +7,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "liburesnet_hip.so")
 SOURCES = ["conv_generic.hip", "conv_tiled.hip", "conv_tiled_3d.hip", "conv_tiled_2d.hip", "wgrad_tiled_3d.hip", "wgrad_tiled_2d.hip", "wgrad4_tiled.hip", "deconv_tiled.hip", "wgradz_tiled.hip", "wgradq_tiled.hip", "wgrad_valu.hip", "conv_igemm.hip", "conv_deep.hip", "wgrad_igemm.hip", "wgrad_deep.hip", "conv_pointwise.hip", "conv_stride2.hip", "deconv_lds.hip",
-           "elementwise.hip", "bf16_conv.hip", "bf16_conv3.hip", "bf16_convcb.hip", "bf16_convdeep.hip", "bf16_wgrad3.hip", "bf16_deconv3.hip", "bf16_scatter.hip", "bf16_pack.hip", "bf16_conv0.hip", "bf16_wgraddeep.hip", "bf16_s2k8.hip", "bf16_pointwise.hip", "bf16_elementwise.hip", "net_bf16.hip",
+           "elementwise.hip", "bf16_conv.hip", "bf16_conv3.hip", "bf16_convcb.hip", "bf16_convdeep.hip", "bf16_wgrad3.hip", "bf16_deconv3.hip", "bf16_scatter.hip", "bf16_pack.hip", "bf16_conv0.hip", "bf16_wgraddeep.hip", "bf16_s2k8.hip", "bf16_s2k8w.hip", "bf16_pointwise.hip", "bf16_elementwise.hip", "net_bf16.hip",
            "conv_api.hip", "net.hip"]
 
 

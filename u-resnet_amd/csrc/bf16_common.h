@@ -156,6 +156,13 @@ int bs2k8_grid_blocks(const GatherGeom& g);   // statistics partials: [blocks][2
 size_t bs2k8_pack_elems();
 int launch_bs2k8(const GatherGeom& g, const bf16_t* in, const float* w, int Kw, int Nw, bf16_t* wpack, bf16_t* out, double* stats_partial,
                  int accumulate, const float* sc_w, bf16_t* out2, int out2_cs, hipStream_t s);
+// ... and their weight gradients (bf16_s2k8w.hip): S = the fine tensor (8 channels), C = the coarse one (16); C2 / dw2: the dz of the
+// unit's 1x1 stride-2 shortcut (coarse, 16 channels, stride c2_cs) and its weight gradient [8][16] (+=), taken in the same pass
+bool bs2k8w_ok(const GatherGeom& g);
+bool bs2k8w_sc_ok(const GatherGeom& g);
+size_t bs2k8w_scratch_bytes(const GatherGeom& g);
+int launch_bs2k8w(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* dw, int Kw, int Nw, void* scratch, size_t scratch_bytes,
+                  const bf16_t* C2, int c2_cs, float* dw2, hipStream_t s);
 bool b3wgrad_ok(const GatherGeom& g);   // z-marching weight gradient of the same layers (bf16_wgrad3.hip)
 bool b3wgrad_scalar_ok(const GatherGeom& g);   // S may be one fp32 channel per voxel (S_f32)
 size_t b3wgrad_scratch_bytes(const GatherGeom& g);

@@ -835,6 +835,7 @@ static bool bwgrad_plan(const GatherGeom& g, BWPlan& p) {
 size_t bwgrad_scratch_bytes(const GatherGeom& g) {   // 256 bytes (the zero piece) + the slabs
   if (b3wgrad_ok(g)) return b3wgrad_scratch_bytes(g);
   if (bdwgrad_ok(g)) return bdwgrad_scratch_bytes(g);
+  if (bs2k8w_ok(g)) return bs2k8w_scratch_bytes(g);
   BWPlan p;
   if (!bwgrad_plan(g, p)) return 0;
   return (size_t)p.nchunks * p.ncob * p.gridx * p.U * 16 * 16 * p.cot * sizeof(float) + 512;
@@ -870,6 +871,7 @@ int launch_bwgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float* 
                   size_t scratch_bytes, hipStream_t s) {
   if (b3wgrad_ok(g)) return launch_b3wgrad(g, S, C, dw, Kw, Nw, scratch, scratch_bytes, s);
   if (bdwgrad_ok(g)) return launch_bdwgrad(g, S, C, dw, Kw, Nw, scratch, scratch_bytes, s);   // deep levels (bf16_wgraddeep.hip)
+  if (bs2k8w_ok(g)) return launch_bs2k8w(g, S, C, dw, Kw, Nw, scratch, scratch_bytes, nullptr, 0, nullptr, s);   // stride 2, 8 x 16 channels
   BWPlan p;
   URSN_REQUIRE(bwgrad_plan(g, p), "bf16 wgrad: unsupported geometry (channels %d x %d)", g.K, g.Nn);
   URSN_REQUIRE(scratch && scratch_bytes >= bwgrad_scratch_bytes(g), "bf16 wgrad: scratch too small");

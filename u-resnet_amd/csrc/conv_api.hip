@@ -565,7 +565,7 @@ extern "C" int ursn_conv_plan(const ursn_conv_desc* d0, int32_t pass_, char* out
     URSN_REQUIRE(n >= 1, "conv_plan: bad descriptor");
     int first = 0;
     while (first < n - 1 && g[first].ntaps == 0) ++first;
-    if (pass == PASS_WGRAD) name = (d0->cin == 1 && b0wgrad_ok(g[0])) ? "b0wgrad" : b3wgrad_ok(g[0]) ? "b3wgrad" : bdwgrad_ok(g[0]) ? "bdwgrad" : (bwgrad_scratch_bytes(g[0]) ? "bwgrad" : "none");
+    if (pass == PASS_WGRAD) name = (d0->cin == 1 && b0wgrad_ok(g[0])) ? "b0wgrad" : b3wgrad_ok(g[0]) ? "b3wgrad" : bdwgrad_ok(g[0]) ? "bdwgrad" : bs2k8w_ok(g[0]) ? "bs2k8w" : (bwgrad_scratch_bytes(g[0]) ? "bwgrad" : "none");
     else if (d0->cin == 1 && pass == PASS_FWD && n == 1 && b0conv_ok(g[0])) name = "b0conv";
     else if (n == 1 && bs2k8_ok(g[0])) name = "bs2k8";
     else if (bdeconv_ok(g, n)) name = "bdeconv";

@@ -637,12 +637,13 @@ struct BBsTarget {
 };
 
 // fused_sc >= 0: the data gradient also carries the term of that (1x1, stride-1) shortcut layer
+// wgrad_sc >= 0: the weight gradient launch also takes that (1x1 stride-2) shortcut layer's (bf16_s2k8w.hip); skip_wgrad: it was taken there
 int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipStream_t s, int fused_sc = -1,
-             const BBsTarget* bs = nullptr, const B3Residual* res = nullptr) {
+             const BBsTarget* bs = nullptr, const B3Residual* res = nullptr, int wgrad_sc = -1, bool skip_wgrad = false) {
   BLayer& L = n->layers[li];
   GatherGeom g[8];
   int Kw, Nw;
-  {  // weight gradient on the second stream, ordered after the dz it reads
+  if (!skip_wgrad) {  // weight gradient on the second stream, ordered after the dz it reads
     URSN_REQUIRE(layer_geoms(n, L, PASS_WGRAD, N, in.cs, L.kout, g) == 1, "bf16 backward: bad weight-gradient geometry");
     real_extents(L, PASS_WGRAD, Kw, Nw);
     hipStream_t ws = s;
@@ -668,6 +669,10 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
       URSN_REQUIRE(!L.kind && layer_geoms(n, L, PASS_WGRAD, N, P.kout, L.kout, g) == 1 && b3wgrad_ok(g[0]), "bf16 backward: %s cannot normalise its input on load", L.name.c_str());
       B3Affine af = {P.mean, P.rstd, beta_of(n, P), in.aff_relu};
       URSN_TRY(launch_b3wgrad(g[0], P.z, L.dz, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, ws, &af));
+    } else if (wgrad_sc >= 0) {
+      const BLayer& SL = n->layers[wgrad_sc];
+      URSN_REQUIRE(!L.kind && bs2k8w_sc_ok(g[0]), "bf16 backward: %s cannot take its shortcut's weight gradient along", L.name.c_str());
+      URSN_TRY(launch_bs2k8w(g[0], in.p, L.dz, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, SL.dz, SL.kout, n->grads + SL.w_off, ws));
     } else {
       const bf16_t* S = L.kind ? L.dz : in.p;
       const bf16_t* Cq = L.kind ? in.p : L.dz;
@@ -806,8 +811,17 @@ int unit_bwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s, const BBsTarget* in_t
     URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, -1, nullptr, &rs));
     return 0;
   }
-  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, fuse ? u.sc : -1, u.sc < 0 ? in_target : nullptr));   // k3 (s1 | s2): writes every voxel of d(in)
-  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, !fuse, N, s));      // 1x1 (s1 | s2): weight gradient (+ accumulated data gradient)
+  // stride-2 unit between the two finest levels: the shortcut's weight gradient rides in conv1's launch (one pass over the fine tensor)
+  bool wsc = false;
+  if (u.sc >= 0 && u.in.aff_layer < 0 && !u.in.in_f32) {
+    GatherGeom gw[8];
+    const BLayer& C1 = n->layers[u.c1];
+    const BLayer& S = n->layers[u.sc];
+    wsc = C1.stride == 2 && S.stride == 2 && S.k == 1 && S.kin == 8 && S.cin == 8 && S.kout == 16 && S.cout == 16 &&
+          layer_geoms(n, C1, PASS_WGRAD, N, u.in.cs, C1.kout, gw) == 1 && bs2k8w_sc_ok(gw[0]);
+  }
+  URSN_TRY(conv_bwd(n, u.c1, u.in, true, N, s, fuse ? u.sc : -1, u.sc < 0 ? in_target : nullptr, nullptr, wsc ? u.sc : -1));   // k3 (s1 | s2): writes every voxel of d(in)
+  if (u.sc >= 0) URSN_TRY(conv_bwd(n, u.sc, u.in, !fuse, N, s, -1, nullptr, nullptr, -1, wsc));   // 1x1 (s1 | s2): weight gradient (+ accumulated data gradient)
   return 0;
 }
 
