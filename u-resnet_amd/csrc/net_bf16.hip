@@ -18,6 +18,7 @@
 
 #include "bf16_common.h"
 #include "bf16_pack.h"
+#include <functional>
 #include "net_bf16.h"
 
 namespace {
@@ -108,6 +109,8 @@ struct ursn_bnet {
   void* head_scratch = nullptr;
   void* wg_scratch = nullptr; size_t wg_bytes = 0;
   double* stats2 = nullptr;
+  std::vector<std::function<int()>> deferred;   // weight-gradient launches held back while the decoder is at level 0
+  bool defer_on = true, defer_open = false;
   hipStream_t s2 = nullptr;
   hipEvent_t s2_done = nullptr;
   std::vector<hipEvent_t> evs;
@@ -644,40 +647,52 @@ int conv_bwd(ursn_bnet* n, int li, const BAct& in, bool need_dgrad, int N, hipSt
   GatherGeom g[8];
   int Kw, Nw;
   if (!skip_wgrad) {  // weight gradient on the second stream, ordered after the dz it reads
-    URSN_REQUIRE(layer_geoms(n, L, PASS_WGRAD, N, in.cs, L.kout, g) == 1, "bf16 backward: bad weight-gradient geometry");
-    real_extents(L, PASS_WGRAD, Kw, Nw);
-    hipStream_t ws = s;
-    if (n->s2 && n->s2_on) {
-      if (n->ev_used == n->evs.size()) {
-        hipEvent_t e;
-        URSN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        n->evs.push_back(e);
+    const BAct inw = in;   // (by value: a deferred launch outlives the caller's reference)
+    auto wgrad = [n, li, inw, N, s, wgrad_sc]() -> int {
+      BLayer& L = n->layers[li];
+      const BAct& in = inw;
+      GatherGeom g[8];
+      int Kw, Nw;
+      URSN_REQUIRE(layer_geoms(n, L, PASS_WGRAD, N, in.cs, L.kout, g) == 1, "bf16 backward: bad weight-gradient geometry");
+      real_extents(L, PASS_WGRAD, Kw, Nw);
+      hipStream_t ws = s;
+      if (n->s2 && n->s2_on) {
+        hipEvent_t e = next_event(n);
+        URSN_REQUIRE(e, "bf16 backward: no event for the weight-gradient stream");
+        URSN_HIP(hipEventRecord(e, s));
+        URSN_HIP(hipStreamWaitEvent(n->s2, e, 0));
+        ws = n->s2;
       }
-      hipEvent_t e = n->evs[n->ev_used++];
-      URSN_HIP(hipEventRecord(e, s));
-      URSN_HIP(hipStreamWaitEvent(n->s2, e, 0));
-      ws = n->s2;
-    }
-    BProf pw(n, ws, li, 2, blayer_flops(n, L, N), blayer_bytes(n, L, N));
-    if (in.in_f32 && !L.kind && b0wgrad_ok(g[0])) {
-      URSN_TRY(launch_b0wgrad(g[0], in.in_f32, L.dz, n->grads + L.w_off, Nw, n->wg_scratch, n->wg_bytes, ws));
-    } else if (in.in_f32) {
-      URSN_REQUIRE(!L.kind && b3wgrad_scalar_ok(g[0]), "bf16 backward: %s cannot read a scalar fp32 input", L.name.c_str());
-      URSN_TRY(launch_b3wgrad(g[0], nullptr, L.dz, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, ws, nullptr, in.in_f32));
-    } else if (in.aff_layer >= 0) {
-      const BLayer& P = n->layers[in.aff_layer];
-      URSN_REQUIRE(!L.kind && layer_geoms(n, L, PASS_WGRAD, N, P.kout, L.kout, g) == 1 && b3wgrad_ok(g[0]), "bf16 backward: %s cannot normalise its input on load", L.name.c_str());
-      B3Affine af = {P.mean, P.rstd, beta_of(n, P), in.aff_relu};
-      URSN_TRY(launch_b3wgrad(g[0], P.z, L.dz, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, ws, &af));
-    } else if (wgrad_sc >= 0) {
-      const BLayer& SL = n->layers[wgrad_sc];
-      URSN_REQUIRE(!L.kind && bs2k8w_sc_ok(g[0]), "bf16 backward: %s cannot take its shortcut's weight gradient along", L.name.c_str());
-      URSN_TRY(launch_bs2k8w(g[0], in.p, L.dz, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, SL.dz, SL.kout, n->grads + SL.w_off, ws));
-    } else {
-      const bf16_t* S = L.kind ? L.dz : in.p;
-      const bf16_t* Cq = L.kind ? in.p : L.dz;
-      URSN_TRY(launch_bwgrad(g[0], S, Cq, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, ws));
-    }
+      BProf pw(n, ws, li, 2, blayer_flops(n, L, N), blayer_bytes(n, L, N));
+      if (in.in_f32 && !L.kind && b0wgrad_ok(g[0])) {
+        URSN_TRY(launch_b0wgrad(g[0], in.in_f32, L.dz, n->grads + L.w_off, Nw, n->wg_scratch, n->wg_bytes, ws));
+      } else if (in.in_f32) {
+        URSN_REQUIRE(!L.kind && b3wgrad_scalar_ok(g[0]), "bf16 backward: %s cannot read a scalar fp32 input", L.name.c_str());
+        URSN_TRY(launch_b3wgrad(g[0], nullptr, L.dz, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, ws, nullptr, in.in_f32));
+      } else if (in.aff_layer >= 0) {
+        const BLayer& P = n->layers[in.aff_layer];
+        URSN_REQUIRE(!L.kind && layer_geoms(n, L, PASS_WGRAD, N, P.kout, L.kout, g) == 1 && b3wgrad_ok(g[0]), "bf16 backward: %s cannot normalise its input on load", L.name.c_str());
+        B3Affine af = {P.mean, P.rstd, beta_of(n, P), in.aff_relu};
+        URSN_TRY(launch_b3wgrad(g[0], P.z, L.dz, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, ws, &af));
+      } else if (wgrad_sc >= 0) {
+        const BLayer& SL = n->layers[wgrad_sc];
+        URSN_REQUIRE(!L.kind && bs2k8w_sc_ok(g[0]), "bf16 backward: %s cannot take its shortcut's weight gradient along", L.name.c_str());
+        URSN_TRY(launch_bs2k8w(g[0], in.p, L.dz, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, SL.dz, SL.kout, n->grads + SL.w_off, ws));
+      } else {
+        const bf16_t* S = L.kind ? L.dz : in.p;
+        const bf16_t* Cq = L.kind ? in.p : L.dz;
+        URSN_TRY(launch_bwgrad(g[0], S, Cq, n->grads + L.w_off, Kw, Nw, n->wg_scratch, n->wg_bytes, ws));
+      }
+      return 0;
+    };
+    // The level-0 weight gradients are HBM-heavy (2-3 GB each) and so is everything the main stream does at level 0: launched
+    // at once they run BESIDE it and both slow down (32.4 ms of main-stream kernels + 9.9 ms of weight gradients take 39.6 ms).
+    // Opt-in experiment (URSN_BF16_DEFER_WGRAD=L): queue them while the decoder is at level 0 and release them when the main stream
+    // reaches decoder level L (small latency-bound kernels that leave the HBM idle).  Measured at cfg5: L = 1 / 2 / 3 / 4: 98.0 /
+    // 98.5 / 98.7 / 98.5 images/s against 101.1 launched at once -- the deep levels are too short (5 ms) to absorb 4.8 ms of level-0
+    // weight gradients, which then land beside the encoder's level-1 / level-0 passes instead.  Off.
+    if (n->defer_open && n->s2 && n->s2_on && L.lout == 0) n->deferred.push_back(wgrad);
+    else URSN_TRY(wgrad());
   }
   if (!need_dgrad) return 0;
   BProf pd(n, s, li, 1, blayer_flops(n, L, N), blayer_bytes(n, L, N));
@@ -825,11 +840,23 @@ int unit_bwd(ursn_bnet* n, BUnit& u, int N, hipStream_t s, const BBsTarget* in_t
   return 0;
 }
 
+int flush_deferred(ursn_bnet* n) {
+  n->defer_open = false;
+  for (auto& f : n->deferred) URSN_TRY(f());
+  n->deferred.clear();
+  return 0;
+}
+
 int backward(ursn_bnet* n, int N, hipStream_t s) {
   const int ns = n->cfg.num_strides;
   for (size_t i = 0; i < n->ginit.size(); ++i) n->ginit[i] = 0;
   n->ev_used = 0;
   n->split0_done = false;
+  // URSN_BF16_DEFER_WGRAD=L: the level-0 weight gradients of the decoder are released when the main stream starts decoder level L
+  // (default 0: launched at once -- measured faster, see conv_bwd)
+  static const int defer_level = getenv("URSN_BF16_DEFER_WGRAD") ? atoi(getenv("URSN_BF16_DEFER_WGRAD")) : 0;
+  n->deferred.clear();
+  n->defer_open = defer_level > 0 && n->s2 && n->s2_on;
   URSN_TRY(bn_back(n, n->conv2, n->dlog, 8, nullptr, 0, 0, -1, nullptr, 0, 0, N, s));
   BBsTarget tc;
   tc.li = n->conv1; tc.mode = 2;
@@ -844,6 +871,7 @@ int backward(ursn_bnet* n, int N, hipStream_t s) {
   tc = join_of(n->units[ui - 1]);
   URSN_TRY(conv_bwd(n, n->conv1, n->a_pre1, true, N, s, -1, &tc));
   for (int i = ns - 1; i >= 0; --i) {
+    if (ns - 1 - i == defer_level) URSN_TRY(flush_deferred(n));
     tc = join_of(n->units[ui - 2]);
     URSN_TRY(unit_bwd(n, n->units[--ui], N, s, &tc));
     URSN_TRY(unit_bwd(n, n->units[--ui], N, s));
@@ -852,6 +880,7 @@ int backward(ursn_bnet* n, int N, hipStream_t s) {
     else URSN_TRY(bn_back(n, n->deconv[i], dout.g, dout.cs, nullptr, 0, 1, -1, nullptr, 0, 0, N, s));
     URSN_TRY(conv_bwd(n, n->deconv[i], n->deconv_in[i], true, N, s));
   }
+  URSN_TRY(flush_deferred(n));   // (a shallow network never reached the level)
   for (int step = ns - 1; step >= 0; --step) {
     tc = join_of(n->units[ui - 2]);
     URSN_TRY(unit_bwd(n, n->units[--ui], N, s, &tc));
