@@ -106,6 +106,13 @@ struct ursn_net {
   // BN-backward passes and the low-occupancy deep-level kernels of the main chain (URSN_WGRAD_STREAM=0 disables)
   hipStream_t s2 = nullptr;
   hipStream_t s2_owned = nullptr;   // s2 == s2_owned when the overlap is switched on
+  // hipGraph replay of the accumulate step for launch-bound workloads (ursn_accum_step): one captured graph per (data, label,
+  // weight, batch) of the last few calls
+  struct StepGraph { const float* data; const float* label; const float* weight; int n, seen; hipGraphExec_t exec; };
+  std::vector<StepGraph> graphs;
+  bool graph_broken = false;
+  hipStream_t gstream = nullptr;   // the graphs are captured on / launched into a stream of their own (the caller's may be the legacy
+  hipEvent_t g_in = nullptr, g_out = nullptr;   // default stream, which cannot be captured), ordered against the caller's by two events
   std::vector<hipEvent_t> sync_pool;
   size_t sync_used = 0;
   std::vector<hipEvent_t> fwd_pool;   // forward: fork / join events of the side-stream shortcut convs
@@ -1005,6 +1012,10 @@ extern "C" int ursn_create(const ursn_config* cfg, float* params, float* grads, 
 }
 
 extern "C" int ursn_destroy(ursn_net* net) {
+  if (net) for (auto& gph : net->graphs) if (gph.exec) (void)hipGraphExecDestroy(gph.exec);
+  if (net && net->gstream) { (void)hipStreamSynchronize(net->gstream); (void)hipStreamDestroy(net->gstream); }
+  if (net && net->g_in) (void)hipEventDestroy(net->g_in);
+  if (net && net->g_out) (void)hipEventDestroy(net->g_out);
   if (!net) return 0;
   if (net->bf) { bnet_destroy(net->bf); delete net; return 0; }
   if (net->s2_owned) { (void)hipStreamSynchronize(net->s2_owned); (void)hipStreamDestroy(net->s2_owned); }
@@ -1060,9 +1071,75 @@ extern "C" int ursn_accum_step(ursn_net* net, const float* data, const float* la
     if (out3) URSN_TRY(read_metrics(net, out3, 3, s));
     return 0;
   }
-  URSN_TRY(forward(net, data, n, s));
-  URSN_TRY(head(net, data, label, net->cfg.use_weight ? weight : nullptr, n, nullptr, true, s));
-  URSN_TRY(backward(net, data, n, s));
+  // hipGraph replay (opt-in experiment).  cfg1 (2-D 256^2 x 4) issues ~560 launches per 5.7 ms step and the host needs 5.5 ms to
+  // enqueue them (tools/host_enqueue_probe.py), so the step looked launch-bound.  With URSN_GRAPH >= 1 the third call with the same
+  // buffers and batch captures the step's launches -- both streams, the events between them -- into a hipGraph on a stream of the
+  // library's own, and later calls are ONE graph launch.  Measured on ROCm 7.2: the replay takes 10.7 ms per step against 5.7 ms
+  // of ordinary launches (the runtime orders the nodes more strictly than the two streams do), so it is OFF by default.
+  // URSN_GRAPH=1: when the batch holds <= 2^20 voxels, 2: always.  Never while profiling (events per launch).
+  static const int gmode = getenv("URSN_GRAPH") ? atoi(getenv("URSN_GRAPH")) : 0;
+  bool geligible = gmode > 0 && !net->profile && !net->graph_broken && !ursn_roctx_on() &&
+                   (gmode > 1 || (int64_t)n * net->lvox[0] <= ((int64_t)1 << 20));
+  auto run_on = [&](hipStream_t rs) -> int {
+    URSN_TRY(forward(net, data, n, rs));
+    URSN_TRY(head(net, data, label, net->cfg.use_weight ? weight : nullptr, n, nullptr, true, rs));
+    URSN_TRY(backward(net, data, n, rs));
+    return 0;
+  };
+  auto run = [&]() -> int { return run_on(s); };
+  if (geligible && !net->gstream) {
+    if (hipStreamCreateWithFlags(&net->gstream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&net->g_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&net->g_out, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      net->graph_broken = true;
+    }
+  }
+  auto graph_launch = [&](hipGraphExec_t ex) -> int {   // caller's stream -> graph stream -> caller's stream
+    URSN_HIP(hipEventRecord(net->g_in, s));
+    URSN_HIP(hipStreamWaitEvent(net->gstream, net->g_in, 0));
+    URSN_HIP(hipGraphLaunch(ex, net->gstream));
+    URSN_HIP(hipEventRecord(net->g_out, net->gstream));
+    URSN_HIP(hipStreamWaitEvent(s, net->g_out, 0));
+    return 0;
+  };
+  geligible = geligible && !net->graph_broken;
+  if (geligible) {
+    ursn_net::StepGraph* sg = nullptr;
+    for (auto& gph : net->graphs)
+      if (gph.data == data && gph.label == label && gph.weight == weight && gph.n == n) sg = &gph;
+    if (!sg) {
+      if (net->graphs.size() >= 4) {   // forget the oldest
+        if (net->graphs[0].exec) (void)hipGraphExecDestroy(net->graphs[0].exec);
+        net->graphs.erase(net->graphs.begin());
+      }
+      net->graphs.push_back({data, label, weight, n, 0, nullptr});
+      sg = &net->graphs.back();
+    }
+    if (sg->exec) {
+      URSN_TRY(graph_launch(sg->exec));
+    } else if (++sg->seen >= 3) {
+      hipGraph_t graph = nullptr;
+      bool ok = hipStreamBeginCapture(net->gstream, hipStreamCaptureModeRelaxed) == hipSuccess;
+      int rc = ok ? run_on(net->gstream) : 1;
+      if (ok) ok = hipStreamEndCapture(net->gstream, &graph) == hipSuccess && graph != nullptr;
+      if (ok && rc == 0) ok = hipGraphInstantiate(&sg->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) (void)hipGraphDestroy(graph);
+      if (getenv("URSN_GRAPH_DEBUG")) fprintf(stderr, "ursn graph capture: ok=%d rc=%d\n", (int)ok, rc);
+      if (ok && rc == 0) {
+        URSN_TRY(graph_launch(sg->exec));
+      } else {   // nothing of the captured step ran: give up on graphs and run it the ordinary way
+        (void)hipGetLastError();
+        sg->exec = nullptr;
+        net->graph_broken = true;
+        URSN_TRY(run());
+      }
+    } else {
+      URSN_TRY(run());
+    }
+  } else {
+    URSN_TRY(run());
+  }
   if (out3) URSN_TRY(read_metrics(net, out3, 3, s));
   return 0;
 }
