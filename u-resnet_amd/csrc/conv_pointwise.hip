@@ -184,8 +184,10 @@ __global__ __launch_bounds__(256) void pwgrad_kernel(PWgradArgs a) {
   int64_t v_end = v_begin + a.vox_per_block;
   if (v_end > a.nvox) v_end = a.nvox;
   const int a_lane = ((il >> 2) * SP + kl) * 4 + (il & 3);
-  for (int64_t v0 = v_begin; v0 < v_end; v0 += 256) {
-    __syncthreads();
+  // the next step's operands are requested before this step's MFMAs (round 4: loaded and stored to LDS back to back the kernel
+  // paid a full memory round trip per 256-voxel step: 4.4 TB/s on the level-0 shortcut, whose operands are 2.7 GB)
+  pw_f32x4 xr[NSX], dr[NSD];
+  auto load_step = [&](int64_t v0) {
 #pragma unroll
     for (int i = 0; i < NSX; ++i) {
       int idx = tid + i * 256;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void pwgrad_kernel(PWgradArgs a) {
         val = __builtin_nontemporal_load((a.split && 4 * q >= a.split) ? (const pw_f32x4*)(a.x2 + hv * a.x2_cs + 4 * q - a.split)
                                                                         : (const pw_f32x4*)(a.x + hv * a.x_cs + 4 * q));
       }
-      *(pw_f32x4*)(xl + ((size_t)q * SP + s) * 4) = val;
+      xr[i] = val;
     }
 #pragma unroll
     for (int i = 0; i < NSD; ++i) {
@@ -215,8 +217,25 @@ __global__ __launch_bounds__(256) void pwgrad_kernel(PWgradArgs a) {
       int64_t v = v0 + s;
       pw_f32x4 val = {0.f, 0.f, 0.f, 0.f};
       if (v < v_end) val = __builtin_nontemporal_load((const pw_f32x4*)(a.dz + v * a.dz_cs + 4 * q));
-      *(pw_f32x4*)(dl + ((size_t)q * SP + s) * 4) = val;
+      dr[i] = val;
     }
+  };
+  if (v_begin < v_end) load_step(v_begin);
+  for (int64_t v0 = v_begin; v0 < v_end; v0 += 256) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NSX; ++i) {
+      int idx = tid + i * 256;
+      int s = idx / XQ, q = idx - s * XQ;
+      *(pw_f32x4*)(xl + ((size_t)q * SP + s) * 4) = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NSD; ++i) {
+      int idx = tid + i * 256;
+      int s = idx / DQ, q = idx - s * DQ;
+      *(pw_f32x4*)(dl + ((size_t)q * SP + s) * 4) = dr[i];
+    }
+    if (v0 + 256 < v_end) load_step(v0 + 256);
     __syncthreads();
 #pragma unroll 4
     for (int ks = wave; ks < 64; ks += 4) {   // voxel quads of this step, interleaved over the 4 waves
