@@ -51,7 +51,8 @@ static bool make_dplan(const ursn_conv_desc& d, ConvPass pass, TDPlan& p, DBlock
   p.ntx = (p.X + TX - 1) / TX;
   p.nty = (p.Y + TY - 1) / TY;
   int64_t base = (int64_t)d.n * p.ntx * p.nty;
-  ursn_pick_zseg(base, p.Z, p.mode == 3 ? 1 : 2, 6, p.zseg, p.nzseg);   // resident workgroups per CU: 1 (3-D, 190-256 VGPRs)
+  // resident workgroups per CU: 2-D 2; 3-D 1 at 16 produced channels (256 VGPRs), 2 at 8 (<= 192 VGPRs since round 4)
+  ursn_pick_zseg(base, p.Z, p.mode == 3 ? (cp <= 8 ? 2 : 1) : 2, 6, p.zseg, p.nzseg);
   p.grid = (int)((int64_t)d.n * p.nzseg * p.nty * p.ntx);
   b = DBlocking();
   if (ck % 16 || ck > 64) return false;
@@ -64,7 +65,8 @@ static bool make_dplan(const ursn_conv_desc& d, ConvPass pass, TDPlan& p, DBlock
   p.ck = 16;
   p.cp = b.pb;
   const int PX = TX + 1, PY = TY + (p.mode == 3 ? 1 : 0);
-  p.lds = (size_t)3 * (p.ck / 4) * PX * PY * 16;
+  // 3 ring planes + per wave the exchange buffer of the line-contiguous stores (2 * cp / 4 + 1 sixteen-byte units per lane)
+  p.lds = (size_t)3 * (p.ck / 4) * PX * PY * 16 + (size_t)256 * (2 * (p.cp / 4) + 1) * 16;
   return p.lds <= 160 * 1024;
 }
 

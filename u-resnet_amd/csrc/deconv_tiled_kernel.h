@@ -11,6 +11,11 @@
 // (27*Cc*Cp/4 v_mfma_f32_4x4x1_16b per voxel), and weights stay in registers via the cbsz/abid A-broadcast
 // exactly as in conv_tiled_kernel.h.  Every lane stores 2 x-adjacent output voxels per (pz,py): 64 contiguous
 // bytes at Cp = 8, instead of the eight stride-2 scatter launches of the generic path.
+//
+// Round 4: those 64 bytes used to leave as four 16-byte stores with a 64-byte lane stride -- every store instruction touched 32
+// lines with 32 bytes each, and the ablation (tools/td_ablate.sh) priced the stores at 0.17 of the layer's 0.43 ms (stores +
+// loads alone: 0.32 ms for 906 MB = 2.8 TB/s).  Now a wave passes each output row class through a 5 KB LDS buffer of its own
+// and lane l stores unit 64 i + l of the wave's row segment: every instruction writes whole lines.
 #pragma once
 #include "conv_tiled_kernel.h"
 
@@ -28,7 +33,7 @@ struct TDeconvArgs {
 
 // CK = contracted channels, CP = produced channels
 template <int CK, int CP, int MODE, bool STATS>
-__global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
+__global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_kernel(TDeconvArgs a) {
   using TL = Tile<MODE>;
   constexpr int TX = TL::TX, TY = TL::TY, NTY = TL::NTY, NT = TL::NT;
   constexpr int HY = (NTY == 3) ? 1 : 0;                       // halo rows on the low side
@@ -112,6 +117,22 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
   __syncthreads();
 
   const int lane_slot = (ty + HY) * PX + tx + 1;   // the lane's own voxel inside a plane
+
+  // line-contiguous stores: a lane owns U = 2 * CQ sixteen-byte units per output row class (2 x-adjacent voxels x CQ quads);
+  // store instruction i of lane l carries unit 64 i + l of the wave = slot (64 i + l) % U of lane (64 i + l) / U
+  constexpr int U = 2 * CQ, XS = 4 * U + 4;        // floats per lane in the exchange buffer (one unit of padding)
+  float* xl = (float*)(dlds + 3 * NQ * PS) + (tid >> 6) * 64 * XS;
+  int xsrc[U], xoff[U];
+  bool xok[U];
+#pragma unroll
+  for (int i = 0; i < U; ++i) {
+    const int u = 64 * i + lane, sl = u / U, slot = u % U;
+    const int st = (tid & ~63) + sl;                // the owner's thread index
+    const int sy = y0 + st / TX, sx = x0 + st % TX;
+    xsrc[i] = sl * XS + 4 * slot;
+    xoff[i] = ((NTY == 3 ? 2 * sy * (2 * a.X) : 0) + 2 * sx + slot / CQ) * a.out_cs + 4 * (slot % CQ);
+    xok[i] = sy < a.Y && sx < a.X;
+  }
   for (int z = z0; z < z1; ++z) {
     stage_load(z + 1);
     f32x4 acc[NCLS][CQ];
@@ -122,8 +143,11 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
     const f32x4* p_cur = dlds + (size_t)(z % 3) * NQ * PS + lane_slot;
     const f32x4* p_prev = dlds + (size_t)((z + 2) % 3) * NQ * PS + lane_slot;
     // loop over the 2^d source offsets; every tap with that offset reuses the loaded voxel
-    static_for<NCLS>([&](auto OFF) {
-      constexpr int off = decltype(OFF)::value;                 // bit2: z-1, bit1: y-1, bit0: x-1 (3-D); 2-D: bit1: row-1
+    // the offsets with z-1 (second half) only feed the even output planes: the odd planes are complete, and stored, after the
+    // first half -- their stores drain under the remaining third of the MFMAs
+    auto run_offsets = [&](auto HALF) {
+    static_for<NCLS / 2>([&](auto OFF) {
+      constexpr int off = decltype(HALF)::value * (NCLS / 2) + decltype(OFF)::value;   // bit2: z-1, bit1: y-1, bit0: x-1 (3-D); 2-D: bit1: row-1
       constexpr int oz = (NTY == 3) ? (off >> 2) & 1 : (off >> 1) & 1;
       constexpr int oy = (NTY == 3) ? (off >> 1) & 1 : 0;
       constexpr int ox = off & 1;
@@ -151,14 +175,16 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
         });
       });
     });
+    };
+    run_offsets(std::integral_constant<int, 0>{});
     if constexpr (STATS) {
-      if (z == z0 && a.stats_partial) {   // wave-uniform, once: the pivots = the first valid lane's parity-0 values of this plane
+      if (z == z0 && a.stats_partial) {   // wave-uniform, once: the pivots = the first valid lane's all-odd outputs of this plane
         const int src = wave_first_valid(vox_ok);
         if (src >= 0) {
-          const float* op = a.out + ((((size_t)n * (2 * a.Z) + 2 * z) * ((NTY == 3) ? 2 * a.Y : 1) + 2 * gy) * (2 * a.X) + 2 * gx) * a.out_cs;
+          const float* op = a.out + ((((size_t)n * (2 * a.Z) + 2 * z + 1) * ((NTY == 3) ? 2 * a.Y : 1) + 2 * gy + (NTY == 3 ? 1 : 0)) * (2 * a.X) + 2 * gx + 1) * a.out_cs;
 #pragma unroll
           for (int cq = 0; cq < CQ; ++cq) {
-            f32x4 v = acc[0][cq];
+            f32x4 v = acc[NCLS - 1][cq];
             if (a.accumulate && vox_ok) v += *(const f32x4*)(op + 4 * cq);
 #pragma unroll
             for (int j = 0; j < 4; ++j) piv[4 * cq + j] = wave_lane_value(v[j], src);
@@ -166,30 +192,50 @@ __global__ __launch_bounds__(256, 1) void tdeconv_kernel(TDeconvArgs a) {
         }
       }
     }
-    if (vox_ok) {
+    auto store_rows = [&](auto RC) {
+      constexpr int rc = decltype(RC)::value;
+      constexpr int pz = (NTY == 3) ? (rc >> 1) & 1 : rc & 1;
+      constexpr int py = (NTY == 3) ? rc & 1 : 0;
+      float* rb = a.out + (((size_t)n * (2 * a.Z) + (2 * z + pz)) * ((NTY == 3) ? 2 * a.Y : 1) + py) * (size_t)(2 * a.X) * a.out_cs;
+      f32x4 old[U];
+      if (a.accumulate) {
 #pragma unroll
-      for (int c = 0; c < NCLS; ++c) {
-        const int pz = (NTY == 3) ? (c >> 2) & 1 : (c >> 1) & 1;
-        const int py = (NTY == 3) ? (c >> 1) & 1 : 0;
-        const int px = c & 1;
-        float* op = a.out + ((((size_t)n * (2 * a.Z) + (2 * z + pz)) * ((NTY == 3) ? 2 * a.Y : 1) + (2 * gy + py)) *
-                                 (2 * a.X) + (2 * gx + px)) * a.out_cs;
+        for (int i = 0; i < U; ++i) old[i] = xok[i] ? *(const f32x4*)(rb + xoff[i]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
-        for (int cq = 0; cq < CQ; ++cq) {
-          f32x4 v = acc[c][cq];
-          if (a.accumulate) v += *(f32x4*)(op + 4 * cq);
-          *(f32x4*)(op + 4 * cq) = v;
-          if constexpr (STATS) {
+      for (int px = 0; px < 2; ++px)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float d = v[j] - piv[4 * cq + j];
-              s1[4 * cq + j] += d;
-              s2[4 * cq + j] = __builtin_fmaf(d, d, s2[4 * cq + j]);
+        for (int cq = 0; cq < CQ; ++cq) *(f32x4*)(xl + lane * XS + 4 * (px * CQ + cq)) = acc[2 * rc + px][cq];
+#pragma unroll
+      for (int i = 0; i < U; ++i) {
+        f32x4 v = *(const f32x4*)(xl + xsrc[i]);
+        if (a.accumulate) {
+          v += old[i];
+          if constexpr (STATS) *(f32x4*)(xl + xsrc[i]) = v;   // the owner lane sums the moments of what is stored
+        }
+        if (xok[i]) *(f32x4*)(rb + xoff[i]) = v;
+      }
+      if constexpr (STATS) {
+        if (vox_ok) {
+#pragma unroll
+          for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int cq = 0; cq < CQ; ++cq) {
+              f32x4 v = acc[2 * rc + px][cq];
+              if (a.accumulate) v = *(const f32x4*)(xl + lane * XS + 4 * (px * CQ + cq));
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float d = v[j] - piv[4 * cq + j];
+                s1[4 * cq + j] += d;
+                s2[4 * cq + j] = __builtin_fmaf(d, d, s2[4 * cq + j]);
+              }
             }
-          }
         }
       }
-    }
+    };
+    static_for<NCLS / 4>([&](auto I) { store_rows(std::integral_constant<int, NCLS / 4 + decltype(I)::value>{}); });
+    run_offsets(std::integral_constant<int, 1>{});
+    static_for<NCLS / 4>([&](auto I) { store_rows(I); });
     stage_store((z + 1) % 3);
     __syncthreads();
   }
