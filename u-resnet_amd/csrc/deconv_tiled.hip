@@ -65,8 +65,7 @@ static bool make_dplan(const ursn_conv_desc& d, ConvPass pass, TDPlan& p, DBlock
   p.ck = 16;
   p.cp = b.pb;
   const int PX = TX + 1, PY = TY + (p.mode == 3 ? 1 : 0);
-  // 3 ring planes + per wave the exchange buffer of the line-contiguous stores (2 * cp / 4 + 1 sixteen-byte units per lane)
-  p.lds = (size_t)3 * (p.ck / 4) * PX * PY * 16 + (size_t)256 * (2 * (p.cp / 4) + 1) * 16;
+  p.lds = (size_t)3 * (p.ck / 4) * PX * PY * 16;
   return p.lds <= 160 * 1024;
 }
 

@@ -12,12 +12,34 @@
 // exactly as in conv_tiled_kernel.h.  Every lane stores 2 x-adjacent output voxels per (pz,py): 64 contiguous
 // bytes at Cp = 8, instead of the eight stride-2 scatter launches of the generic path.
 //
-// Round 4: those 64 bytes used to leave as four 16-byte stores with a 64-byte lane stride -- every store instruction touched 32
-// lines with 32 bytes each, and the ablation (tools/td_ablate.sh) priced the stores at 0.17 of the layer's 0.43 ms (stores +
-// loads alone: 0.32 ms for 906 MB = 2.8 TB/s).  Now a wave passes each output row class through a 5 KB LDS buffer of its own
-// and lane l stores unit 64 i + l of the wave's row segment: every instruction writes whole lines.
+// Round 4: those 64 bytes used to leave as four 16-byte stores with a 64-byte lane stride -- every store instruction touched
+// all 64 half-lines of the wave's row segment with 16 bytes each, and the ablation (tools/td_ablate.sh) priced the stores at
+// 0.17 of the layer's 0.43 ms (stores + loads alone: 0.32 ms for 906 MB = 2.8 TB/s).  Now the four lanes of a quad transpose
+// their 4 x 4 sixteen-byte units in registers (two DPP butterfly stages, VALU work in the shadow of the MFMAs) and store
+// instruction i of lane q carries unit q of lane i: 64 contiguous bytes per quad and instruction.  (A per-wave LDS exchange
+// that makes whole 1 KB runs was measured first: 0.427 -> 0.375 ms, its ds_write / ds_read round trips cost the MFMA phase
+// 0.10 of the 0.15 ms it saves.)
 #pragma once
 #include "conv_tiled_kernel.h"
+
+// 2 x 2 block exchange between lanes l and l ^ 1 (CTRL 0xB1 = quad_perm [1,0,3,2]) or l ^ 2 (0x4E = [2,3,0,1]): lanes with the bit
+// clear keep `lo` and receive the partner's `lo` into `hi`; lanes with the bit set keep `hi` and receive the partner's `hi` into `lo`
+template <int CTRL>
+__device__ __forceinline__ void td_quad_swap(f32x4& lo, f32x4& hi, bool bit) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float send = bit ? lo[j] : hi[j];
+    const float r = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), CTRL, 0xf, 0xf, true));
+    if (bit) lo[j] = r; else hi[j] = r;
+  }
+}
+// r[i] of lane q (= lane & 3) becomes r[q] of lane i of the same quad
+__device__ __forceinline__ void td_quad_transpose(f32x4 (&r)[4], int q) {
+  td_quad_swap<0xB1>(r[0], r[1], q & 1);
+  td_quad_swap<0xB1>(r[2], r[3], q & 1);
+  td_quad_swap<0x4E>(r[0], r[2], q & 2);
+  td_quad_swap<0x4E>(r[1], r[3], q & 2);
+}
 
 struct TDeconvArgs {
   const float* in;   // low-res [N][Z][Y][X][in_cs]
@@ -31,8 +53,9 @@ struct TDeconvArgs {
   int cp_w, ck_w;    // stored weight dims
 };
 
-// CK = contracted channels, CP = produced channels
-template <int CK, int CP, int MODE, bool STATS>
+// CK = contracted channels, CP = produced channels; ACC: a.accumulate, compiled in (with a run-time flag the compiler joined the
+// two paths in front of an s_waitcnt vmcnt(0) in the middle of every plane: all stores and the staged plane drained there)
+template <int CK, int CP, int MODE, bool STATS, bool ACC>
 __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_kernel(TDeconvArgs a) {
   using TL = Tile<MODE>;
   constexpr int TX = TL::TX, TY = TL::TY, NTY = TL::NTY, NT = TL::NT;
@@ -118,23 +141,23 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
 
   const int lane_slot = (ty + HY) * PX + tx + 1;   // the lane's own voxel inside a plane
 
-  // line-contiguous stores: a lane owns U = 2 * CQ sixteen-byte units per output row class (2 x-adjacent voxels x CQ quads);
-  // store instruction i of lane l carries unit 64 i + l of the wave = slot (64 i + l) % U of lane (64 i + l) / U
-  constexpr int U = 2 * CQ, XS = 4 * U + 4;        // floats per lane in the exchange buffer (one unit of padding)
-  float* xl = (float*)(dlds + 3 * NQ * PS) + (tid >> 6) * 64 * XS;
-  int xsrc[U], xoff[U];
-  bool xok[U];
+  // line-contiguous stores: a lane owns 2 * CQ sixteen-byte units per output row class (2 x-adjacent voxels x CQ quads).  After
+  // the quad transpose, register i of lane q holds unit q of lane i (CQ = 2: unit = (px, cq) = (q >> 1, q & 1) of one transpose;
+  // CQ = 4: unit = cq of one transpose per px)
+  static_assert(CQ == 2 || CQ == 4, "quad transpose of the stores: 8 or 16 produced channels");
+  constexpr int NXP = CQ / 2;                       // transposes per row class
+  const int qd = lane & 3;
+  int xoff[4];
+  bool xok[4];
 #pragma unroll
-  for (int i = 0; i < U; ++i) {
-    const int u = 64 * i + lane, sl = u / U, slot = u % U;
-    const int st = (tid & ~63) + sl;                // the owner's thread index
-    const int sy = y0 + st / TX, sx = x0 + st % TX;
-    xsrc[i] = sl * XS + 4 * slot;
-    xoff[i] = ((NTY == 3 ? 2 * sy * (2 * a.X) : 0) + 2 * sx + slot / CQ) * a.out_cs + 4 * (slot % CQ);
-    xok[i] = sy < a.Y && sx < a.X;
+  for (int i = 0; i < 4; ++i) {
+    const int sx = gx - qd + i;                     // the owner's voxel (quads never straddle a tile row)
+    xoff[i] = ((NTY == 3 ? 2 * gy * (2 * a.X) : 0) + 2 * sx + (CQ == 2 ? qd >> 1 : 0)) * a.out_cs + 4 * (CQ == 2 ? qd & 1 : qd);
+    xok[i] = gy < a.Y && sx < a.X;
   }
   for (int z = z0; z < z1; ++z) {
     stage_load(z + 1);
+    __builtin_amdgcn_sched_barrier(0);   // the loads stay here: two thirds of the plane's MFMAs ahead of their LDS stores
     f32x4 acc[NCLS][CQ];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c)
@@ -177,6 +200,10 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
     });
     };
     run_offsets(std::integral_constant<int, 0>{});
+    // the staged plane goes to its ring slot (read by nobody during this plane) BEFORE this plane's stores: the stores sit under
+    // lane-validity branches, so the compiler cannot count them and waits vmcnt(0) for the staged registers -- placed behind
+    // the stores that wait drained all 16 of them at the end of every plane
+    stage_store((z + 1) % 3);
     if constexpr (STATS) {
       if (z == z0 && a.stats_partial) {   // wave-uniform, once: the pivots = the first valid lane's all-odd outputs of this plane
         const int src = wave_first_valid(vox_ok);
@@ -185,7 +212,7 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
 #pragma unroll
           for (int cq = 0; cq < CQ; ++cq) {
             f32x4 v = acc[NCLS - 1][cq];
-            if (a.accumulate && vox_ok) v += *(const f32x4*)(op + 4 * cq);
+            if (ACC && vox_ok) v += *(const f32x4*)(op + 4 * cq);
 #pragma unroll
             for (int j = 0; j < 4; ++j) piv[4 * cq + j] = wave_lane_value(v[j], src);
           }
@@ -197,32 +224,15 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
       constexpr int pz = (NTY == 3) ? (rc >> 1) & 1 : rc & 1;
       constexpr int py = (NTY == 3) ? rc & 1 : 0;
       float* rb = a.out + (((size_t)n * (2 * a.Z) + (2 * z + pz)) * ((NTY == 3) ? 2 * a.Y : 1) + py) * (size_t)(2 * a.X) * a.out_cs;
-      f32x4 old[U];
-      if (a.accumulate) {
-#pragma unroll
-        for (int i = 0; i < U; ++i) old[i] = xok[i] ? *(const f32x4*)(rb + xoff[i]) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int px = 0; px < 2; ++px)
-#pragma unroll
-        for (int cq = 0; cq < CQ; ++cq) *(f32x4*)(xl + lane * XS + 4 * (px * CQ + cq)) = acc[2 * rc + px][cq];
-#pragma unroll
-      for (int i = 0; i < U; ++i) {
-        f32x4 v = *(const f32x4*)(xl + xsrc[i]);
-        if (a.accumulate) {
-          v += old[i];
-          if constexpr (STATS) *(f32x4*)(xl + xsrc[i]) = v;   // the owner lane sums the moments of what is stored
-        }
-        if (xok[i]) *(f32x4*)(rb + xoff[i]) = v;
-      }
       if constexpr (STATS) {
-        if (vox_ok) {
+        // moments on the owner lanes, before the transpose (an accumulated output: the old values in owner layout)
 #pragma unroll
-          for (int px = 0; px < 2; ++px)
+        for (int px = 0; px < 2; ++px)
 #pragma unroll
-            for (int cq = 0; cq < CQ; ++cq) {
-              f32x4 v = acc[2 * rc + px][cq];
-              if (a.accumulate) v = *(const f32x4*)(xl + lane * XS + 4 * (px * CQ + cq));
+          for (int cq = 0; cq < CQ; ++cq) {
+            f32x4& v = acc[2 * rc + px][cq];
+            if (ACC && vox_ok) v += *(const f32x4*)(rb + ((NTY == 3 ? 2 * gy * (2 * a.X) : 0) + 2 * gx + px) * a.out_cs + 4 * cq);
+            if (vox_ok) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 const float d = v[j] - piv[4 * cq + j];
@@ -230,13 +240,30 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
                 s2[4 * cq + j] = __builtin_fmaf(d, d, s2[4 * cq + j]);
               }
             }
+          }
+      }
+#pragma unroll
+      for (int h = 0; h < NXP; ++h) {               // CQ = 4: h = px
+        const int hoff = (CQ == 4) ? h * a.out_cs : 0;
+        f32x4 old[4];
+        if (!STATS && ACC) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) old[i] = xok[i] ? *(const f32x4*)(rb + hoff + xoff[i]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = (CQ == 2) ? acc[2 * rc + (i >> 1)][i & 1] : acc[2 * rc + h][i];
+        td_quad_transpose(r, qd);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (!STATS && ACC) r[i] += old[i];
+          if (xok[i]) *(f32x4*)(rb + hoff + xoff[i]) = r[i];
         }
       }
     };
     static_for<NCLS / 4>([&](auto I) { store_rows(std::integral_constant<int, NCLS / 4 + decltype(I)::value>{}); });
     run_offsets(std::integral_constant<int, 1>{});
     static_for<NCLS / 4>([&](auto I) { store_rows(I); });
-    stage_store((z + 1) % 3);
     __syncthreads();
   }
 
@@ -260,9 +287,9 @@ struct TDPlan {
   int grid;
 };
 
-template <int CK, int CP, int MODE, bool STATS>
+template <int CK, int CP, int MODE, bool STATS, bool ACC>
 static int launch_td(const TDPlan& p, const TDeconvArgs& a, hipStream_t s) {
-  auto kern = tdeconv_kernel<CK, CP, MODE, STATS>;
+  auto kern = tdeconv_kernel<CK, CP, MODE, STATS, ACC>;
   static size_t attr_lds = 48 * 1024;
   if (p.lds > attr_lds) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
@@ -276,7 +303,8 @@ static int launch_td(const TDPlan& p, const TDeconvArgs& a, hipStream_t s) {
 #define URSN_TD(ck_, cp_)                                                                        \
   if (p.ck == ck_ && p.cp == cp_) {                                                              \
     ursn_note_kernel("tdeconv<" #ck_ "," #cp_ ">");                                              \
-    return a.stats_partial ? launch_td<ck_, cp_, MODE, true>(p, a, s) : launch_td<ck_, cp_, MODE, false>(p, a, s); \
+    if (a.accumulate) return a.stats_partial ? launch_td<ck_, cp_, MODE, true, true>(p, a, s) : launch_td<ck_, cp_, MODE, false, true>(p, a, s); \
+    return a.stats_partial ? launch_td<ck_, cp_, MODE, true, false>(p, a, s) : launch_td<ck_, cp_, MODE, false, false>(p, a, s); \
   }
 
 int tdeconv_dispatch_3d(const TDPlan& p, const TDeconvArgs& a, hipStream_t s);
