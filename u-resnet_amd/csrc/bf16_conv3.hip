@@ -81,7 +81,9 @@ struct B3Args {
 // per CU (URSN_B3CONV_PF2, round 2: slower).  The wait that ends an iteration counts this wave's own younger VM operations
 // exactly (its stores of the plane just completed, the DMAs of the planes behind the next one), so it never drains the ring.
 template <int CI, int CO, bool STATS, bool PW = false, int BS = 0, bool AFF = false, bool DMA = false>
-__global__ __launch_bounds__(256, (BS == 1 || (CI == 8 && CO == 8 && BS == 0)) ? 3 : 2) void b3conv_kernel(B3Args a) {
+// (BS == 1 on the DMA path -- opt-in, URSN_B3CONV_BS_DMA -- stays at two waves per SIMD: at three it spills 80 bytes per lane, and
+// compiler-placed scratch traffic between a DMA and its hand-counted s_waitcnt vmcnt(N) would make that count too loose)
+__global__ __launch_bounds__(256, ((BS == 1 && !DMA) || (CI == 8 && CO == 8 && BS == 0)) ? 3 : 2) void b3conv_kernel(B3Args a) {
   static_assert(!AFF || (!PW && BS == 0), "normalise-on-load: plain forward instantiations");
   static_assert(!DMA || (!AFF && !PW), "LDS-DMA staging: no transform on the way in (the BS operands belong to the epilogue)");
   using G = B3<CI, CO>;
