@@ -13,6 +13,7 @@
 
 #include "bf16_common.h"
 #include "bf16_pack.h"
+#include "buffer_stage.h"
 
 namespace {
 
@@ -37,7 +38,8 @@ struct D3Args {
   int accumulate;
 };
 
-template <bool STATS>
+// ACC: a.accumulate, compiled in (a run-time flag puts uniform branches with loads between the counted accesses)
+template <bool STATS, bool ACC>
 __global__ __launch_bounds__(256, 2) void bdeconv_kernel(D3Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * D3_PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -59,32 +61,30 @@ __global__ __launch_bounds__(256, 2) void bdeconv_kernel(D3Args a) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) A[e][mt] = *(const bfx8*)(a.wp + ((size_t)((e * 2 + mt) * 64 + lane)) * 8);
 
-  int srel[D3_NST];
-  unsigned sval = 0;
+  // Every global access of the plane loop is a buffer instruction with a per-lane byte offset (out-of-range elements: the
+  // URSN_OOB_BYTES marker, read as zeros / dropped by the bounds check) -- no lane-validity branch around any of them, so the
+  // compiler counts them and waits for the staged plane with vmcnt(stores issued since), not vmcnt(0).  Round 3 had the branches:
+  // each plane (32 MFMAs = 0.4 us) ended by draining its 16 output stores before the next plane's 10 KB could go to LDS.
+  unsigned soffb[D3_NST];
 #pragma unroll
   for (int i = 0; i < D3_NST; ++i) {
     const int idx = tid + 256 * i;
-    srel[i] = 0;
+    soffb[i] = URSN_OOB_BYTES;
     if (idx < D3_PIECES) {
       const int vi = idx >> 1, hp = idx & 1;
       const int yy = vi / D3_PX, xx = vi - yy * D3_PX;
       const int gy = y0 + yy + a.dmin[1], gx = x0 + xx + a.dmin[2];
-      if (gy >= 0 && gy < a.Yc && gx >= 0 && gx < a.Xc) {
-        sval |= 1u << i;
-        srel[i] = (gy * a.Xc + gx) * a.in_cs + hp * 8;
-      }
+      if (gy >= 0 && gy < a.Yc && gx >= 0 && gx < a.Xc) soffb[i] = (unsigned)((gy * a.Xc + gx) * a.in_cs + hp * 8) * 2u;
     }
   }
+  const size_t in_plane = (size_t)a.Yc * a.Xc * a.in_cs;
+  const unsigned in_plane_bytes = (unsigned)(in_plane * 2);
   u32x4 st[D3_NST];
-  auto stage_load = [&](int p) {   // coarse plane p
+  auto stage_load = [&](int p) {   // coarse plane p (outside the volume or the segment's reach: zeros, no traffic)
     const bool pz = p >= 0 && p < a.Zc;
-    const bf16_t* base = a.in + ((size_t)n * a.Zc + (pz ? p : 0)) * a.Yc * a.Xc * a.in_cs;
+    const __amdgpu_buffer_rsrc_t r = ursn_rsrc(a.in + ((size_t)n * a.Zc + (pz ? p : 0)) * in_plane, pz ? in_plane_bytes : 0u);
 #pragma unroll
-    for (int i = 0; i < D3_NST; ++i) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (pz && ((sval >> i) & 1u)) v = *(const u32x4*)(base + srel[i]);
-      st[i] = v;
-    }
+    for (int i = 0; i < D3_NST; ++i) st[i] = ursn_bload_b128(r, soffb[i]);
   };
   auto stage_store = [&](int slot) {
 #pragma unroll
@@ -101,37 +101,54 @@ __global__ __launch_bounds__(256, 2) void bdeconv_kernel(D3Args a) {
 
   float piv[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, nacc = 0.f;
 
-  // coarse plane P lives in slot P mod 3 (P >= -1): iteration qz reads planes qz + dmin_z and qz + dmin_z + 1
+  // coarse plane P lives in slot P mod 3 (P >= -1): iteration qz reads planes pl = qz + dmin_z and pl + 1.  Before the loop planes
+  // pl .. pl + 2 are in LDS and pl + 3 is requested; an iteration ENDS by putting the plane requested one iteration ago into the
+  // slot it has just finished with and requesting the next one.  With the staging at the end of the body the loop header sees the
+  // same pending accesses from the prologue and from the back edge (three loads, youngest), so the compiler waits for them with
+  // vmcnt(16): the iteration's 16 output stores stay in flight.  (Staged at the top -- round 3 -- the two paths disagree and
+  // the wait is vmcnt(0): every plane, 32 MFMAs = 0.4 us, drained its stores before 10 KB went to LDS.)
   const int pz0 = z0 + a.dmin[0];
   stage_load(pz0);
   stage_store((pz0 + 3) % 3);
   stage_load(pz0 + 1);
   stage_store((pz0 + 4) % 3);
+  stage_load(z0 + 1 < z1 ? pz0 + 2 : -1);
+  stage_store((pz0 + 5) % 3);
+  stage_load(z0 + 2 < z1 ? pz0 + 3 : -1);
   __syncthreads();
+  // fine-plane resources and the lane's offsets inside a fine plane, per row of the wave
+  const size_t out_plane = (size_t)(2 * a.Yc) * (2 * a.Xc) * a.out_cs;
+  const unsigned out_plane_bytes = (unsigned)(out_plane * 2);
+  unsigned ooff[D3_RPW];
+#pragma unroll
+  for (int rr = 0; rr < D3_RPW; ++rr) {
+    const int gy = y0 + D3_RPW * wave + rr, gx = x0 + c;
+    ooff[rr] = (gy < a.Yc && gx < a.Xc) ? (unsigned)((2 * gy * (2 * a.Xc) + 2 * gx) * a.out_cs + h * 4) * 2u : URSN_OOB_BYTES;
+  }
+  const unsigned oy = (unsigned)(2 * a.Xc * a.out_cs) * 2u, ox = (unsigned)a.out_cs * 2u;
+  auto out_rsrc = [&](int qz_, int pz) {
+    return ursn_rsrc(a.out + ((size_t)n * (2 * a.Zc) + 2 * qz_ + pz) * out_plane, out_plane_bytes);
+  };
   // accumulate: the old values of a row are requested one row ahead of their use (read inside the epilogue -- a load behind every
   // store of the previous class -- the data gradient of the stride-2 conv took 0.58 ms instead of 0.26 + the 0.18 of the extra read)
   u32x2 exn[8];
-  auto old_addr = [&](int qz_, int rr_, int cl) {
-    const int pz = cl >> 2, py = (cl >> 1) & 1, px = cl & 1;
-    const int gy = y0 + D3_RPW * wave + rr_, gx = x0 + c;
-    return (u32x2*)(a.out + ((((size_t)n * (2 * a.Zc) + 2 * qz_ + pz) * (2 * a.Yc) + 2 * gy + py) * (size_t)(2 * a.Xc) + 2 * gx + px) * a.out_cs + h * 4);
-  };
   auto old_load = [&](int qz_, int rr_) {
-    const int gy = y0 + D3_RPW * wave + rr_, gx = x0 + c;
+    const __amdgpu_buffer_rsrc_t r0 = out_rsrc(qz_, 0), r1 = out_rsrc(qz_, 1);
 #pragma unroll
-    for (int cl = 0; cl < 8; ++cl) exn[cl] = (gy < a.Yc && gx < a.Xc) ? *old_addr(qz_, rr_, cl) : (u32x2){0u, 0u};
+    for (int cl = 0; cl < 8; ++cl)
+      exn[cl] = ursn_bload_b64((cl >> 2) ? r1 : r0, ooff[rr_] + ((cl >> 1) & 1) * oy + (cl & 1) * ox);
   };
-  if (a.accumulate) old_load(z0, 0);
+  if constexpr (ACC) old_load(z0, 0);
   for (int qz = z0; qz < z1; ++qz) {
     const int pl = qz + a.dmin[0];
-    if (qz + 1 < z1) stage_load(pl + 2);
     const unsigned sb0 = (unsigned)(((pl + 3) % 3) * D3_PLANE), sb1 = (unsigned)(((pl + 4) % 3) * D3_PLANE);
+    const __amdgpu_buffer_rsrc_t ro0 = out_rsrc(qz, 0), ro1 = out_rsrc(qz, 1);
 #pragma unroll
     for (int rr = 0; rr < D3_RPW; ++rr) {
       u32x2 exo[8];
 #pragma unroll
       for (int cl = 0; cl < 8; ++cl) exo[cl] = exn[cl];
-      if (a.accumulate) {
+      if constexpr (ACC) {
         if (rr + 1 < D3_RPW) old_load(qz, rr + 1);
         else if (qz + 1 < z1) old_load(qz + 1, 0);
       }
@@ -144,25 +161,23 @@ __global__ __launch_bounds__(256, 2) void bdeconv_kernel(D3Args a) {
         cc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[e][0], b, cc[0], 0, 0, 0);
         cc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[e][1], b, cc[1], 0, 0, 0);
       }
-      const int gy = y0 + D3_RPW * wave + rr, gx = x0 + c;
-      if (gy < a.Yc && gx < a.Xc) {
+      const bool lane_ok = ooff[rr] != URSN_OOB_BYTES;
 #pragma unroll
-        for (int cl = 0; cl < 8; ++cl) {   // class (pz, py, px) = bits of cl: register block (cl & 3) of tile cl >> 2, channels 4 h ..
-          const int pz = cl >> 2, py = (cl >> 1) & 1, px = cl & 1;
-          float v[4];
+      for (int cl = 0; cl < 8; ++cl) {   // class (pz, py, px) = bits of cl: register block (cl & 3) of tile cl >> 2, channels 4 h ..
+        float v[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = cc[cl >> 2][(cl & 3) * 4 + i];
-          u32x2* o = (u32x2*)(a.out + ((((size_t)n * (2 * a.Zc) + 2 * qz + pz) * (2 * a.Yc) + 2 * gy + py) * (size_t)(2 * a.Xc) + 2 * gx + px) * a.out_cs + h * 4);
-          if (a.accumulate) {
-            const u32x2 ex = exo[cl];
-            v[0] += __uint_as_float(ex[0] << 16); v[1] += __uint_as_float(ex[0] & 0xffff0000u);
-            v[2] += __uint_as_float(ex[1] << 16); v[3] += __uint_as_float(ex[1] & 0xffff0000u);
-          }
-          u32x2 pk;
-          pk[0] = pack_bf2(v[0], v[1]);
-          pk[1] = pack_bf2(v[2], v[3]);
-          *o = pk;
-          if constexpr (STATS) {
+        for (int i = 0; i < 4; ++i) v[i] = cc[cl >> 2][(cl & 3) * 4 + i];
+        if constexpr (ACC) {
+          const u32x2 ex = exo[cl];
+          v[0] += __uint_as_float(ex[0] << 16); v[1] += __uint_as_float(ex[0] & 0xffff0000u);
+          v[2] += __uint_as_float(ex[1] << 16); v[3] += __uint_as_float(ex[1] & 0xffff0000u);
+        }
+        u32x2 pk;
+        pk[0] = pack_bf2(v[0], v[1]);
+        pk[1] = pack_bf2(v[2], v[3]);
+        ursn_bstore_b64(pk, (cl >> 2) ? ro1 : ro0, ooff[rr] + ((cl >> 1) & 1) * oy + (cl & 1) * ox);
+        if constexpr (STATS) {
+          if (lane_ok) {
             const float rv[4] = {__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xffff0000u),
                                  __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xffff0000u)};
 #pragma unroll
@@ -175,8 +190,9 @@ __global__ __launch_bounds__(256, 2) void bdeconv_kernel(D3Args a) {
         }
       }
     }
-    if (qz + 1 < z1) stage_store((pl + 5) % 3);
     __syncthreads();
+    stage_store((pl + 3) % 3);   // plane pl + 3 (zeros past the segment) into the slot of plane pl
+    stage_load(qz + 3 < z1 ? pl + 4 : -1);
   }
 
   if constexpr (STATS) {
@@ -227,7 +243,8 @@ bool d3_plan(const GatherGeom* g, int cnt, D3Plan& p) {
       for (int j = 0; j < 3; ++j)
         if (g[i].tap_d[t][j] - p.dmin[j] > 1) return false;
   const int Zc = g0.in_d[0], Yc = g0.in_d[1], Xc = g0.in_d[2];
-  if ((int64_t)Yc * Xc * g0.in_cs >= ((int64_t)1 << 31)) return false;
+  // buffer path: a coarse plane and a fine plane stay below the out-of-range marker (and marker + an in-plane offset below 2^32)
+  if ((int64_t)Yc * Xc * g0.in_cs * 2 >= (int64_t)URSN_OOB_BYTES || (int64_t)Yc * Xc * 4 * g0.out_cs * 2 >= (int64_t)URSN_OOB_BYTES) return false;
   p.ntx = (Xc + 31) / 32;
   p.nty = (Yc + D3_TY - 1) / D3_TY;
   const int64_t tiles = (int64_t)g0.N * p.nty * p.ntx;
@@ -271,8 +288,10 @@ int launch_bdeconv(const GatherGeom* g, int cnt, const bf16_t* in, const float* 
   a.zseg = p.zseg; a.nzseg = p.nzseg; a.nty = p.nty; a.ntx = p.ntx;
   a.accumulate = accumulate;
   ursn_note_kernel("bdeconv_bf16<16,8>");
-  if (stats_partial) hipLaunchKernelGGL(bdeconv_kernel<true>, dim3(p.grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(bdeconv_kernel<false>, dim3(p.grid), dim3(256), 0, s, a);
+  if (stats_partial && accumulate) hipLaunchKernelGGL((bdeconv_kernel<true, true>), dim3(p.grid), dim3(256), 0, s, a);
+  else if (stats_partial) hipLaunchKernelGGL((bdeconv_kernel<true, false>), dim3(p.grid), dim3(256), 0, s, a);
+  else if (accumulate) hipLaunchKernelGGL((bdeconv_kernel<false, true>), dim3(p.grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((bdeconv_kernel<false, false>), dim3(p.grid), dim3(256), 0, s, a);
   URSN_HIP(hipGetLastError());
   return 0;
 }

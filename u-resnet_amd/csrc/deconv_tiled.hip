@@ -47,7 +47,10 @@ static bool make_dplan(const ursn_conv_desc& d, ConvPass pass, TDPlan& p, DBlock
   else { p.Z = lo[0]; p.Y = 1; p.X = lo[1]; }
   const int TX = p.mode == 3 ? 32 : 256, TY = p.mode == 3 ? 8 : 1;
   if (p.X < TX / 2 || p.Y < TY || p.Z < 8) return false;
-  if ((int64_t)p.Y * p.X * ics * 4 >= (int64_t)0x80000000ll) return false;   // buffer-path staging: a plane below the out-of-range marker
+  // buffer path (staging loads, output stores): a low-res plane and a high-res plane stay below the out-of-range marker
+  const int lo_cs = fwd_t ? ics : ocs, hi_cs = fwd_t ? ocs : ics;
+  if ((int64_t)p.Y * p.X * lo_cs * 4 >= (int64_t)0x80000000ll) return false;
+  if ((int64_t)(p.mode == 3 ? 2 * p.Y : 1) * 2 * p.X * hi_cs * 4 >= (int64_t)0x80000000ll) return false;
   p.ntx = (p.X + TX - 1) / TX;
   p.nty = (p.Y + TY - 1) / TY;
   int64_t base = (int64_t)d.n * p.ntx * p.nty;

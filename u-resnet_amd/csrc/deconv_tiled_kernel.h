@@ -137,6 +137,9 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
   stage_store((z0 + 2) % 3);
   stage_load(z0);
   stage_store(z0 % 3);
+  stage_load(z0 + 1 < z1 ? z0 + 1 : -1);
+  stage_store((z0 + 1) % 3);
+  stage_load(z0 + 2 < z1 ? z0 + 2 : -1);
   __syncthreads();
 
   const int lane_slot = (ty + HY) * PX + tx + 1;   // the lane's own voxel inside a plane
@@ -147,17 +150,18 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
   static_assert(CQ == 2 || CQ == 4, "quad transpose of the stores: 8 or 16 produced channels");
   constexpr int NXP = CQ / 2;                       // transposes per row class
   const int qd = lane & 3;
-  int xoff[4];
-  bool xok[4];
+  unsigned xoff[4];   // byte offsets inside the (pz, py) row class of a fine plane; out-of-range owners: the marker, dropped by the
+                      // bounds check -- no lane-validity branch around the stores, so the compiler counts them (see the loop's end)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int sx = gx - qd + i;                     // the owner's voxel (quads never straddle a tile row)
-    xoff[i] = ((NTY == 3 ? 2 * gy * (2 * a.X) : 0) + 2 * sx + (CQ == 2 ? qd >> 1 : 0)) * a.out_cs + 4 * (CQ == 2 ? qd & 1 : qd);
-    xok[i] = gy < a.Y && sx < a.X;
+    const int e = ((NTY == 3 ? 2 * gy * (2 * a.X) : 0) + 2 * sx + (CQ == 2 ? qd >> 1 : 0)) * a.out_cs + 4 * (CQ == 2 ? qd & 1 : qd);
+    xoff[i] = (gy < a.Y && sx < a.X) ? (unsigned)e * 4u : URSN_OOB_OFFSET;
   }
+  // bytes from the first row of a (pz, py) class to the end of its fine plane (the resource of a class); the lane's own voxel pair
+  const unsigned out_rows_bytes = (unsigned)(((NTY == 3 ? 2 * a.Y : 1) * (2 * a.X)) * a.out_cs) * 4u;
+  const unsigned own_off = vox_ok ? (unsigned)(((NTY == 3 ? 2 * gy * (2 * a.X) : 0) + 2 * gx) * a.out_cs) * 4u : URSN_OOB_OFFSET;
   for (int z = z0; z < z1; ++z) {
-    stage_load(z + 1);
-    __builtin_amdgcn_sched_barrier(0);   // the loads stay here: two thirds of the plane's MFMAs ahead of their LDS stores
     f32x4 acc[NCLS][CQ];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c)
@@ -200,10 +204,6 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
     });
     };
     run_offsets(std::integral_constant<int, 0>{});
-    // the staged plane goes to its ring slot (read by nobody during this plane) BEFORE this plane's stores: the stores sit under
-    // lane-validity branches, so the compiler cannot count them and waits vmcnt(0) for the staged registers -- placed behind
-    // the stores that wait drained all 16 of them at the end of every plane
-    stage_store((z + 1) % 3);
     if constexpr (STATS) {
       if (z == z0 && a.stats_partial) {   // wave-uniform, once: the pivots = the first valid lane's all-odd outputs of this plane
         const int src = wave_first_valid(vox_ok);
@@ -224,6 +224,7 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
       constexpr int pz = (NTY == 3) ? (rc >> 1) & 1 : rc & 1;
       constexpr int py = (NTY == 3) ? rc & 1 : 0;
       float* rb = a.out + (((size_t)n * (2 * a.Z) + (2 * z + pz)) * ((NTY == 3) ? 2 * a.Y : 1) + py) * (size_t)(2 * a.X) * a.out_cs;
+      const __amdgpu_buffer_rsrc_t rr = ursn_plane_rsrc(rb, out_rows_bytes);
       if constexpr (STATS) {
         // moments on the owner lanes, before the transpose (an accumulated output: the old values in owner layout)
 #pragma unroll
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
 #pragma unroll
           for (int cq = 0; cq < CQ; ++cq) {
             f32x4& v = acc[2 * rc + px][cq];
-            if (ACC && vox_ok) v += *(const f32x4*)(rb + ((NTY == 3 ? 2 * gy * (2 * a.X) : 0) + 2 * gx + px) * a.out_cs + 4 * cq);
+            if constexpr (ACC) v += ursn_buffer_load_f4(rr, own_off + (unsigned)(px * a.out_cs + 4 * cq) * 4u);
             if (vox_ok) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -244,11 +245,11 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
       }
 #pragma unroll
       for (int h = 0; h < NXP; ++h) {               // CQ = 4: h = px
-        const int hoff = (CQ == 4) ? h * a.out_cs : 0;
+        const unsigned hoff = (CQ == 4) ? (unsigned)(h * a.out_cs) * 4u : 0u;
         f32x4 old[4];
         if (!STATS && ACC) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) old[i] = xok[i] ? *(const f32x4*)(rb + hoff + xoff[i]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int i = 0; i < 4; ++i) old[i] = ursn_buffer_load_f4(rr, hoff + xoff[i]);
         }
         f32x4 r[4];
 #pragma unroll
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (!STATS && ACC) r[i] += old[i];
-          if (xok[i]) *(f32x4*)(rb + hoff + xoff[i]) = r[i];
+          ursn_buffer_store_f4(rr, hoff + xoff[i], r[i]);
         }
       }
     };
@@ -265,6 +266,13 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
     run_offsets(std::integral_constant<int, 1>{});
     static_for<NCLS / 4>([&](auto I) { store_rows(I); });
     __syncthreads();
+    // a plane ENDS by putting the plane requested one plane ago into the slot of the plane it has just finished with (z - 1) and
+    // requesting the next one: with the staging here the loop header sees the same pending accesses from the prologue and from the
+    // back edge (the staged loads, youngest), and the compiler waits for them with vmcnt(this plane's stores) instead of
+    // vmcnt(0) -- staged at the top of the body the two paths disagree and every plane drained its 16 stores (round 3; with one
+    // wave per SIMD that was 0.1 of the pass's 0.43 ms)
+    stage_store((z + 2) % 3);
+    stage_load(z + 3 < z1 ? z + 3 : -1);
   }
 
   if constexpr (STATS) if (a.stats_partial) {
