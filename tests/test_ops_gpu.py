@@ -673,6 +673,38 @@ def test_tiled_dgrad_with_fused_shortcut_term(ndim, S, ci, co, split):
     assert lib.ursn_conv_forward(ctypes.byref(d), P(dev(x)), P(wg), P(yy), stream()) != 0
 
 
+@pytest.mark.parametrize("S,ci,co,cs", [((16, 32, 64), 8, 16, 0), ((18, 22, 74), 8, 16, 0), ((16, 16, 64), 8, 16, 24), ((16, 32, 64), 16, 16, 0)])
+def test_stride2_dgrad_with_fused_stride2_shortcut_term(S, ci, co, cs):
+    """dx of a unit's stride-2 resnet_conv1 AND of its 1x1 stride-2 shortcut (lib/resnet_module.py:25-43) in one launch of the
+    lane-per-low-res-voxel kernel (tdeconv + pw): the shortcut touches the even-even-even voxels only.  Overwrite and accumulate;
+    cs: channel stride of the shortcut's gradient tensor (0 = compact)."""
+    N, ndim = 2, 3
+    rng = np.random.default_rng(S[0] + S[2] + ci + cs)
+    x = _rand(rng, (N,) + S + (ci,))
+    w = _rand(rng, (3,) * ndim + (ci, co)) * 0.2
+    ws = _rand(rng, (1,) * ndim + (ci, co)) * 0.3
+    Slo = tuple((v + 1) // 2 for v in S)
+    dy, dys = _rand(rng, (N,) + Slo + (co,)), _rand(rng, (N,) + Slo + (co,))
+    dx = O.conv_bwd(x, w, 2, dy)[0] + O.conv_bwd(x, ws, 2, dys)[0]
+    wg, wsg, dyg = dev(w), dev(ws), dev(dy)
+    if cs:
+        wide = np.full((N,) + Slo + (cs,), np.nan, dtype=np.float32)
+        wide[..., :co] = dys
+        dysg = dev(wide)
+    else:
+        dysg = dev(dys)
+    d = desc(ndim, N, S, ci, co, 3, 2)
+    d.pw_dy, d.pw_w, d.pw_dy_cstride = dysg.data_ptr(), wsg.data_ptr(), cs
+    lib = _lib.load()
+    lib.ursn_last_kernel_name.restype = ctypes.c_char_p
+    for acc in (0, 1):
+        base = torch.full(x.shape, 1.0 if acc else float("nan"), dtype=torch.float32, device="cuda")
+        got = conv_backward_data(d, dyg, wg, x.shape, accumulate=acc, dx_init=base).cpu().numpy()
+        name = lib.ursn_last_kernel_name().decode()
+        assert name.startswith("tdeconv<16,") and name.endswith("+pw"), name
+        assert rel_err(got, dx + acc) < TOL
+
+
 @pytest.mark.parametrize("case", [(3, 2, (8, 16, 32), 32, 16), (3, 1, (5, 7, 19), 16, 16), (3, 1, (6, 6, 6), 64, 32),
                                   (2, 2, (24, 40), 32, 16), (2, 1, (17, 35), 16, 32)])
 def test_lds_scatter_transposed_conv_forward(case):

@@ -290,6 +290,8 @@ int conv_dispatch(const ursn_conv_desc& d, ConvPass pass, const float* in, const
   }
   if (d.pw_dy) {      // fused shortcut data gradient: all-taps implicit GEMM or tiled kernels
     URSN_REQUIRE(pass == PASS_DGRAD, "conv: fused pointwise term (pw_dy) applies to the data gradient only");
+    if (tiled_deconv_supported(d, pass))   // stride-2 resnet_conv1 + its stride-2 shortcut (level 0 / 1 of an F = 8 network)
+      return launch_tiled_deconv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
     if (!d.in_split && igemm_conv_supported(d, pass))
       return launch_igemm_conv(d, pass, in, w, out, accumulate, nullptr, 0.f, nullptr, nullptr, s);
     URSN_REQUIRE(tiled_conv_supported(d, pass), "conv: fused pointwise term (pw_dy) not supported for this shape");
@@ -590,6 +592,7 @@ extern "C" int ursn_conv_plan(const ursn_conv_desc* d0, int32_t pass_, char* out
     else name = "wgrad_mfma";
   } else {
     if (d.vdz_z || d.bs_partial || (d.in_mean && pass != PASS_DGRAD)) name = tiled_conv_supported(d, pass) ? "tconv" : "none";
+    else if (d.pw_dy && tiled_deconv_supported(d, pass)) name = "tdeconv+pw";
     else if (d.pw_dy) name = (!d.in_split && igemm_conv_supported(d, pass)) ? "igemm" : (tiled_conv_supported(d, pass) ? "tconv" : "none");
     else if (d.in_split) name = pointwise_conv_supported(d, pass, 0) ? "pconv" : (tiled_conv_supported(d, pass) ? "tconv" : "none");
     else if (pointwise_conv_supported(d, pass, 0)) name = "pconv";

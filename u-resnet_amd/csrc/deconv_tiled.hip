@@ -27,6 +27,7 @@ static bool make_dplan(const ursn_conv_desc& d, ConvPass pass, TDPlan& p, DBlock
   }
   // transposed conv forward, or data gradient of a k3 stride-2 conv
   if (d.in_split || d.in_mean) return false;
+  if (d.pw_dy && (pass != PASS_DGRAD || d.transposed || !d.pw_w)) return false;
   const bool fwd_t = d.transposed && pass == PASS_FWD;
   const bool dgrad_s2 = !d.transposed && d.k == 3 && d.stride == 2 && pass == PASS_DGRAD;
   if (!fwd_t && !dgrad_s2) return false;
@@ -65,6 +66,9 @@ static bool make_dplan(const ursn_conv_desc& d, ConvPass pass, TDPlan& p, DBlock
   b.nbk = ck / 16;
   b.nbp = cp / b.pb;
   if ((b.nbk > 1 || b.nbp > 1) && p.grid < 128 && d.algo != 3) return false;
+  // fused shortcut term: one launch (16 contracted, 8 | 16 produced channels), 3-D, compact-enough gradient tensor
+  if (d.pw_dy && (b.nbk != 1 || b.nbp != 1 || p.mode != 3 || (((d.pw_dy_cstride > 0 ? d.pw_dy_cstride : d.cout)) & 3) ||
+                  (int64_t)p.Y * p.X * (d.pw_dy_cstride > 0 ? d.pw_dy_cstride : d.cout) * 4 >= (int64_t)0x80000000ll)) return false;
   p.ck = 16;
   p.cp = b.pb;
   const int PX = TX + 1, PY = TY + (p.mode == 3 ? 1 : 0);
@@ -107,6 +111,8 @@ int launch_tiled_deconv(const ursn_conv_desc& d, ConvPass pass, const float* in,
   // W[k][produced][contracted]: transposed conv [k][cout][cin]; conv [k][cin][cout]
   a.cp_w = fwd_t ? d.cout : d.cin;
   a.ck_w = fwd_t ? d.cin : d.cout;
+  a.pw_in = d.pw_dy; a.pw_w = d.pw_w; a.pw_in_cs = d.pw_dy_cstride > 0 ? d.pw_dy_cstride : d.cout; a.pw_ws = d.cout;
+  URSN_REQUIRE(!d.pw_dy || !stats_partial, "tiled deconv: the fused shortcut term belongs to a plain data gradient");
   const int64_t V = (int64_t)d.n * p.Z * p.Y * p.X * (d.ndim == 3 ? 8 : 4);
   for (int bp = 0; bp < b.nbp; ++bp)
     for (int bk = 0; bk < b.nbk; ++bk) {

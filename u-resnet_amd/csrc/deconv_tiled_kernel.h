@@ -51,11 +51,17 @@ struct TDeconvArgs {
   int zseg, nzseg, nty, ntx;
   int accumulate;
   int cp_w, ck_w;    // stored weight dims
+  // PW instantiations (data gradient of a unit's stride-2 resnet_conv1, lib/resnet_module.py:25-43): + pw_in[q] . pw_w^T into the
+  // even-even-even output of low-res voxel q -- the data gradient of the unit's 1x1 stride-2 shortcut, which touches exactly
+  // those voxels (as a separate pass it re-read and re-wrote them: pconv_dgrad, 0.37 ms at 192^3)
+  const float* pw_in;   // [N][Z][Y][X][pw_in_cs], CK channels (the shortcut's dz)
+  const float* pw_w;    // [produced][contracted], row stride pw_ws
+  int pw_in_cs, pw_ws;
 };
 
 // CK = contracted channels, CP = produced channels; ACC: a.accumulate, compiled in (with a run-time flag the compiler joined the
 // two paths in front of an s_waitcnt vmcnt(0) in the middle of every plane: all stores and the staged plane drained there)
-template <int CK, int CP, int MODE, bool STATS, bool ACC>
+template <int CK, int CP, int MODE, bool STATS, bool ACC, bool PW = false>
 __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_kernel(TDeconvArgs a) {
   using TL = Tile<MODE>;
   constexpr int TX = TL::TX, TY = TL::TY, NTY = TL::NTY, NT = TL::NT;
@@ -97,6 +103,15 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
       }
   }
 
+  float wpw[PW ? CQ : 1];   // lane l holds Wsc[p = 4cq + (l&3)][c = l>>2]
+  if constexpr (PW) {
+    static_assert(CK == 16, "fused shortcut term: one 16-channel contraction block");
+#pragma unroll
+    for (int cq = 0; cq < CQ; ++cq) {
+      const int pch = 4 * cq + (lane & 3);
+      wpw[cq] = pch < a.cp_w ? a.pw_w[(size_t)pch * a.pw_ws + (lane >> 2)] : 0.f;
+    }
+  }
   // staging through buffer loads (buffer_stage.h): tabulated byte offsets, out-of-range elements read as 0
   f32x4 stage[NSTAGE];
   unsigned soff[NSTAGE];
@@ -127,6 +142,17 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
     }
   };
 
+  f32x4 pv[PW ? NQ : 1];   // the lane's own voxel of the shortcut gradient, requested one plane ahead
+  const ptrdiff_t pw_plane = PW ? (ptrdiff_t)a.Y * a.X * a.pw_in_cs : 0;
+  const unsigned pw_off = (PW && vox_ok) ? (unsigned)((gy * a.X + gx) * a.pw_in_cs) * 4u : URSN_OOB_OFFSET;
+  auto pw_load = [&](int zin) {
+    if constexpr (PW) {
+      const bool zok = zin >= 0 && zin < a.Z;
+      const __amdgpu_buffer_rsrc_t r = ursn_plane_rsrc(a.pw_in + ((ptrdiff_t)n * a.Z + (zok ? zin : 0)) * pw_plane, zok ? (unsigned)pw_plane * 4u : 0u);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) pv[q] = ursn_buffer_load_f4(r, pw_off + 16u * q);
+    }
+  };
   // BatchNorm moments around a wave-uniform pivot (wave_pivot.h): piv[] lives in SGPRs
   float s1[STATS ? CP : 1], s2[STATS ? CP : 1], piv[STATS ? CP : 1];
 #pragma unroll
@@ -140,6 +166,7 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
   stage_load(z0 + 1 < z1 ? z0 + 1 : -1);
   stage_store((z0 + 1) % 3);
   stage_load(z0 + 2 < z1 ? z0 + 2 : -1);
+  pw_load(z0);
   __syncthreads();
 
   const int lane_slot = (ty + HY) * PX + tx + 1;   // the lane's own voxel inside a plane
@@ -263,6 +290,15 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
       }
     };
     static_for<NCLS / 4>([&](auto I) { store_rows(std::integral_constant<int, NCLS / 4 + decltype(I)::value>{}); });
+    if constexpr (PW) {
+      static_for<CK>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        static_for<CQ>([&](auto C) {
+          constexpr int cq = decltype(C)::value;
+          acc[0][cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wpw[cq], pv[k / 4][k % 4], acc[0][cq], 4, k, 0);
+        });
+      });
+    }
     run_offsets(std::integral_constant<int, 1>{});
     static_for<NCLS / 4>([&](auto I) { store_rows(I); });
     __syncthreads();
@@ -273,6 +309,7 @@ __global__ __launch_bounds__(256, (CP <= 8 && MODE == 3) ? 2 : 1) void tdeconv_k
     // wave per SIMD that was 0.1 of the pass's 0.43 ms)
     stage_store((z + 2) % 3);
     stage_load(z + 3 < z1 ? z + 3 : -1);
+    pw_load(z + 1 < z1 ? z + 1 : -1);
   }
 
   if constexpr (STATS) if (a.stats_partial) {
@@ -295,9 +332,9 @@ struct TDPlan {
   int grid;
 };
 
-template <int CK, int CP, int MODE, bool STATS, bool ACC>
+template <int CK, int CP, int MODE, bool STATS, bool ACC, bool PW = false>
 static int launch_td(const TDPlan& p, const TDeconvArgs& a, hipStream_t s) {
-  auto kern = tdeconv_kernel<CK, CP, MODE, STATS, ACC>;
+  auto kern = tdeconv_kernel<CK, CP, MODE, STATS, ACC, PW>;
   static size_t attr_lds = 48 * 1024;
   if (p.lds > attr_lds) {
     URSN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
@@ -311,6 +348,10 @@ static int launch_td(const TDPlan& p, const TDeconvArgs& a, hipStream_t s) {
 #define URSN_TD(ck_, cp_)                                                                        \
   if (p.ck == ck_ && p.cp == cp_) {                                                              \
     ursn_note_kernel("tdeconv<" #ck_ "," #cp_ ">");                                              \
+    if (a.pw_in) {                                                                               \
+      ursn_note_kernel("tdeconv<" #ck_ "," #cp_ ">+pw");                                         \
+      return a.accumulate ? launch_td<ck_, cp_, MODE, false, true, true>(p, a, s) : launch_td<ck_, cp_, MODE, false, false, true>(p, a, s); \
+    }                                                                                            \
     if (a.accumulate) return a.stats_partial ? launch_td<ck_, cp_, MODE, true, true>(p, a, s) : launch_td<ck_, cp_, MODE, false, true>(p, a, s); \
     return a.stats_partial ? launch_td<ck_, cp_, MODE, true, false>(p, a, s) : launch_td<ck_, cp_, MODE, false, false>(p, a, s); \
   }

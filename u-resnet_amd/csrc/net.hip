@@ -825,6 +825,13 @@ int unit_bwd(ursn_net* n, Unit& u, int N, hipStream_t s, const BsTarget* in_targ
     fuse = !off && ((!in2 && igemm_conv_supported(d, PASS_DGRAD)) ||
                     (tiled_conv_supported(d, PASS_DGRAD) && !igemm_conv_supported(d0, PASS_DGRAD)));
   }
+  // stride-2 unit on the lane-per-low-res-voxel kernel: the shortcut's data gradient (it touches the even-even-even voxels only)
+  // rides in conv1's scatter-type data gradient (deconv_tiled_kernel.h, PW); URSN_FUSE_SHORTCUT_DGRAD_S2=0: the separate pass
+  if (u.sc >= 0 && n->layers[u.sc].stride == 2 && !in2) {
+    static const bool off2 = getenv("URSN_FUSE_SHORTCUT_DGRAD_S2") && getenv("URSN_FUSE_SHORTCUT_DGRAD_S2")[0] == '0';
+    ursn_conv_desc d = bwd_desc(n, u.c1, u.in, N, nullptr, u.sc);
+    fuse = !off2 && n->layers[u.sc].zcs == n->layers[u.sc].cout && tiled_deconv_supported(d, PASS_DGRAD);
+  }
   // conv1's data gradient is the LAST contribution to d(in) when the shortcut is the identity (the join wrote the first) or
   // rides in the same kernel: the consumer of d(in) named by the caller gets its reductions from this launch
   const BsTarget* tin = (in_target && (u.sc < 0 || fuse)) ? in_target : nullptr;
