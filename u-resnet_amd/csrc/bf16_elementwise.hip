@@ -7,8 +7,10 @@
 
 #include "bf16_common.h"
 
+// voxels (16-byte pieces per tensor) in flight per thread.  Round 4, A/B on one box at cfg5: 2 -> 4 takes bbn_bwd 11.65 -> 11.41 and
+// bbn_act 3.55 -> 3.50 ms per step (101.2 -> 102.6 images/s); 8: 11.80 / 3.83 (100.2)
 #ifndef URSN_BEW_U
-#define URSN_BEW_U 2
+#define URSN_BEW_U 4
 #endif
 
 namespace {
