@@ -65,7 +65,7 @@ SWITCHES = [
     ("bf16", {"URSN_BF16_FUSE_BN_BWD_REDUCE": "1"}),       # BatchNorm-backward reductions in the data-gradient epilogue
     ("bf16", {"URSN_B3CONV_PW": "0", "URSN_BF16_NORM_ON_LOAD": "0", "URSN_BF16_SKIP0_OWN": "0"}),   # no fused shortcut term, materialised activations, skip inside the concat buffer
     ("bf16", {"URSN_B3CONV": "0", "URSN_B3WGRAD": "0", "URSN_BDECONV": "0", "URSN_BPW": "0"}),      # generic kernels everywhere
-    ("fp32", {"URSN_FUSE_BN_BWD_REDUCE": "0", "URSN_FUSE_SHORTCUT_DGRAD": "0", "URSN_RELU_MASK": "0"}),
+    ("fp32", {"URSN_FUSE_BN_BWD_REDUCE": "0", "URSN_FUSE_SHORTCUT_DGRAD": "0", "URSN_FUSE_SHORTCUT_DGRAD_S2": "0", "URSN_RELU_MASK": "0"}),   # (the stride-2 shortcut's data gradient as its own pass too)
     ("fp32", {"URSN_SPLIT_CAT": "0", "URSN_NORM_ON_LOAD": "0"}),    # concat buffer, materialised resnet_conv1 activations
     ("fp32", {"URSN_DISABLE_TILED": "1", "URSN_WGRAD_STREAM": "0"}),
     ("fp32", {"URSN_S2CONV_V2": "2", "URSN_HEAD_BN_BWD": "0"}),   # stride-2 gather kernel with 16-byte operand reads on every layer it can take; logits-layer BatchNorm-backward sums as a separate pass
