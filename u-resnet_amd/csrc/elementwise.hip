@@ -24,6 +24,9 @@ template <> struct VT<4> { typedef f32x4 T; };
 #ifndef URSN_EW_U
 #define URSN_EW_U 2   // voxels (float4 per array) in flight per thread: 124-140 VGPRs in the BN-backward kernels (4: 196-228)
 #endif
+#ifndef URSN_EW_ACT_U
+#define URSN_EW_ACT_U 4   // the same for bn_act (74 VGPRs at 2)
+#endif
 template <int VEC> __device__ inline typename VT<VEC>::T ldv(const float* p) {
 #if URSN_EW_NT & 1
   return __builtin_nontemporal_load((const typename VT<VEC>::T*)p);
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a, int shift) {
   }
   // 4 voxels per iteration, all loads issued before the first use (the struct pointers may alias, so the
   // compiler will not hoist them itself): keeps 4x the bytes in flight per wave
-  constexpr int U = URSN_EW_U;
+  constexpr int U = URSN_EW_ACT_U;
   const int64_t stride = (int64_t)gridDim.x * VPB;
   for (int64_t v0 = (int64_t)blockIdx.x * VPB + vr; v0 < a.V; v0 += stride * U) {
     typename VT<VEC>::T x[U], x2[U], r[U];
