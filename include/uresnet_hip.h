@@ -184,8 +184,10 @@ typedef struct ursn_conv_desc {
   int32_t in2_cstride; /* channel stride of x2 / dx2; 0 = compact (= cin - in_split)                                   */
   const float* x2;     /* forward and weight gradient: second input tensor                                            */
   float* dx2;          /* data gradient: second output tensor                                                         */
-  /* Data gradient only: fused term of a parallel 1x1 stride-1 conv with the same cin/cout (the residual unit's shortcut,
-   * lib/resnet_module.py:25-33): dx (+)= conv^T(dy, w) + pw_dy . pw_w^T.  pw_dy = NULL: none.  k3 s1 tiled kernels only. */
+  /* Data gradient only: fused term of a parallel 1x1 conv with the same cin / cout and stride (the residual unit's shortcut,
+   * lib/resnet_module.py:25-33): dx (+)= conv^T(dy, w) + pw_dy . pw_w^T.  pw_dy = NULL: none.  k3 s1 layers on the tiled /
+   * all-taps kernels; fp32 k3 s2 layers 8 | 16 <- 16 channels on the lane-per-low-res-voxel kernel (the 1x1 stride-2 shortcut
+   * touches the even-even-even voxels only; deconv_tiled_kernel.h).  Any other shape with pw_dy set is refused. */
   const float* pw_dy;  /* [voxels][cout] gradient at the shortcut conv's output                                       */
   const float* pw_w;   /* [cin][cout] shortcut weights                                                                 */
   int32_t pw_dy_cstride; /* 0 = compact (= cout)                                                                       */
