@@ -351,14 +351,20 @@ static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
       p.grid = (int)((int64_t)d.n * p.nty * p.ntx);
     }
     const int py = ty + (p.mode == 3 ? 2 : 0);
-    p.lds = ((size_t)6 * PX * py * 8 + (size_t)4 * TX * ty * 8) * sizeof(float) + 256;
+    p.lds = ((size_t)6 * PX * py * 8 + (size_t)2 * TX * ty * 8) * sizeof(float) + 256;   // 6 x planes, 2 dz planes
     if (use_wgradq(d)) p.lds = ((size_t)4 * 6 * 8 * 48 + (size_t)2 * 4 * 8 * 48) * sizeof(float);   // QTile::LDS: 4 x planes, 2 dz planes, channel-major rows of 48
-    vg = 2;
+    // 3-D, plain input: 159 VGPRs and 46.5 KB would run THREE workgroups per CU (URSN_WGRADZ_OCC3=1).  Measured (round 4, three
+    // A/B pairs on one box): the kernel alone 1.125 -> 1.08 ms per launch (0.552 -> 0.576 of the MFMA peak), but the step with the
+    // weight gradients beside the main stream 58.48 -> 58.70 ms -- three resident workgroups hold 140 of the CU's 160 KB of LDS
+    // and the main stream's kernels (43.5 KB per workgroup) wait for a slot.  Default: LDS padded to two workgroups per CU.
+    static const bool occ3 = getenv("URSN_WGRADZ_OCC3") && getenv("URSN_WGRADZ_OCC3")[0] == '1';
+    vg = (p.mode == 3 && !d.in_mean && !use_wgradq(d) && occ3) ? 3 : 2;
+    if (p.mode == 3 && !use_wgradq(d) && !occ3) p.lds += 8 * 1024;
   } else if (!blocked_shape && use_wgrad4(d, p)) vg = 2;
   {  // the per-wave accumulator copies of the final cross-wave sum reuse the plane rings
     const int taps = p.mode == 3 ? 27 : 9;
     size_t red = use_wgradq(d) ? 0
-                 : use_wgradz(d) ? (size_t)(p.mode == 3 ? 4 : 8) * 2 * taps * 64 * sizeof(float)
+                 : use_wgradz(d) ? (size_t)(p.mode == 3 ? 2 : 8) * 2 * taps * 64 * sizeof(float)
                                  : (size_t)4 * taps * p.cin * p.cout * sizeof(float);
     if (red > p.lds) p.lds = red;
   }

@@ -8,7 +8,9 @@
 //     D[(tz4,ty,tx,ci)][8 + co] accumulates tap (tz4-1, ty, tx) for plane z + 1  (valid tz4 >= 1)
 // i.e. 36 tap rows serve 2 x 27 taps: 18 MFMAs per 4-voxel group and plane pair instead of 2 x 14 (Cin = 8).
 // Both column halves cover exactly the workgroup's voxels of their own plane, so image borders need no
-// special case.  Ring of 6 x planes (4 live + 2 in flight), 4 dz planes; the waves are summed in LDS in fixed order,
+// special case.  Ring of 6 x planes (4 live + 2 in flight), 2 dz planes (a wave stages and reads only its OWN 32 voxels of a dz
+// plane, so the two incoming planes overwrite the two live ones once the wave's MFMAs of the step are issued -- no barrier
+// involved; round 4: with 4 dz planes the ring was 55.5 KB, 0.9 KB too much for three workgroups per CU); the waves are summed in LDS in fixed order,
 // two slabs per workgroup (one per column half) go to the deterministic reduce.  Cin = 16 runs as two 8-channel slices.
 #pragma once
 #include "wgrad_tiled_kernel.h"
@@ -16,15 +18,15 @@
 #define URSN_SCHED_PIPELINE 1
 #endif
 
-// 3-D: 4 waves on a 32 x 4 tile (one row per wave), two workgroups per CU so one computes while the other sits in its
-// plane barrier (55 KB LDS each); 2-D: 8 waves x 32 voxels of a 256-wide row.
+// 3-D: 4 waves on a 32 x 4 tile (one row per wave), three workgroups per CU (two with normalise-on-load: 174 VGPRs) so that
+// others compute while one sits in its plane barrier (46.5 KB LDS each); 2-D: 8 waves x 32 voxels of a 256-wide row.
 template <int MODE> struct ZTile;
 template <> struct ZTile<3> { static constexpr int TX = 32, TY = 4, NTY = 3, NT = 27, NW = 4; };
 template <> struct ZTile<2> { static constexpr int TX = 256, TY = 1, NTY = 1, NT = 9, NW = 8; };
 
 // AFF: normalise-on-load of x compiled in (a.aff_* set); the plain instantiation carries none of its selects and branches
 template <int MODE, bool AFF>
-__global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgradArgs a) {
+__global__ __launch_bounds__(ZTile<MODE>::NW * 64, (MODE == 3 && !AFF) ? 3 : 2) void twgradz_kernel(TWgradArgs a) {
   constexpr int CIN = 8, COUT = 8;
   using TL = ZTile<MODE>;
   constexpr int NW = TL::NW, NTHR = 64 * NW, NG = 8;            // 32 voxels = 8 groups of 4 per wave and plane
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
   constexpr int XQ = CIN / 4, DQ = COUT / 4;
   constexpr int NSX = (XQ * PS + NTHR - 1) / NTHR, NSD = (DQ * TX * TY + NTHR - 1) / NTHR;
   constexpr int XPLANE = PS * CIN, DPLANE = TX * TY * COUT;
-  extern __shared__ __attribute__((aligned(16))) float wldz[];  // [6][XPLANE] then [4][DPLANE]
+  extern __shared__ __attribute__((aligned(16))) float wldz[];  // [6][XPLANE] then [2][DPLANE]
   float* xr = wldz;
   float* dr = wldz + 6 * XPLANE;
 
@@ -155,10 +157,11 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
 #pragma unroll
     for (int i = 0; i < NSD; ++i) {
       int idx = tid + i * NTHR;
-      if (idx < DQ * TX * TY) *(wg_f32x4*)(dr + (size_t)(zin & 3) * DPLANE + idx * 4) = sd[i];
+      if (idx < DQ * TX * TY) *(wg_f32x4*)(dr + (size_t)(zin & 1) * DPLANE + idx * 4) = sd[i];
     }
   };
 
+  static_assert(NSD == 1 && DQ * 32 == 64, "dz staging is wave-private: thread t stages quad t % 2 of voxel t / 2 = the voxels its own wave reads");
   wg_f32x4 sxa[NSX], sxb[NSX], sda[NSD], sdb[NSD];
   unsigned inba = 0, inbb = 0;
   int sb[4];   // offsets of planes z - 1 .. z + 2
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
       if constexpr (tzA == tzB) abase[m] = sb[tzA] + a_cm[m];
       else abase[m] = (hi ? sb[tzB] : sb[tzA]) + a_cm[m];
     });
-    const float* dcur = dr + (size_t)((hi ? z + 1 : z) & 3) * DPLANE + b_lane;
+    const float* dcur = dr + (size_t)((hi ? z + 1 : z) & 1) * DPLANE + b_lane;
     wg_static_for<NG>([&](auto G) {
       constexpr int g = decltype(G)::value;
       constexpr int grow = 0;
@@ -225,25 +228,35 @@ __global__ __launch_bounds__(ZTile<MODE>::NW * 64, 2) void twgradz_kernel(TWgrad
   // serialises on LDS latency), then all threads add the copies.  Half 0: columns 0..7 (plane z, tap tz4); half 1:
   // columns 8..15 (plane z+1, tap tz4-1).
   constexpr int NRED = 2 * NT * CIN * COUT;
-  float* part = wldz + (size_t)wave * NRED;
+  // 3-D: TWO copies (waves 0, 1 store, waves 2, 3 add theirs on top: (w0 + w2) + (w1 + w3)) -- four would need 54 KB, more than
+  // the ring; 2-D: one copy per wave (the ring is larger there anyway)
+  constexpr int NCOPY = (MODE == 3) ? 2 : NW;
+  __syncthreads();   // every wave is done with the rings
+  float* part = wldz + (size_t)(wave % NCOPY) * NRED;
+  for (int ph = 0; ph < NW / NCOPY; ++ph) {
+    if (wave / NCOPY == ph) {
 #pragma unroll
-  for (int m = 0; m < NA; ++m) {
+      for (int m = 0; m < NA; ++m) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int row = 4 * kl + r;
-      int tap4 = 2 * m + (row >> 3), ci = row & 7;
-      int tz4 = tap4 / (NTY * 3), rest = tap4 - tz4 * (NTY * 3);
-      int tz = hi ? tz4 - 1 : tz4;
-      if (tz >= 0 && tz <= 2)
-        part[(hi ? NT * CIN * COUT : 0) + ((tz * (NTY * 3) + rest) * CIN + ci) * COUT + (il & 7)] = acc[m][r];
+        for (int r = 0; r < 4; ++r) {
+          int row = 4 * kl + r;
+          int tap4 = 2 * m + (row >> 3), ci = row & 7;
+          int tz4 = tap4 / (NTY * 3), rest = tap4 - tz4 * (NTY * 3);
+          int tz = hi ? tz4 - 1 : tz4;
+          if (tz >= 0 && tz <= 2) {
+            float* q = part + (hi ? NT * CIN * COUT : 0) + ((tz * (NTY * 3) + rest) * CIN + ci) * COUT + (il & 7);
+            *q = ph ? *q + acc[m][r] : acc[m][r];
+          }
+        }
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
   float* slab = a.slab + (size_t)blockIdx.x * (size_t)NRED;
   for (int i = tid; i < NRED; i += NTHR) {
     float v = wldz[i];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) v += wldz[(size_t)w * NRED + i];
+    for (int w = 1; w < NCOPY; ++w) v += wldz[(size_t)w * NRED + i];
     slab[i] = v;
   }
 }
