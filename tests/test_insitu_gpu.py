@@ -68,7 +68,7 @@ SWITCHES = [
     ("fp32", {"URSN_FUSE_BN_BWD_REDUCE": "0", "URSN_FUSE_SHORTCUT_DGRAD": "0", "URSN_FUSE_SHORTCUT_DGRAD_S2": "0", "URSN_RELU_MASK": "0"}),   # (the stride-2 shortcut's data gradient as its own pass too)
     ("fp32", {"URSN_SPLIT_CAT": "0", "URSN_NORM_ON_LOAD": "0"}),    # concat buffer, materialised resnet_conv1 activations
     ("fp32", {"URSN_DISABLE_TILED": "1", "URSN_WGRAD_STREAM": "0"}),
-    ("fp32", {"URSN_S2CONV_V2": "2", "URSN_HEAD_BN_BWD": "0"}),   # stride-2 gather kernel with 16-byte operand reads on every layer it can take; logits-layer BatchNorm-backward sums as a separate pass
+    ("fp32", {"URSN_S2CONV_V2": "2", "URSN_HEAD_BN_BWD": "0", "URSN_WGRADZ_OCC3": "1"}),   # stride-2 gather kernel with 16-byte operand reads on every layer it can take; logits-layer BatchNorm-backward sums as a separate pass
     ("fp32", {"URSN_WGRADQ": "1", "URSN_NORM_ON_LOAD": "2"}),   # 4x4-block weight gradient at level 0 (opt-in, wgradq_tiled_kernel.h)
 ]
 
