@@ -23,6 +23,7 @@ LABEL = [  # rocprof kernel name (regex) -> bench.py kernel label
     (r"s2conv_kernel<3", "s2conv"), (r"s2wgrad_kernel<3>", "s2wgrad"), (r"s2scatter_kernel<3", "s2scatter"),
     (r"dconv_kernel<27, true", "dconv"), (r"dconv_kernel<27, false, false", "dconv_dgrad"),
     (r"tconv_kernel<8, 8, 3, true, false, 1, true", "tconv_dgrad<8,8>+dz"),
+    (r"tdeconv_kernel<16, 8, 3, true", "tdeconv<16,8>"), (r"tdeconv_kernel<16, 8, 3, false, true, true", "tdeconv<16,8>+pw"),
     (r"bn_bwd_apply_kernel", "bn_bwd_apply"), (r"bn_bwd_reduce_kernel", "bn_bwd_reduce"), (r"bn_act_kernel", "bn_act"),
 ]
 if BF16:
