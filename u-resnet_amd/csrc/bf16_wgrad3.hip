@@ -554,13 +554,18 @@ int launch_b3wgrad(const GatherGeom& g, const bf16_t* S, const bf16_t* C, float*
   ursn_note_kernel(g.K == 8 ? (w3_pair(g) ? "b3wgrad_bf16<8,8>(pair)" : "b3wgrad_bf16<8,8>") : (g.Nn == 8 ? "b3wgrad_bf16<16,8>" : "b3wgrad_bf16<16,16>"));
   if (w3_pair(g)) {
     static bool attr = false;
+    // resident workgroups per CU of this weight-gradient kernel beside the main stream's kernels: 49 KB = three (147 of the CU's
+    // 160 KB of LDS); URSN_B3WGRADZ_LDSPAD=<KB> pads the request (16: two, 32: one) -- A/B of the LDS share of the two streams.
+    // Measured (round 4, cfg5, two rounds on one box): 39.11 / 39.19 ms per step at three, 39.00 / 39.12 at two, 39.12 / 39.09 at
+    // one -- unlike fp32's twgradz (conv_tiled.hip, URSN_WGRADZ_OCC3) the share does not matter here; default unchanged
+    static const int lds_z = WZ::LDS + 1024 * (getenv("URSN_B3WGRADZ_LDSPAD") ? atoi(getenv("URSN_B3WGRADZ_LDSPAD")) : 0);
     if (!attr) {
-      URSN_HIP(hipFuncSetAttribute((const void*)b3wgradz_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WZ::LDS));
-      URSN_HIP(hipFuncSetAttribute((const void*)b3wgradz_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WZ::LDS));
+      URSN_HIP(hipFuncSetAttribute((const void*)b3wgradz_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_z));
+      URSN_HIP(hipFuncSetAttribute((const void*)b3wgradz_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_z));
       attr = true;
     }
-    if (aff) hipLaunchKernelGGL(b3wgradz_kernel<true>, dim3(p.grid), dim3(256), WZ::LDS, s, a);
-    else hipLaunchKernelGGL(b3wgradz_kernel<false>, dim3(p.grid), dim3(256), WZ::LDS, s, a);
+    if (aff) hipLaunchKernelGGL(b3wgradz_kernel<true>, dim3(p.grid), dim3(256), lds_z, s, a);
+    else hipLaunchKernelGGL(b3wgradz_kernel<false>, dim3(p.grid), dim3(256), lds_z, s, a);
     URSN_HIP(hipGetLastError());
     URSN_TRY(slab_fold(a.slab, r.nslabs, r.stride, (size_t)WZ::NT * 256, s));
     hipLaunchKernelGGL(b3wgradz_reduce_kernel, dim3(3 * WZ::TPD), dim3(128, 4), 0, s, r);
