@@ -359,7 +359,11 @@ static bool make_wplan(const ursn_conv_desc& d, TWPlan& p, Blocking& b) {
     // and the main stream's kernels (43.5 KB per workgroup) wait for a slot.  Default: LDS padded to two workgroups per CU.
     static const bool occ3 = getenv("URSN_WGRADZ_OCC3") && getenv("URSN_WGRADZ_OCC3")[0] == '1';
     vg = (p.mode == 3 && !d.in_mean && !use_wgradq(d) && occ3) ? 3 : 2;
-    if (p.mode == 3 && !use_wgradq(d) && !occ3) p.lds += 8 * 1024;
+    // (A/B of the other direction, URSN_WGRADZ_LDSPAD=40 = ONE workgroup per CU: the kernel alone 7.0 -> 8.2 ms per step, the
+    // overlapped step 58.86 -> 58.74 ms, two pairs on one box -- the main stream gains what the weight gradients lose; not the
+    // default: 0.2 % against a fifth of the dominant kernel's rate when it runs alone)
+    static const int pad_kb = getenv("URSN_WGRADZ_LDSPAD") ? atoi(getenv("URSN_WGRADZ_LDSPAD")) : 8;
+    if (p.mode == 3 && !use_wgradq(d) && !occ3) p.lds += (size_t)pad_kb * 1024;
   } else if (!blocked_shape && use_wgrad4(d, p)) vg = 2;
   {  // the per-wave accumulator copies of the final cross-wave sum reuse the plane rings
     const int taps = p.mode == 3 ? 27 : 9;
